@@ -1,0 +1,279 @@
+"""oracle -- TEST INFRASTRUCTURE ONLY.
+
+ctypes bindings for the two CPU checkers:
+
+* ``Oracle()``  -> oracle/liboracle.so, our own C restatement of the reference hot path
+  (oracle/ofx_oracle.c, double storage + arithmetic, OpenMP pragmas as in the reference).
+* ``Ref()``     -> oracle/_ref/libofref.so, the reference's own sources compiled by
+  oracle/Makefile where they lie under /root/reference/src (binary only; git-ignored).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product (optical-flow-1_amd, libofx.so) never does, and has no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libofref.so")
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = C.POINTER(C.c_int)
+
+
+def build(verbose=False):
+    """Compile liboracle.so (and _ref/libofref.so when /root/reference is present)."""
+    out = subprocess.run(["make", "-C", HERE], capture_output=True, text=True)
+    if verbose or out.returncode:
+        print(out.stdout, out.stderr)
+    if out.returncode:
+        raise RuntimeError("oracle build failed")
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class _Lib:
+    prefix = ""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " (run `make -C oracle`)")
+        self.lib = C.CDLL(path)
+
+    def _fn(self, name, restype, *argtypes):
+        f = getattr(self.lib, self.prefix + name)
+        f.restype = restype
+        f.argtypes = list(argtypes)
+        return f
+
+    # ---- operators ---------------------------------------------------------------------------
+    def divergence(self, v1, v2):
+        ny, nx = v1.shape
+        out = np.empty((ny, nx))
+        self._fn("divergence", None, _dp, _dp, _dp, C.c_int, C.c_int)(_f64(v1), _f64(v2), out, nx, ny)
+        return out
+
+    def forward_gradient(self, f):
+        ny, nx = f.shape
+        fx, fy = np.empty((ny, nx)), np.empty((ny, nx))
+        self._fn("forward_gradient", None, _dp, _dp, _dp, C.c_int, C.c_int)(_f64(f), fx, fy, nx, ny)
+        return fx, fy
+
+    def centered_gradient(self, f):
+        ny, nx = f.shape
+        fx, fy = np.empty((ny, nx)), np.empty((ny, nx))
+        self._fn("centered_gradient", None, _dp, _dp, _dp, C.c_int, C.c_int)(_f64(f), fx, fy, nx, ny)
+        return fx, fy
+
+    def _second(self, name, f):
+        ny, nx = f.shape
+        out = np.empty((ny, nx))
+        self._fn(name, None, _dp, _dp, C.c_int, C.c_int)(_f64(f), out, nx, ny)
+        return out
+
+    def gaussian(self, I, sigma):
+        ny, nx = I.shape
+        out = _f64(I).copy()
+        rc = self._fn("gaussian", C.c_int, _dp, C.c_int, C.c_int, C.c_double)(out, nx, ny, sigma)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return out
+
+    def bicubic_at(self, I, uu, vv, border_out=False):
+        ny, nx = I.shape
+        return self._fn("bicubic_at", C.c_double, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int)(
+            _f64(I), uu, vv, nx, ny, int(border_out))
+
+    def bicubic_warp(self, I, u, v, border_out=False):
+        ny, nx = I.shape
+        out = np.empty((ny, nx))
+        self._fn("bicubic_warp", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int)(
+            _f64(I), _f64(u), _f64(v), out, nx, ny, int(border_out))
+        return out
+
+    def zoom_size(self, nx, ny, factor):
+        a, b = C.c_int(), C.c_int()
+        self._fn("zoom_size", None, C.c_int, C.c_int, _ip, _ip, C.c_double)(nx, ny, C.byref(a), C.byref(b), factor)
+        return a.value, b.value
+
+    def zoom_out(self, I, factor):
+        ny, nx = I.shape
+        nxx, nyy = self.zoom_size(nx, ny, factor)
+        out = np.empty((nyy, nxx))
+        rc = self._fn("zoom_out", C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double)(_f64(I), out, nx, ny, factor)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return out
+
+    def zoom_in(self, I, nxx, nyy):
+        ny, nx = I.shape
+        out = np.empty((nyy, nxx))
+        self._fn("zoom_in", None, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int)(_f64(I), out, nx, ny, nxx, nyy)
+        return out
+
+    def image_normalization_2(self, I1, I2):
+        a, b = np.empty(I1.shape), np.empty(I2.shape)
+        self._fn("image_normalization_2", None, _dp, _dp, _dp, _dp, C.c_int)(_f64(I1), _f64(I2), a, b, I1.size)
+        return a, b
+
+
+class Oracle(_Lib):
+    """Our C restatement (oracle/ofx_oracle.c)."""
+    prefix = "orc_"
+    kind = "port"
+
+    def __init__(self):
+        super().__init__(ORACLE_SO)
+
+    def set_num_threads(self, n):
+        self._fn("set_num_threads", None, C.c_int)(n)
+
+    def max_threads(self):
+        return self._fn("max_threads", C.c_int)()
+
+    def dxx(self, f): return self._second("dxx", f)
+    def dyy(self, f): return self._second("dyy", f)
+    def dxy(self, f): return self._second("dxy", f)
+
+    def tvl1_single_scale(self, I0, I1, u1, u2, tau=0.25, lam=0.15, theta=0.3, warps=5, epsilon=0.01,
+                          verbose=0):
+        ny, nx = I0.shape
+        u1, u2 = _f64(u1).copy(), _f64(u2).copy()
+        iters = (C.c_int * warps)()
+        errs = np.zeros(warps)
+        self._fn("tvl1_single_scale", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                 C.c_double, C.c_int, C.c_double, C.c_int, _ip, _dp)(
+            _f64(I0), _f64(I1), u1, u2, nx, ny, tau, lam, theta, warps, epsilon, verbose, iters, errs)
+        return u1, u2, list(iters), errs
+
+    def tvl1_multiscale(self, I0, I1, tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5,
+                        epsilon=0.01, verbose=0):
+        ny, nx = I0.shape
+        u1, u2 = np.zeros((ny, nx)), np.zeros((ny, nx))
+        iters = (C.c_int * (warps * nscales))()
+        errs = np.zeros(warps * nscales)
+        rc = self._fn("tvl1_multiscale", C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double,
+                      C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, _ip, _dp)(
+            _f64(I0), _f64(I1), u1, u2, nx, ny, tau, lam, theta, nscales, zfactor, warps, epsilon, verbose,
+            iters, errs)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return u1, u2, np.array(list(iters)).reshape(nscales, warps), errs.reshape(nscales, warps)
+
+    def tvl1_iterations(self, u1, u2, p11, p12, p21, p22, I1wx, I1wy, rho_c, grad, tau, lam, theta, n_iter):
+        """In place on the six state arrays; returns the last error."""
+        ny, nx = u1.shape
+        return self._fn("tvl1_iterations", C.c_double, *([_dp] * 10), C.c_int, C.c_int, C.c_double, C.c_double,
+                        C.c_double, C.c_int)(u1, u2, p11, p12, p21, p22, _f64(I1wx), _f64(I1wy), _f64(rho_c),
+                                             _f64(grad), nx, ny, tau, lam, theta, n_iter)
+
+    def hs_single_scale(self, I1, I2, u, v, alpha=7.0, warps=10, TOL=1e-4, maxiter=150, verbose=0):
+        ny, nx = I1.shape
+        u, v = _f64(u).copy(), _f64(v).copy()
+        iters = (C.c_int * warps)()
+        self._fn("hs_single_scale", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int,
+                 C.c_double, C.c_int, C.c_int, _ip)(_f64(I1), _f64(I2), u, v, nx, ny, alpha, warps, TOL, maxiter,
+                                                    verbose, iters)
+        return u, v, list(iters)
+
+    def hs_pyramidal(self, I1, I2, alpha=7.0, nscales=10, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150,
+                     verbose=0):
+        ny, nx = I1.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        iters = (C.c_int * (warps * nscales))()
+        rc = self._fn("hs_pyramidal", C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int,
+                      C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, _ip)(
+            _f64(I1), _f64(I2), u, v, nx, ny, alpha, nscales, zfactor, warps, TOL, maxiter, verbose, iters)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return u, v, np.array(list(iters)).reshape(nscales, warps)
+
+    def brox_spatial(self, I1, I2, alpha=50.0, gamma=10.0, nscales=10, nu=0.5, TOL=1e-4, inner=1, outer=15,
+                     verbose=0):
+        ny, nx = I1.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        iters = (C.c_int * (inner * outer * nscales))()
+        rc = self._fn("brox_spatial", C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                      C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _ip)(
+            _f64(I1), _f64(I2), u, v, nx, ny, alpha, gamma, nscales, nu, TOL, inner, outer, verbose, iters)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return u, v, np.array(list(iters)).reshape(nscales, inner * outer)
+
+
+class Ref(_Lib):
+    """The compiled reference itself (oracle/_ref/libofref.so via oracle/ref_shim.cpp)."""
+    prefix = "ref_"
+    kind = "reference"
+
+    def __init__(self):
+        super().__init__(REF_SO)
+
+    def set_num_threads(self, n):
+        self._fn("set_num_threads", None, C.c_int)(n)
+
+    def max_threads(self):
+        return self._fn("max_threads", C.c_int)()
+
+    def dxx(self, f): return self._second("Dxx", f)
+    def dyy(self, f): return self._second("Dyy", f)
+    def dxy(self, f): return self._second("Dxy", f)
+
+    def tvl1_single_scale(self, I0, I1, u1, u2, tau=0.25, lam=0.15, theta=0.3, warps=5, epsilon=0.01,
+                          verbose=0):
+        ny, nx = I0.shape
+        u1, u2 = _f64(u1).copy(), _f64(u2).copy()
+        self._fn("tvl1_single_scale", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                 C.c_double, C.c_int, C.c_double, C.c_int)(
+            _f64(I0).copy(), _f64(I1).copy(), u1, u2, nx, ny, tau, lam, theta, warps, epsilon, verbose)
+        return u1, u2
+
+    def tvl1_multiscale(self, I0, I1, tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5,
+                        epsilon=0.01, verbose=0):
+        ny, nx = I0.shape
+        u1, u2 = np.zeros((ny, nx)), np.zeros((ny, nx))
+        rc = self._fn("tvl1_multiscale", C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double,
+                      C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int)(
+            _f64(I0).copy(), _f64(I1).copy(), u1, u2, nx, ny, tau, lam, theta, nscales, zfactor, warps,
+            epsilon, verbose)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return u1, u2
+
+    def hs_single_scale(self, I1, I2, u, v, alpha=7.0, warps=10, TOL=1e-4, maxiter=150, verbose=0):
+        ny, nx = I1.shape
+        u, v = _f64(u).copy(), _f64(v).copy()
+        self._fn("hs_single_scale", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int,
+                 C.c_double, C.c_int, C.c_int)(_f64(I1), _f64(I2), u, v, nx, ny, alpha, warps, TOL, maxiter, verbose)
+        return u, v
+
+    def hs_pyramidal(self, I1, I2, alpha=7.0, nscales=10, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150,
+                     verbose=0):
+        ny, nx = I1.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        rc = self._fn("hs_pyramidal", C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int,
+                      C.c_double, C.c_int, C.c_double, C.c_int, C.c_int)(
+            _f64(I1), _f64(I2), u, v, nx, ny, alpha, nscales, zfactor, warps, TOL, maxiter, verbose)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return u, v
+
+    def brox_spatial(self, I1, I2, alpha=50.0, gamma=10.0, nscales=10, nu=0.5, TOL=1e-4, inner=1, outer=15,
+                     verbose=0):
+        ny, nx = I1.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        rc = self._fn("brox_spatial", C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                      C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int)(
+            _f64(I1), _f64(I2), u, v, nx, ny, alpha, gamma, nscales, nu, TOL, inner, outer, verbose)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return u, v

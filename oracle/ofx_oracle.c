@@ -1,0 +1,916 @@
+/* oracle/ofx_oracle.c -- TEST INFRASTRUCTURE ONLY (see ofx_oracle.h).
+ *
+ * Plain-C restatement of the reference hot path, double storage + double arithmetic, same
+ * association order as the reference expressions so that it is bit-identical to the compiled
+ * reference with one OpenMP thread (checked in tests/test_oracle_vs_ref.py).  Border handling is
+ * written as clamped / predicated index arithmetic wherever that is provably the same IEEE
+ * expression as the reference's separate border loops; where the reference associates border
+ * terms differently (divergence first/last column) the exact order is kept.
+ *
+ * Every function cites the reference lines it follows (paths relative to /root/reference/).
+ */
+#include "ofx_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TVL1_MAX_ITERATIONS   300      /* src/tvl1flow.cpp:22 */
+#define TVL1_PRESMOOTH_SIGMA  0.8      /* src/tvl1flow.cpp:23 */
+#define TVL1_GRAD_IS_ZERO     1E-10    /* src/tvl1flow.cpp:24 */
+#define ZOOM_SIGMA_ZERO       0.6      /* src/zoom.cpp:15 */
+#define GAUSS_WINDOW          5        /* src/operators.h:120 */
+#define HS_SOR_W              1.9      /* src/horn_schunck_pyramidal.cpp:21 */
+#define HS_PRESMOOTH_SIGMA    0.8      /* src/horn_schunck_pyramidal.cpp:22 */
+#define BROX_EPSILON          0.001    /* src/brox_optic_flow_spatial.cpp:23 */
+#define BROX_MAXITER          300      /* src/brox_optic_flow_spatial.cpp:24 */
+#define BROX_SOR_W            1.9      /* src/brox_optic_flow_spatial.cpp:25 */
+#define BROX_SIGMA            0.8      /* src/brox_optic_flow_spatial.cpp:26 */
+
+static double *dalloc(size_t n)
+{
+    double *p = (double *) malloc((n ? n : 1) * sizeof(double));
+    if (!p) { fprintf(stderr, "oracle: out of memory\n"); abort(); }
+    return p;
+}
+
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void) n;
+#endif
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/operators.cpp:35-78  backward-difference divergence.
+ * interior: (v1[p]-v1[p-1]) + (v2[p]-v2[p-nx]).  Rows 0 / ny-1 drop one v2 term and keep the
+ * interior association; columns 0 / nx-1 are written by the reference as ((a + b) - c)
+ * (operators.cpp:70-71), which is NOT the interior association, so they get their own branch. */
+void orc_divergence(const double *v1, const double *v2, double *div, int nx, int ny)
+{
+    #pragma omp parallel for schedule(dynamic)
+    for (int i = 0; i < ny; i++) {
+        const int top = (i == 0), bot = (i == ny - 1);
+        for (int j = 0; j < nx; j++) {
+            const int p = i * nx + j;
+            const int lef = (j == 0), rig = (j == nx - 1);
+            double d;
+            if (!lef && !rig) {
+                const double dxv = v1[p] - v1[p - 1];
+                if (top)      d = dxv + v2[p];                 /* :61 */
+                else if (bot) d = dxv - v2[p - nx];            /* :62 */
+                else          d = dxv + (v2[p] - v2[p - nx]);  /* :50-53 */
+            } else if (lef) {
+                if (top)      d = v1[p] + v2[p];               /* :74 */
+                else if (bot) d = v1[p] - v2[p - nx];          /* :76 */
+                else          d = v1[p] + v2[p] - v2[p - nx];  /* :70 */
+            } else {
+                if (top)      d = -v1[p - 1] + v2[p];              /* :75 */
+                else if (bot) d = -v1[p - 1] - v2[p - nx];         /* :77 */
+                else          d = -v1[p - 1] + v2[p] - v2[p - nx]; /* :71 */
+            }
+            div[p] = d;
+        }
+    }
+}
+
+/* src/operators.cpp:86-125  forward-difference gradient, zero across the right / bottom edge */
+void orc_forward_gradient(const double *f, double *fx, double *fy, int nx, int ny)
+{
+    #pragma omp parallel for schedule(dynamic)
+    for (int i = 0; i < ny; i++) {
+        for (int j = 0; j < nx; j++) {
+            const int p = i * nx + j;
+            fx[p] = (j < nx - 1) ? f[p + 1] - f[p] : 0.0;
+            fy[p] = (i < ny - 1) ? f[p + nx] - f[p] : 0.0;
+        }
+    }
+}
+
+/* src/operators.cpp:335-406 (nz = 1)  centred differences; at the border the missing neighbour
+ * is the pixel itself and the factor stays 1/2 (:363-404) == clamped indices. */
+void orc_centered_gradient(const double *f, double *dx, double *dy, int nx, int ny)
+{
+    #pragma omp parallel for
+    for (int i = 0; i < ny; i++) {
+        const int iu = (i > 0) ? i - 1 : 0, id = (i < ny - 1) ? i + 1 : ny - 1;
+        for (int j = 0; j < nx; j++) {
+            const int jl = (j > 0) ? j - 1 : 0, jr = (j < nx - 1) ? j + 1 : nx - 1;
+            dx[i * nx + j] = 0.5 * (f[i * nx + jr] - f[i * nx + jl]);
+            dy[i * nx + j] = 0.5 * (f[id * nx + j] - f[iu * nx + j]);
+        }
+    }
+}
+
+/* src/operators.cpp:132-256 mask3x3 (nz = 1).  Taps that fall outside are folded onto the edge
+ * sample and their weights are summed BEFORE the multiply (e.g. first row: in[j-1]*(m0+m3), :168);
+ * the products are accumulated in row-major order of the distinct clamped taps. */
+static void mask3x3(const double *in, double *out, int nx, int ny, const double *m)
+{
+    #pragma omp parallel for
+    for (int i = 0; i < ny; i++) {
+        for (int j = 0; j < nx; j++) {
+            int rr[3], cc[3];
+            for (int l = 0; l < 3; l++) {
+                int r = i + l - 1, c = j + l - 1;
+                rr[l] = r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r);
+                cc[l] = c < 0 ? 0 : (c > nx - 1 ? nx - 1 : c);
+            }
+            double sum = 0;
+            for (int l = 0; l < 3; l++) {
+                if (l > 0 && rr[l] == rr[l - 1]) continue;           /* merged into an earlier row */
+                for (int q = 0; q < 3; q++) {
+                    if (q > 0 && cc[q] == cc[q - 1]) continue;       /* merged into an earlier col */
+                    double w = 0;
+                    int first = 1;
+                    for (int l2 = 0; l2 < 3; l2++) {
+                        if (rr[l2] != rr[l]) continue;
+                        for (int q2 = 0; q2 < 3; q2++) {
+                            if (cc[q2] != cc[q]) continue;
+                            w = first ? m[l2 * 3 + q2] : w + m[l2 * 3 + q2];
+                            first = 0;
+                        }
+                    }
+                    sum += in[rr[l] * nx + cc[q]] * w;
+                }
+            }
+            out[i * nx + j] = sum;
+        }
+    }
+}
+
+/* src/operators.cpp:263-328 */
+void orc_dxx(const double *f, double *out, int nx, int ny)
+{
+    const double m[9] = { 0., 0., 0., 1., -2., 1., 0., 0., 0. };
+    mask3x3(f, out, nx, ny, m);
+}
+
+void orc_dyy(const double *f, double *out, int nx, int ny)
+{
+    const double m[9] = { 0., 1., 0., 0., -2., 0., 0., 1., 0. };
+    mask3x3(f, out, nx, ny, m);
+}
+
+void orc_dxy(const double *f, double *out, int nx, int ny)
+{
+    const double m[9] = { 1. / 4., 0., -1. / 4., 0., 0., 0., -1. / 4., 0., 1. / 4. };
+    mask3x3(f, out, nx, ny, m);
+}
+
+/* src/operators.cpp:506-624, default arguments (reflecting boundary, window 5).
+ * Kernel radius size = (int)(5 sigma) + 1 (:516); taps B[i] = 1/(sigma sqrt(2*3.1415926)) *
+ * exp(-i*i/(2 sigma^2)) normalised by 2*sum(B) - B[0] (:524-539).  Row pass over the whole image,
+ * then column pass on the row-smoothed image, both in place (:544-619).  Reflection (:557-562):
+ * sample t < 0 reads I[-t] (edge not repeated); sample t >= n reads I[2n-1-t] (edge repeated).
+ * The reference is serial here (no OpenMP) and so is this. */
+static int gauss_taps(double sigma, double **Bout)
+{
+    const double den = 2 * sigma * sigma;
+    const int size = (int) (GAUSS_WINDOW * sigma) + 1;
+    double *B = dalloc((size_t) size);
+    for (int i = 0; i < size; i++)
+        B[i] = 1 / (sigma * sqrt(2.0 * 3.1415926)) * exp(-i * i / den);
+    double norm = 0;
+    for (int i = 0; i < size; i++) norm += B[i];
+    norm *= 2;
+    norm -= B[0];
+    for (int i = 0; i < size; i++) B[i] /= norm;
+    *Bout = B;
+    return size;
+}
+
+static inline int gauss_reflect(int t, int n)
+{
+    return t < 0 ? -t : (t >= n ? 2 * n - 1 - t : t);
+}
+
+int orc_gaussian(double *I, int nx, int ny, double sigma)
+{
+    double *B;
+    const int size = gauss_taps(sigma, &B);
+    if (size > nx) { free(B); return 1; }        /* :520-522 throws */
+    /* The reference reads out of bounds when size >= ny or size == nx; mirror its column pass only
+     * when that is safe and report the same error otherwise. */
+    if (size >= ny || size >= nx) { free(B); return 1; }
+
+    double *line = dalloc((size_t) (nx > ny ? nx : ny));
+    for (int k = 0; k < ny; k++) {
+        double *row = I + (size_t) k * nx;
+        for (int x = 0; x < nx; x++) {
+            double sum = B[0] * row[x];
+            for (int j = 1; j < size; j++)
+                sum += B[j] * (row[gauss_reflect(x - j, nx)] + row[gauss_reflect(x + j, nx)]);
+            line[x] = sum;
+        }
+        memcpy(row, line, (size_t) nx * sizeof(double));
+    }
+    for (int k = 0; k < nx; k++) {
+        for (int y = 0; y < ny; y++) {
+            double sum = B[0] * I[(size_t) y * nx + k];
+            for (int j = 1; j < size; j++)
+                sum += B[j] * (I[(size_t) gauss_reflect(y - j, ny) * nx + k] +
+                               I[(size_t) gauss_reflect(y + j, ny) * nx + k]);
+            line[y] = sum;
+        }
+        for (int y = 0; y < ny; y++) I[(size_t) y * nx + k] = line[y];
+    }
+    free(line);
+    free(B);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/bicubic_interpolation.cpp:24-39 */
+static inline int clamp_flag(int x, int n, int *out)
+{
+    if (x < 0)  { *out = 1; return 0; }
+    if (x >= n) { *out = 1; return n - 1; }
+    return x;
+}
+
+/* src/bicubic_interpolation.cpp:108-123  Keys cubic (a = -1/2) in the reference's Horner form */
+static inline double cubic_cell(double v0, double v1, double v2, double v3, double x)
+{
+    return v1 + 0.5 * x * (v2 - v0 + x * (2.0 * v0 - 5.0 * v1 + 4.0 * v2 - v3
+                                          + x * (3.0 * (v1 - v2) + v3 - v0)));
+}
+
+/* src/bicubic_interpolation.cpp:153-245 with BOUNDARY_CONDITION 0 (Neumann).
+ * Quirks kept: truncation (int)uu toward zero (:170); tap direction follows the sign of the
+ * coordinate (:162-163); `my` uses sx, not sy (:173); the fractional offset is taken against the
+ * CLAMPED base index (:243); any clamped tap zeroes the sample when border_out (:214-215);
+ * columns are interpolated in y first, then one cubic in x (:130-145, :236-243). */
+double orc_bicubic_at(const double *in, double uu, double vv, int nx, int ny, int border_out)
+{
+    const int sx = (uu < 0) ? -1 : 1;
+    const int sy = (vv < 0) ? -1 : 1;
+    int out = 0;
+    const int x   = clamp_flag((int) uu, nx, &out);
+    const int y   = clamp_flag((int) vv, ny, &out);
+    const int mx  = clamp_flag((int) uu - sx, nx, &out);
+    const int my  = clamp_flag((int) vv - sx, ny, &out);
+    const int dx  = clamp_flag((int) uu + sx, nx, &out);
+    const int dy  = clamp_flag((int) vv + sy, ny, &out);
+    const int ddx = clamp_flag((int) uu + 2 * sx, nx, &out);
+    const int ddy = clamp_flag((int) vv + 2 * sy, ny, &out);
+
+    if (out && border_out) return 0.0;
+
+    const double fx = uu - x, fy = vv - y;
+    const int col[4] = { mx, x, dx, ddx };
+    double c[4];
+    for (int k = 0; k < 4; k++)
+        c[k] = cubic_cell(in[col[k] + nx * my], in[col[k] + nx * y],
+                          in[col[k] + nx * dy], in[col[k] + nx * ddy], fy);
+    return cubic_cell(c[0], c[1], c[2], c[3], fx);
+}
+
+/* src/bicubic_interpolation.cpp:352-374 */
+void orc_bicubic_warp(const double *in, const double *u, const double *v, double *out,
+                      int nx, int ny, int border_out)
+{
+    #pragma omp parallel for
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++) {
+            const int p = i * nx + j;
+            out[p] = orc_bicubic_at(in, j + u[p], i + v[p], nx, ny, border_out);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/zoom.cpp:22-34 */
+void orc_zoom_size(int nx, int ny, int *nxx, int *nyy, double factor)
+{
+    *nxx = (int) (nx * factor + 0.5);
+    *nyy = (int) (ny * factor + 0.5);
+}
+
+/* src/zoom.cpp:41-78 */
+int orc_zoom_out(const double *I, double *Iout, int nx, int ny, double factor)
+{
+    double *Is = dalloc((size_t) nx * ny);
+    memcpy(Is, I, (size_t) nx * ny * sizeof(double));
+    int nxx, nyy;
+    orc_zoom_size(nx, ny, &nxx, &nyy, factor);
+    const double sigma = ZOOM_SIGMA_ZERO * sqrt(1.0 / (factor * factor) - 1.0);
+    if (orc_gaussian(Is, nx, ny, sigma)) { free(Is); return 1; }
+    #pragma omp parallel for
+    for (int i1 = 0; i1 < nyy; i1++)
+        for (int j1 = 0; j1 < nxx; j1++) {
+            const double i2 = i1 / factor, j2 = j1 / factor;
+            Iout[i1 * nxx + j1] = orc_bicubic_at(Is, j2, i2, nx, ny, 0);
+        }
+    free(Is);
+    return 0;
+}
+
+/* src/zoom.cpp:132-155 */
+void orc_zoom_in(const double *I, double *Iout, int nx, int ny, int nxx, int nyy)
+{
+    const double factorx = ((double) nxx / nx);
+    const double factory = ((double) nyy / ny);
+    #pragma omp parallel for
+    for (int i1 = 0; i1 < nyy; i1++)
+        for (int j1 = 0; j1 < nxx; j1++) {
+            const double i2 = i1 / factory, j2 = j1 / factorx;
+            Iout[i1 * nxx + j1] = orc_bicubic_at(I, j2, i2, nx, ny, 0);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/utils.cpp:283-326 + getminmax :509-525 */
+void orc_image_normalization_2(const double *I1, const double *I2, double *I1n, double *I2n, int size)
+{
+    double lo = I1[0], hi = I1[0];
+    for (int i = 1; i < size; i++) { if (I1[i] < lo) lo = I1[i]; if (I1[i] > hi) hi = I1[i]; }
+    double lo2 = I2[0], hi2 = I2[0];
+    for (int i = 1; i < size; i++) { if (I2[i] < lo2) lo2 = I2[i]; if (I2[i] > hi2) hi2 = I2[i]; }
+    if (hi2 > hi) hi = hi2;
+    if (lo2 < lo) lo = lo2;
+    const double den = hi - lo;
+    if (den > 0) {
+        #pragma omp parallel for
+        for (int i = 0; i < size; i++) {
+            I1n[i] = 255.0 * (I1[i] - lo) / den;
+            I2n[i] = 255.0 * (I2[i] - lo) / den;
+        }
+    } else {
+        #pragma omp parallel for
+        for (int i = 0; i < size; i++) { I1n[i] = I1[i]; I2n[i] = I2[i]; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* TV-L1 inner iterations, src/tvl1flow.cpp:113-182: five separate sweeps per iteration exactly as
+ * the reference runs them (threshold -> div p -> u update + error -> grad u -> dual update). */
+typedef struct {
+    double *v1, *v2, *div_p1, *div_p2, *u1x, *u1y, *u2x, *u2y;
+} tvl1_scratch;
+
+static void tvl1_scratch_alloc(tvl1_scratch *s, size_t n)
+{
+    s->v1 = dalloc(n); s->v2 = dalloc(n); s->div_p1 = dalloc(n); s->div_p2 = dalloc(n);
+    s->u1x = dalloc(n); s->u1y = dalloc(n); s->u2x = dalloc(n); s->u2y = dalloc(n);
+}
+
+static void tvl1_scratch_free(tvl1_scratch *s)
+{
+    free(s->v1); free(s->v2); free(s->div_p1); free(s->div_p2);
+    free(s->u1x); free(s->u1y); free(s->u2x); free(s->u2y);
+}
+
+static double tvl1_one_iteration(double *u1, double *u2, double *p11, double *p12, double *p21,
+                                 double *p22, const double *I1wx, const double *I1wy,
+                                 const double *rho_c, const double *grad, tvl1_scratch *s,
+                                 int nx, int ny, double tau, double theta, double l_t)
+{
+    const int size = nx * ny;
+    double *v1 = s->v1, *v2 = s->v2;
+
+    /* thresholding operator TH, :117-143 */
+    #pragma omp parallel for
+    for (int i = 0; i < size; i++) {
+        const double rho = rho_c[i] + (I1wx[i] * u1[i] + I1wy[i] * u2[i]);
+        double d1, d2;
+        if (rho < -l_t * grad[i]) {
+            d1 = l_t * I1wx[i];
+            d2 = l_t * I1wy[i];
+        } else if (rho > l_t * grad[i]) {
+            d1 = -l_t * I1wx[i];
+            d2 = -l_t * I1wy[i];
+        } else if (grad[i] < TVL1_GRAD_IS_ZERO) {
+            d1 = d2 = 0;
+        } else {
+            const double fi = -rho / grad[i];
+            d1 = fi * I1wx[i];
+            d2 = fi * I1wy[i];
+        }
+        v1[i] = u1[i] + d1;
+        v2[i] = u2[i] + d2;
+    }
+
+    orc_divergence(p11, p12, s->div_p1, nx, ny);      /* :146 */
+    orc_divergence(p21, p22, s->div_p2, nx, ny);      /* :147 */
+
+    /* primal update + convergence error, :150-162 */
+    double error = 0.0;
+    #pragma omp parallel for reduction(+:error)
+    for (int i = 0; i < size; i++) {
+        const double u1k = u1[i], u2k = u2[i];
+        u1[i] = v1[i] + theta * s->div_p1[i];
+        u2[i] = v2[i] + theta * s->div_p2[i];
+        error += (u1[i] - u1k) * (u1[i] - u1k) + (u2[i] - u2k) * (u2[i] - u2k);
+    }
+    error /= size;
+
+    orc_forward_gradient(u1, s->u1x, s->u1y, nx, ny); /* :165 */
+    orc_forward_gradient(u2, s->u2x, s->u2y, nx, ny); /* :166 */
+
+    /* dual update, :169-181 */
+    #pragma omp parallel for
+    for (int i = 0; i < size; i++) {
+        const double taut = tau / theta;
+        const double g1 = hypot(s->u1x[i], s->u1y[i]);
+        const double g2 = hypot(s->u2x[i], s->u2y[i]);
+        const double ng1 = 1.0 + taut * g1;
+        const double ng2 = 1.0 + taut * g2;
+        p11[i] = (p11[i] + taut * s->u1x[i]) / ng1;
+        p12[i] = (p12[i] + taut * s->u1y[i]) / ng1;
+        p21[i] = (p21[i] + taut * s->u2x[i]) / ng2;
+        p22[i] = (p22[i] + taut * s->u2y[i]) / ng2;
+    }
+    return error;
+}
+
+double orc_tvl1_iterations(double *u1, double *u2, double *p11, double *p12, double *p21, double *p22,
+                           const double *I1wx, const double *I1wy, const double *rho_c,
+                           const double *grad, int nx, int ny, double tau, double lambda,
+                           double theta, int n_iter)
+{
+    tvl1_scratch s;
+    tvl1_scratch_alloc(&s, (size_t) nx * ny);
+    double error = INFINITY;
+    for (int n = 0; n < n_iter; n++)
+        error = tvl1_one_iteration(u1, u2, p11, p12, p21, p22, I1wx, I1wy, rho_c, grad, &s,
+                                   nx, ny, tau, theta, lambda * theta);
+    tvl1_scratch_free(&s);
+    return error;
+}
+
+/* src/tvl1flow.cpp:46-212 */
+void orc_tvl1_single_scale(const double *I0, const double *I1, double *u1, double *u2, int nx, int ny,
+                           double tau, double lambda, double theta, int warps, double epsilon,
+                           int verbose, int *iters, double *errs)
+{
+    const int size = nx * ny;
+    const size_t n = (size_t) size;
+    const double l_t = lambda * theta;
+    double *I1x = dalloc(n), *I1y = dalloc(n), *I1w = dalloc(n), *I1wx = dalloc(n), *I1wy = dalloc(n);
+    double *rho_c = dalloc(n), *grad = dalloc(n);
+    double *p11 = dalloc(n), *p12 = dalloc(n), *p21 = dalloc(n), *p22 = dalloc(n);
+    tvl1_scratch s;
+    tvl1_scratch_alloc(&s, n);
+
+    orc_centered_gradient(I1, I1x, I1y, nx, ny);                       /* :84 */
+    for (int i = 0; i < size; i++) p11[i] = p12[i] = p21[i] = p22[i] = 0.0;   /* :87-90 */
+
+    for (int w = 0; w < warps; w++) {
+        orc_bicubic_warp(I1,  u1, u2, I1w,  nx, ny, 1);                /* :94-96 */
+        orc_bicubic_warp(I1x, u1, u2, I1wx, nx, ny, 1);
+        orc_bicubic_warp(I1y, u1, u2, I1wy, nx, ny, 1);
+
+        #pragma omp parallel for
+        for (int i = 0; i < size; i++) {                               /* :98-109 */
+            const double Ix2 = I1wx[i] * I1wx[i];
+            const double Iy2 = I1wy[i] * I1wy[i];
+            grad[i] = (Ix2 + Iy2);
+            rho_c[i] = (I1w[i] - I1wx[i] * u1[i] - I1wy[i] * u2[i] - I0[i]);
+        }
+
+        int it = 0;
+        double error = INFINITY;
+        while (error > epsilon * epsilon && it < TVL1_MAX_ITERATIONS) {  /* :113 */
+            it++;
+            error = tvl1_one_iteration(u1, u2, p11, p12, p21, p22, I1wx, I1wy, rho_c, grad, &s,
+                                       nx, ny, tau, theta, l_t);
+        }
+        if (verbose)
+            fprintf(stderr, "Warping: %d, Iterations: %d, Error: %f\n", w, it, error);  /* :184-188 */
+        if (iters) iters[w] = it;
+        if (errs) errs[w] = error;
+    }
+
+    tvl1_scratch_free(&s);
+    free(I1x); free(I1y); free(I1w); free(I1wx); free(I1wy); free(rho_c); free(grad);
+    free(p11); free(p12); free(p21); free(p22);
+}
+
+/* Shared pyramid prologue: src/tvl1flow.cpp:236-280, horn_schunck_pyramidal.cpp:279-323,
+ * brox_optic_flow_spatial.cpp:467-509 are the same code. */
+typedef struct {
+    int nscales;
+    int *nx, *ny;
+    double **A, **B, **u, **v;
+} pyramid;
+
+static int pyramid_build(pyramid *P, const double *Ia, const double *Ib, double *u, double *v,
+                         int nx, int ny, int nscales, double zfactor, double presmooth)
+{
+    P->nscales = nscales;
+    P->nx = (int *) malloc(sizeof(int) * nscales);
+    P->ny = (int *) malloc(sizeof(int) * nscales);
+    P->A = (double **) calloc(nscales, sizeof(double *));
+    P->B = (double **) calloc(nscales, sizeof(double *));
+    P->u = (double **) calloc(nscales, sizeof(double *));
+    P->v = (double **) calloc(nscales, sizeof(double *));
+    P->nx[0] = nx; P->ny[0] = ny;
+    P->A[0] = dalloc((size_t) nx * ny);
+    P->B[0] = dalloc((size_t) nx * ny);
+    P->u[0] = u; P->v[0] = v;
+    int rc = 0;
+    orc_image_normalization_2(Ia, Ib, P->A[0], P->B[0], nx * ny);
+    rc |= orc_gaussian(P->A[0], nx, ny, presmooth);
+    rc |= orc_gaussian(P->B[0], nx, ny, presmooth);
+    for (int s = 1; s < nscales && !rc; s++) {
+        orc_zoom_size(P->nx[s - 1], P->ny[s - 1], &P->nx[s], &P->ny[s], zfactor);
+        const size_t n = (size_t) P->nx[s] * P->ny[s];
+        P->A[s] = dalloc(n); P->B[s] = dalloc(n); P->u[s] = dalloc(n); P->v[s] = dalloc(n);
+        rc |= orc_zoom_out(P->A[s - 1], P->A[s], P->nx[s - 1], P->ny[s - 1], zfactor);
+        rc |= orc_zoom_out(P->B[s - 1], P->B[s], P->nx[s - 1], P->ny[s - 1], zfactor);
+    }
+    if (!rc) {
+        const int c = nscales - 1;
+        for (int i = 0; i < P->nx[c] * P->ny[c]; i++) P->u[c][i] = P->v[c][i] = 0.0;
+    }
+    return rc;
+}
+
+/* zoom the flow to the next finer level and rescale it: tvl1flow.cpp:302-309 */
+static void pyramid_upsample(pyramid *P, int s, double zfactor)
+{
+    orc_zoom_in(P->u[s], P->u[s - 1], P->nx[s], P->ny[s], P->nx[s - 1], P->ny[s - 1]);
+    orc_zoom_in(P->v[s], P->v[s - 1], P->nx[s], P->ny[s], P->nx[s - 1], P->ny[s - 1]);
+    const int n = P->nx[s - 1] * P->ny[s - 1];
+    for (int i = 0; i < n; i++) {
+        P->u[s - 1][i] *= 1.0 / zfactor;
+        P->v[s - 1][i] *= 1.0 / zfactor;
+    }
+}
+
+static void pyramid_free(pyramid *P)
+{
+    for (int s = 0; s < P->nscales; s++) {
+        free(P->A[s]); free(P->B[s]);
+        if (s) { free(P->u[s]); free(P->v[s]); }
+    }
+    free(P->A); free(P->B); free(P->u); free(P->v); free(P->nx); free(P->ny);
+}
+
+/* src/tvl1flow.cpp:219-328 */
+int orc_tvl1_multiscale(const double *I0, const double *I1, double *u1, double *u2, int nx, int ny,
+                        double tau, double lambda, double theta, int nscales, double zfactor,
+                        int warps, double epsilon, int verbose, int *iters, double *errs)
+{
+    pyramid P;
+    int rc = pyramid_build(&P, I0, I1, u1, u2, nx, ny, nscales, zfactor, TVL1_PRESMOOTH_SIGMA);
+    for (int s = nscales - 1; s >= 0 && !rc; s--) {
+        if (verbose) fprintf(stderr, "Scale %d: %dx%d\n", s, P.nx[s], P.ny[s]);
+        orc_tvl1_single_scale(P.A[s], P.B[s], P.u[s], P.v[s], P.nx[s], P.ny[s], tau, lambda, theta,
+                              warps, epsilon, verbose, iters ? iters + s * warps : NULL,
+                              errs ? errs + s * warps : NULL);
+        if (s) pyramid_upsample(&P, s, zfactor);
+    }
+    pyramid_free(&P);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Horn-Schunck SOR point update, src/horn_schunck_pyramidal.cpp:31-71.  nb[0..3] = diagonal
+ * neighbours (weight 1/12), nb[4..7] = axial neighbours (weight 1/6), in the reference order
+ * p1..p8; v is updated with the NEW u (:66-67). */
+static inline double hs_sor_point(const double *Au, const double *Av, const double *Du,
+                                  const double *Dv, const double *D, double *u, double *v,
+                                  double al, int p, int p1, int p2, int p3, int p4, int p5, int p6,
+                                  int p7, int p8)
+{
+    const double w = HS_SOR_W;
+    const double ula = 1. / 12. * (u[p1] + u[p2] + u[p3] + u[p4]) + 1. / 6. * (u[p5] + u[p6] + u[p7] + u[p8]);
+    const double vla = 1. / 12. * (v[p1] + v[p2] + v[p3] + v[p4]) + 1. / 6. * (v[p5] + v[p6] + v[p7] + v[p8]);
+    const double uk = u[p], vk = v[p];
+    u[p] = (1.0 - w) * uk + w * (Au[p] - D[p] * v[p] + al * ula) / Du[p];
+    v[p] = (1.0 - w) * vk + w * (Av[p] - D[p] * u[p] + al * vla) / Dv[p];
+    return (u[p] - uk) * (u[p] - uk) + (v[p] - vk) * (v[p] - vk);
+}
+
+/* One full sweep in the reference's visiting order (:143-231): interior rows lexicographic (under
+ * the reference's racy `omp parallel for`, deterministic with one thread), then first/last row
+ * interleaved per column, first/last column interleaved per row, then the four corners.  Border
+ * pixels replace missing neighbours by replicated indices exactly as :161-228 pass them. */
+static double hs_sweep(const double *Au, const double *Av, const double *Du, const double *Dv,
+                       const double *D, double *u, double *v, double a2, int nx, int ny)
+{
+    double error = 0;
+    #pragma omp parallel for reduction(+:error)
+    for (int i = 1; i < ny - 1; i++)
+        for (int j = 1; j < nx - 1; j++) {
+            const int k = i * nx + j;
+            error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, k, k - nx - 1, k - nx + 1,
+                                  k + nx - 1, k + nx + 1, k - nx, k - 1, k + nx, k + 1);
+        }
+    for (int j = 1; j < nx - 1; j++) {
+        int k = j;
+        error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, k, k - 1, k + 1, k + nx - 1, k + nx + 1,
+                              k, k - 1, k + nx, k + 1);
+        k = (ny - 1) * nx + j;
+        error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, k, k - nx - 1, k - nx + 1, k - 1, k + 1,
+                              k - nx, k - 1, k, k + 1);
+    }
+    for (int i = 1; i < ny - 1; i++) {
+        int k = i * nx;
+        error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, k, k - nx, k - nx + 1, k + nx, k + nx + 1,
+                              k - nx, k, k + nx, k + 1);
+        k = (i + 1) * nx - 1;
+        error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, k, k - nx - 1, k - nx, k + nx - 1, k + nx,
+                              k - nx, k - 1, k + nx, k);
+    }
+    error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, 0, 0, 1, nx, nx + 1, 0, 0, nx, 1);
+    int k = nx - 1;
+    error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, k, k - 1, k, k + nx - 1, k + nx, k, k - 1, k + nx, k);
+    k = (ny - 1) * nx;
+    error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, k, k - nx, k - nx + 1, k, k + 1, k - nx, k, k, k + 1);
+    k = ny * nx - 1;
+    error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, k, k - 1, k, k - nx - 1, k - nx, k - nx, k - 1, k, k);
+    return error;
+}
+
+/* src/horn_schunck_pyramidal.cpp:78-249 */
+void orc_hs_single_scale(const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                         double alpha, int warps, double TOL, int maxiter, int verbose, int *iters)
+{
+    const int size = nx * ny;
+    const size_t n = (size_t) size;
+    const double alpha2 = alpha * alpha;
+    double *I2x = dalloc(n), *I2y = dalloc(n), *I2w = dalloc(n), *I2wx = dalloc(n), *I2wy = dalloc(n);
+    double *Au = dalloc(n), *Av = dalloc(n), *Du = dalloc(n), *Dv = dalloc(n), *D = dalloc(n);
+
+    if (verbose)
+        fprintf(stderr, "Single-scale Horn-Schunck of a %dx%d image\n\ta=%g nw=%d eps=%g mi=%d v=%d\n",
+                nx, ny, alpha, warps, TOL, maxiter, verbose);
+
+    orc_centered_gradient(I2, I2x, I2y, nx, ny);                       /* :114 */
+    for (int w = 0; w < warps; w++) {
+        if (verbose) fprintf(stderr, "Warping %d:", w);
+        orc_bicubic_warp(I2,  u, v, I2w,  nx, ny, 1);                  /* :123-125 */
+        orc_bicubic_warp(I2x, u, v, I2wx, nx, ny, 1);
+        orc_bicubic_warp(I2y, u, v, I2wy, nx, ny, 1);
+        for (int i = 0; i < size; i++) {                               /* :128-137 */
+            const double I2wl = I2wx[i] * u[i] + I2wy[i] * v[i];
+            const double dif = I1[i] - I2w[i] + I2wl;
+            Au[i] = dif * I2wx[i];
+            Av[i] = dif * I2wy[i];
+            Du[i] = I2wx[i] * I2wx[i] + alpha2;
+            Dv[i] = I2wy[i] * I2wy[i] + alpha2;
+            D[i]  = I2wx[i] * I2wy[i];
+        }
+        int niter = 0;
+        double error = 1000;
+        while (error > TOL && niter < maxiter) {                       /* :143 */
+            niter++;
+            error = hs_sweep(Au, Av, Du, Dv, D, u, v, alpha2, nx, ny);
+            error = sqrt(error / size);                                /* :230 */
+        }
+        if (verbose) fprintf(stderr, "Iterations %d (%g)\n", niter, error);
+        if (iters) iters[w] = niter;
+    }
+    free(I2x); free(I2y); free(I2w); free(I2wx); free(I2wy);
+    free(Au); free(Av); free(Du); free(Dv); free(D);
+}
+
+/* src/horn_schunck_pyramidal.cpp:258-370 */
+int orc_hs_pyramidal(const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                     double alpha, int nscales, double zfactor, int warps, double TOL, int maxiter,
+                     int verbose, int *iters)
+{
+    if (verbose)
+        fprintf(stderr, "Multiscale Horn-Schunck of a %dx%d pair\n\ta=%g ns=%d zf=%g nw=%d eps=%g mi=%d\n",
+                nx, ny, alpha, nscales, zfactor, warps, TOL, maxiter);
+    pyramid P;
+    int rc = pyramid_build(&P, I1, I2, u, v, nx, ny, nscales, zfactor, HS_PRESMOOTH_SIGMA);
+    for (int s = nscales - 1; s >= 0 && !rc; s--) {
+        if (verbose) fprintf(stderr, "Scale: %d %dx%d\n", s, P.nx[s], P.ny[s]);
+        orc_hs_single_scale(P.A[s], P.B[s], P.u[s], P.v[s], P.nx[s], P.ny[s], alpha, warps, TOL,
+                            maxiter, verbose, iters ? iters + s * warps : NULL);
+        if (s) pyramid_upsample(&P, s, zfactor);
+    }
+    pyramid_free(&P);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Brox spatial.  src/brox_spatial_mask.cpp:16-93: psi1..4 = half-sums with the down / up / right /
+ * left neighbour, 0 across the image border. */
+static void brox_psi_divergence(const double *psi, double *psi1, double *psi2, double *psi3,
+                                double *psi4, int nx, int ny)
+{
+    #pragma omp parallel for
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++) {
+            const int k = i * nx + j;
+            psi1[k] = (i < ny - 1) ? 0.5 * (psi[k + nx] + psi[k]) : 0;
+            psi2[k] = (i > 0)      ? 0.5 * (psi[k - nx] + psi[k]) : 0;
+            psi3[k] = (j < nx - 1) ? 0.5 * (psi[k + 1] + psi[k]) : 0;
+            psi4[k] = (j > 0)      ? 0.5 * (psi[k - 1] + psi[k]) : 0;
+        }
+}
+
+/* src/brox_spatial_mask.cpp:100-171: sum of psi_k * (neighbour - centre) over the neighbours that
+ * exist, accumulated in the order down, up, right, left (missing terms are left out of the
+ * expression, not added as zeros). */
+static inline double brox_div_at(const double *f, const double *psi1, const double *psi2,
+                                 const double *psi3, const double *psi4, int i, int j, int nx, int ny)
+{
+    const int k = i * nx + j;
+    double acc = 0;
+    int have = 0;
+    if (i < ny - 1) { acc = psi1[k] * (f[k + nx] - f[k]); have = 1; }
+    if (i > 0)      { const double t = psi2[k] * (f[k - nx] - f[k]); acc = have ? acc + t : t; have = 1; }
+    if (j < nx - 1) { const double t = psi3[k] * (f[k + 1] - f[k]);  acc = have ? acc + t : t; have = 1; }
+    if (j > 0)      { const double t = psi4[k] * (f[k - 1] - f[k]);  acc = have ? acc + t : t; have = 1; }
+    return acc;
+}
+
+static void brox_divergence_u(const double *u, const double *v, const double *psi1,
+                              const double *psi2, const double *psi3, const double *psi4,
+                              double *div_u, double *div_v, int nx, int ny)
+{
+    #pragma omp parallel for
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++) {
+            div_u[i * nx + j] = brox_div_at(u, psi1, psi2, psi3, psi4, i, j, nx, ny);
+            div_v[i * nx + j] = brox_div_at(v, psi1, psi2, psi3, psi4, i, j, nx, ny);
+        }
+}
+
+/* src/brox_optic_flow_spatial.cpp:129-172.  (i0, i1, j0, j1) are the OFFSETS to the previous /
+ * following row and column; the reference passes 0 for a missing neighbour so the tap lands on
+ * the pixel itself (:332-388), with psi = 0 there. */
+static inline double brox_sor_point(const double *Au, const double *Av, const double *Du,
+                                    const double *Dv, const double *D, double *du, double *dv,
+                                    double alpha, const double *psi1, const double *psi2,
+                                    const double *psi3, const double *psi4, int i, int i0, int i1,
+                                    int j, int nx, int j0, int j1)
+{
+    const double w = BROX_SOR_W;
+    const int k = i * nx + j;
+    const double div_du = psi1[k] * du[k + i1] + psi2[k] * du[k - i0] + psi3[k] * du[k + j1] + psi4[k] * du[k - j0];
+    const double div_dv = psi1[k] * dv[k + i1] + psi2[k] * dv[k - i0] + psi3[k] * dv[k + j1] + psi4[k] * dv[k - j0];
+    const double duk = du[k], dvk = dv[k];
+    du[k] = (1. - w) * du[k] + w * (Au[k] - D[k] * dv[k] + alpha * div_du) / Du[k];
+    dv[k] = (1. - w) * dv[k] + w * (Av[k] - D[k] * du[k] + alpha * div_dv) / Dv[k];
+    return (du[k] - duk) * (du[k] - duk) + (dv[k] - dvk) * (dv[k] - dvk);
+}
+
+/* src/brox_optic_flow_spatial.cpp:179-444 */
+static void brox_single_scale(const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                              double alpha, double gamma, double TOL, int inner_iter, int outer_iter,
+                              int nthreads, int verbose, int *iters)
+{
+    const int size = nx * ny;
+    const size_t n = (size_t) size;
+    enum { NARR = 34 };
+    double *a[NARR];
+    for (int q = 0; q < NARR; q++) a[q] = dalloc(n);
+    double *du = a[0], *dv = a[1], *ux = a[2], *uy = a[3], *vx = a[4], *vy = a[5];
+    double *I1x = a[6], *I1y = a[7], *I2x = a[8], *I2y = a[9], *I2w = a[10], *I2wx = a[11], *I2wy = a[12];
+    double *I2xx = a[13], *I2yy = a[14], *I2xy = a[15], *I2wxx = a[16], *I2wyy = a[17], *I2wxy = a[18];
+    double *div_u = a[19], *div_v = a[20], *div_d = a[21];
+    double *Au = a[22], *Av = a[23], *Du = a[24], *Dv = a[25], *D = a[26];
+    double *psid = a[27], *psig = a[28], *psis = a[29], *psi1 = a[30], *psi2 = a[31], *psi3 = a[32], *psi4 = a[33];
+    int solve = 0;
+    (void) nthreads;
+
+    orc_centered_gradient(I1, I1x, I1y, nx, ny);               /* :235-236 */
+    orc_centered_gradient(I2, I2x, I2y, nx, ny);
+    orc_dxx(I2, I2xx, nx, ny);                                 /* :239-241 */
+    orc_dyy(I2, I2yy, nx, ny);
+    orc_dxy(I2, I2xy, nx, ny);
+
+    for (int no = 0; no < outer_iter; no++) {                  /* :244 */
+        orc_bicubic_warp(I2,   u, v, I2w,   nx, ny, 1);        /* :246-251 */
+        orc_bicubic_warp(I2x,  u, v, I2wx,  nx, ny, 1);
+        orc_bicubic_warp(I2y,  u, v, I2wy,  nx, ny, 1);
+        orc_bicubic_warp(I2xx, u, v, I2wxx, nx, ny, 1);
+        orc_bicubic_warp(I2xy, u, v, I2wxy, nx, ny, 1);
+        orc_bicubic_warp(I2yy, u, v, I2wyy, nx, ny, 1);
+
+        orc_centered_gradient(u, ux, uy, nx, ny);              /* :254-255 */
+        orc_centered_gradient(v, vx, vy, nx, ny);
+
+        #pragma omp parallel for
+        for (int i = 0; i < size; i++) {                       /* psi_smooth :99-122 */
+            const double gu = ux[i] * ux[i] + uy[i] * uy[i];
+            const double gv = vx[i] * vx[i] + vy[i] * vy[i];
+            const double d2 = gu + gv;
+            psis[i] = 1. / sqrt(d2 + BROX_EPSILON * BROX_EPSILON);
+        }
+        brox_psi_divergence(psis, psi1, psi2, psi3, psi4, nx, ny);                   /* :261 */
+        brox_divergence_u(u, v, psi1, psi2, psi3, psi4, div_u, div_v, nx, ny);       /* :264 */
+
+        #pragma omp parallel for
+        for (int i = 0; i < size; i++) {                       /* :266-274 */
+            div_d[i] = alpha * (psi1[i] + psi2[i] + psi3[i] + psi4[i]);
+            du[i] = dv[i] = 0;
+        }
+
+        for (int ni = 0; ni < inner_iter; ni++) {              /* :277 */
+            #pragma omp parallel for
+            for (int i = 0; i < size; i++) {                   /* psi_data :33-57 */
+                const double dI = I2w[i] - I1[i] + I2wx[i] * du[i] + I2wy[i] * dv[i];
+                const double dI2 = dI * dI;
+                psid[i] = 1. / sqrt(dI2 + BROX_EPSILON * BROX_EPSILON);
+            }
+            #pragma omp parallel for
+            for (int i = 0; i < size; i++) {                   /* psi_gradient :64-92 */
+                const double dIx = I2wx[i] - I1x[i] + I2wxx[i] * du[i] + I2wxy[i] * dv[i];
+                const double dIy = I2wy[i] - I1y[i] + I2wxy[i] * du[i] + I2wyy[i] * dv[i];
+                const double dI2 = dIx * dIx + dIy * dIy;
+                psig[i] = 1. / sqrt(dI2 + BROX_EPSILON * BROX_EPSILON);
+            }
+            for (int i = 0; i < size; i++) {                   /* :283-309 */
+                const double p = psid[i];
+                const double g = gamma * psig[i];
+                const double dif = I2w[i] - I1[i];
+                const double BNu = -p * dif * I2wx[i];
+                const double BNv = -p * dif * I2wy[i];
+                const double BDu = p * I2wx[i] * I2wx[i];
+                const double BDv = p * I2wy[i] * I2wy[i];
+                const double dx = (I2wx[i] - I1x[i]);
+                const double dy = (I2wy[i] - I1y[i]);
+                const double GNu = -g * (dx * I2wxx[i] + dy * I2wxy[i]);
+                const double GNv = -g * (dx * I2wxy[i] + dy * I2wyy[i]);
+                const double GDu = g * (I2wxx[i] * I2wxx[i] + I2wxy[i] * I2wxy[i]);
+                const double GDv = g * (I2wyy[i] * I2wyy[i] + I2wxy[i] * I2wxy[i]);
+                const double DI = (I2wxx[i] + I2wyy[i]) * I2wxy[i];
+                const double Duv = p * I2wy[i] * I2wx[i] + g * DI;
+                Au[i] = BNu + GNu + alpha * div_u[i];
+                Av[i] = BNv + GNv + alpha * div_v[i];
+                Du[i] = BDu + GDu + div_d[i];
+                Dv[i] = BDv + GDv + div_d[i];
+                D[i] = Duv;
+            }
+
+            double error = 1000;
+            int nsor = 0;
+            while (error > TOL && nsor < BROX_MAXITER) {       /* :315 */
+                error = 0;
+                nsor++;
+                #pragma omp parallel for reduction(+:error)
+                for (int i = 1; i < ny - 1; i++)
+                    for (int j = 1; j < nx - 1; j++)
+                        error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4,
+                                                i, nx, nx, j, nx, 1, 1);
+                for (int j = 1; j < nx - 1; j++) {
+                    error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4,
+                                            0, 0, nx, j, nx, 1, 1);
+                    error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4,
+                                            ny - 1, nx, 0, j, nx, 1, 1);
+                }
+                for (int i = 1; i < ny - 1; i++) {
+                    error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4,
+                                            i, nx, nx, 0, nx, 0, 1);
+                    error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4,
+                                            i, nx, nx, nx - 1, nx, 1, 0);
+                }
+                error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4,
+                                        0, 0, nx, 0, nx, 0, 1);
+                error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4,
+                                        0, 0, nx, nx - 1, nx, 1, 0);
+                error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4,
+                                        ny - 1, nx, 0, 0, nx, 0, 1);
+                error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4,
+                                        ny - 1, nx, 0, nx - 1, nx, 1, 0);
+                error = sqrt(error / size);                    /* :389 */
+            }
+            if (verbose) printf("Iterations: %d\n", nsor);
+            if (iters) iters[solve] = nsor;
+            solve++;
+        }
+        for (int i = 0; i < size; i++) { u[i] += du[i]; v[i] += dv[i]; }   /* :398-401 */
+    }
+    for (int q = 0; q < NARR; q++) free(a[q]);
+}
+
+/* src/brox_optic_flow_spatial.cpp:451-549.  `iters` is laid out [scale][outer*inner]. */
+int orc_brox_spatial(const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                     double alpha, double gamma, int nscales, double nu, double TOL,
+                     int inner_iter, int outer_iter, int verbose, int *iters)
+{
+    pyramid P;
+    int rc = pyramid_build(&P, I1, I2, u, v, nx, ny, nscales, nu, BROX_SIGMA);
+    const int nthreads = orc_max_threads();
+    for (int s = nscales - 1; s >= 0 && !rc; s--) {
+        if (verbose) printf("Scale: %d\n", s);
+        brox_single_scale(P.A[s], P.B[s], P.u[s], P.v[s], P.nx[s], P.ny[s], alpha, gamma, TOL,
+                          inner_iter, outer_iter, nthreads, verbose,
+                          iters ? iters + s * inner_iter * outer_iter : NULL);
+        if (s) pyramid_upsample(&P, s, nu);
+    }
+    pyramid_free(&P);
+    return rc;
+}

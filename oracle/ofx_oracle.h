@@ -1,0 +1,81 @@
+/* oracle/ofx_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C + OpenMP, double storage and arithmetic) of the reference hot path.
+ * It is the CHECKER for the HIP product path: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product library (libofx.so) never links,
+ * loads or falls back to anything in oracle/.
+ *
+ * Parity status: PINNED.  Every function below is checked bit-for-bit (OMP_NUM_THREADS=1)
+ * against the reference's own compiled sources (oracle/_ref/libofref.so, built by
+ * oracle/Makefile from /root/reference/src where they lie) in tests/test_oracle_vs_ref.py, and
+ * against golden vectors generated from that build (tests/golden/, generator
+ * tests/golden/make_golden.py).  The reference itself ships no tests or fixtures.
+ *
+ * All arrays are dense row-major nx*ny doubles, index p = i*nx + j.
+ */
+#ifndef OFX_ORACLE_H
+#define OFX_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void orc_set_num_threads(int n);
+int  orc_max_threads(void);
+
+/* operators.cpp */
+void orc_divergence(const double *v1, const double *v2, double *div, int nx, int ny);
+void orc_forward_gradient(const double *f, double *fx, double *fy, int nx, int ny);
+void orc_centered_gradient(const double *f, double *dx, double *dy, int nx, int ny);
+void orc_dxx(const double *f, double *out, int nx, int ny);
+void orc_dyy(const double *f, double *out, int nx, int ny);
+void orc_dxy(const double *f, double *out, int nx, int ny);
+int  orc_gaussian(double *I, int nx, int ny, double sigma);        /* 1 = "sigma too large" */
+
+/* bicubic_interpolation.cpp */
+double orc_bicubic_at(const double *in, double uu, double vv, int nx, int ny, int border_out);
+void orc_bicubic_warp(const double *in, const double *u, const double *v, double *out,
+                      int nx, int ny, int border_out);
+
+/* zoom.cpp */
+void orc_zoom_size(int nx, int ny, int *nxx, int *nyy, double factor);
+int  orc_zoom_out(const double *I, double *Iout, int nx, int ny, double factor);
+void orc_zoom_in(const double *I, double *Iout, int nx, int ny, int nxx, int nyy);
+
+/* utils.cpp */
+void orc_image_normalization_2(const double *I1, const double *I2, double *I1n, double *I2n, int size);
+
+/* tvl1flow.cpp.  iters (optional, may be NULL) receives the inner-iteration count of every warp
+ * (`n` of the reference's verbose line, tvl1flow.cpp:184-188); errs (optional) the final error.
+ * max_iter <= 0 selects the reference's MAX_ITERATIONS (300). */
+void orc_tvl1_single_scale(const double *I0, const double *I1, double *u1, double *u2, int nx, int ny,
+                           double tau, double lambda, double theta, int warps, double epsilon,
+                           int verbose, int *iters, double *errs);
+int  orc_tvl1_multiscale(const double *I0, const double *I1, double *u1, double *u2, int nx, int ny,
+                         double tau, double lambda, double theta, int nscales, double zfactor,
+                         int warps, double epsilon, int verbose, int *iters, double *errs);
+/* `iters` for the multiscale call is laid out [scale][warp] with scale 0 = finest. */
+
+/* One inner iteration sweep only (for fixed-work CPU timing): runs exactly n_iter iterations of
+ * tvl1flow.cpp:113-182 on already-linearised data; returns the last error. */
+double orc_tvl1_iterations(double *u1, double *u2, double *p11, double *p12, double *p21, double *p22,
+                           const double *I1wx, const double *I1wy, const double *rho_c,
+                           const double *grad, int nx, int ny, double tau, double lambda,
+                           double theta, int n_iter);
+
+/* horn_schunck_pyramidal.cpp */
+void orc_hs_single_scale(const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                         double alpha, int warps, double TOL, int maxiter, int verbose, int *iters);
+int  orc_hs_pyramidal(const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                      double alpha, int nscales, double zfactor, int warps, double TOL, int maxiter,
+                      int verbose, int *iters);
+
+/* brox_optic_flow_spatial.cpp + brox_spatial_mask.cpp */
+int  orc_brox_spatial(const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                      double alpha, double gamma, int nscales, double nu, double TOL,
+                      int inner_iter, int outer_iter, int verbose, int *iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
