@@ -1,0 +1,154 @@
+/* include/ofx.h -- C ABI of libofx.so: the MI355X (gfx950) implementation of the variational
+ * optical-flow hot path of 12334zq/optical-flow-1 (TV-L1 primal-dual solver + the shared stencil /
+ * warp / pyramid operators; Horn-Schunck-pyramidal and Brox-spatial SOR solvers on top of them).
+ *
+ * The reference has no FFI / plugin layer: its boundary is the C++ library libof.a (mangled names,
+ * `bool` and default arguments) called by its command-line programs.  Every entry
+ * point below replaces one reference prototype 1:1 -- same argument order and meaning, with
+ *   - a leading `ofx_ctx *` (one context = one GPU + one HIP stream + its workspace),
+ *   - `bool` -> `int`,
+ *   - an `int` status return instead of `void` + C++ exceptions (0 = OFX_OK).
+ * Host-pointer entry points take/return dense row-major `double` arrays (the reference's ofpix_t,
+ * src/of.h:4-10), index p = i*nx + j; device residency is internal.  The *_dev entry points take
+ * device pointers (hipMalloc / torch tensors) and run on the context's stream.
+ *
+ * There is NO CPU fallback: without a usable gfx950 device ofx_ctx_create fails with
+ * OFX_ERR_NODEV and every other call needs a context.
+ *
+ * Thread-safety: calls on different contexts are independent; one context must not be used from
+ * two threads at once.  Calls are blocking (they return after the result is in the caller's
+ * buffer), except where noted for *_dev.
+ */
+#ifndef OFX_H
+#define OFX_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFX_VERSION 100
+
+/* status codes */
+#define OFX_OK          0
+#define OFX_ERR_ARG     1   /* bad size / NULL pointer / parameter out of range                  */
+#define OFX_ERR_SIGMA   2   /* replaces std::runtime_error("GaussianSmooth: sigma too large"),
+                               src/operators.cpp:520-522 (also returned where the reference would
+                               read out of bounds: kernel radius >= image width or height)       */
+#define OFX_ERR_NOMEM   3   /* replaces std::bad_alloc (device or host allocation failed)         */
+#define OFX_ERR_HIP     4   /* a HIP runtime call or kernel launch failed                        */
+#define OFX_ERR_NODEV   5   /* no gfx950 device / device index out of range                      */
+
+/* storage precision of the device-resident arrays; arithmetic is ALWAYS double in registers.   */
+#define OFX_F64 0           /* strict mode: double storage, bit-compatible per-pixel arithmetic  */
+#define OFX_F32 1           /* fast mode: float storage (half the HBM traffic)                   */
+
+/* solver limits mirrored from the reference's #defines */
+#define OFX_TVL1_MAX_ITERATIONS 300   /* src/tvl1flow.cpp:22  */
+#define OFX_BROX_MAX_ITERATIONS 300   /* src/brox_optic_flow_spatial.cpp:24 */
+#define OFX_MAX_SCALES 32
+#define OFX_MAX_SOLVES 64             /* warps (TV-L1, HS) or outer*inner solves (Brox) per scale */
+
+typedef struct ofx_ctx ofx_ctx;
+
+/* Work / timing record of the last solver call on a context (the reference only prints these on
+ * stderr when `verbose`: src/tvl1flow.cpp:184-188,284-286). */
+typedef struct ofx_stats {
+    int    nscales;                                   /* pyramid levels actually used            */
+    int    nsolves;                                   /* warps per scale (Brox: outer*inner)     */
+    int    nx[OFX_MAX_SCALES], ny[OFX_MAX_SCALES];    /* level sizes, 0 = finest                 */
+    int    iters[OFX_MAX_SCALES][OFX_MAX_SOLVES];     /* inner iterations / SOR sweeps per solve */
+    double error[OFX_MAX_SCALES][OFX_MAX_SOLVES];     /* stopping-criterion value at exit        */
+    double iter_ms[OFX_MAX_SCALES];                   /* HIP-event time of the inner-iteration
+                                                         launches of a level (0 unless profiling) */
+    long long iter_launches[OFX_MAX_SCALES];          /* iteration kernels that did real work    */
+    double work_pix_iters;                            /* sum n_iter * nx_s * ny_s                */
+    double total_ms;                                  /* wall time of the call on the host       */
+} ofx_stats;
+
+/* ---- context ---------------------------------------------------------------------------------*/
+int  ofx_device_count(void);                                   /* number of usable HIP devices    */
+int  ofx_ctx_create(ofx_ctx **out, int device, int precision); /* precision: OFX_F64 | OFX_F32   */
+void ofx_ctx_destroy(ofx_ctx *ctx);
+const char *ofx_strerror(int status);
+const char *ofx_last_error(const ofx_ctx *ctx);                /* detail text of the last failure */
+void *ofx_ctx_stream(const ofx_ctx *ctx);                      /* the context's hipStream_t       */
+int   ofx_ctx_precision(const ofx_ctx *ctx);
+int   ofx_ctx_synchronize(ofx_ctx *ctx);
+int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
+/* options: "profile" (0/1: bracket inner-iteration launches with HIP events -> stats.iter_ms),
+ *          "rows_per_wave", "chunk" (tuning of the TV-L1 iteration kernel / launch batching). */
+int   ofx_get_stats(const ofx_ctx *ctx, ofx_stats *out);
+
+/* ---- operators (replace src/operators.h:29-134) ---------------------------------------------*/
+int ofx_divergence(ofx_ctx *ctx, const double *v1, const double *v2, double *div, int nx, int ny);
+int ofx_forward_gradient(ofx_ctx *ctx, const double *f, double *fx, double *fy, int nx, int ny);
+int ofx_centered_gradient(ofx_ctx *ctx, const double *f, double *dx, double *dy, int nx, int ny);  /* nz = 1 */
+int ofx_dxx(ofx_ctx *ctx, const double *I, double *Ixx, int nx, int ny);                         /* nz = 1 */
+int ofx_dyy(ofx_ctx *ctx, const double *I, double *Iyy, int nx, int ny);
+int ofx_dxy(ofx_ctx *ctx, const double *I, double *Ixy, int nx, int ny);
+/* in-place separable Gaussian with the reference's default arguments (reflecting boundary,
+ * window 5): src/operators.cpp:506-624 */
+int ofx_gaussian(ofx_ctx *ctx, double *I, int nx, int ny, double sigma);
+
+/* ---- bicubic interpolation (replace src/bicubic_interpolation.h:16-52) -----------------------*/
+/* n samples at (uu[k], vv[k]) -> out[k]; one call of the reference's bicubic_interpolation_at
+ * per sample */
+int ofx_bicubic_at(ofx_ctx *ctx, const double *input, const double *uu, const double *vv, double *out,
+                   int n, int nx, int ny, int border_out);
+int ofx_bicubic_warp(ofx_ctx *ctx, const double *input, const double *u, const double *v, double *output,
+                     int nx, int ny, int border_out);
+
+/* ---- pyramid zoom (replace src/zoom.h:20-63) -------------------------------------------------*/
+void ofx_zoom_size(int nx, int ny, int *nxx, int *nyy, double factor);      /* pure host arithmetic */
+int  ofx_zoom_out(ofx_ctx *ctx, const double *I, double *Iout, int nx, int ny, double factor);
+int  ofx_zoom_in(ofx_ctx *ctx, const double *I, double *Iout, int nx, int ny, int nxx, int nyy);
+
+/* ---- normalisation (replace src/utils.h:27-32) -----------------------------------------------*/
+int ofx_image_normalization_2(ofx_ctx *ctx, const double *I1, const double *I2, double *I1n, double *I2n,
+                              int size);
+
+/* ---- TV-L1 (replace src/tvl1flow.h:36-70) ----------------------------------------------------*/
+/* single scale: u1/u2 are read as the initial flow and overwritten with the result */
+int ofx_tvl1_single_scale(ofx_ctx *ctx, const double *I0, const double *I1, double *u1, double *u2,
+                          int nx, int ny, double tau, double lambda, double theta, int warps,
+                          double epsilon, int verbose);
+/* multiscale: incoming u1/u2 content is ignored (zeroed at the coarsest level) */
+int ofx_tvl1_multiscale(ofx_ctx *ctx, const double *I0, const double *I1, double *u1, double *u2,
+                        int nx, int ny, double tau, double lambda, double theta, int nscales,
+                        double zfactor, int warps, double epsilon, int verbose);
+
+/* Device-resident variant: dI0/dI1 are device arrays of nx*ny elements of the context's storage
+ * precision (double for OFX_F64, float for OFX_F32); d_flo receives the Middlebury .flo payload,
+ * nx*ny interleaved (u,v) float32 pairs (src/tvl1flow_main.cpp:209-213).  Runs on the context's
+ * stream; returns after the solve has been fully enqueued AND its convergence tests resolved
+ * (the result itself is complete once the stream is synchronised). */
+int ofx_tvl1_multiscale_dev(ofx_ctx *ctx, const void *dI0, const void *dI1, void *d_flo,
+                            int nx, int ny, double tau, double lambda, double theta, int nscales,
+                            double zfactor, int warps, double epsilon, int verbose);
+
+/* Fixed-work inner loop only (src/tvl1flow.cpp:113-182 run exactly n_iter times on linearised
+ * data, all arrays host double planes; u/p updated in place).  Returns the last error in *error.
+ * Used by the kernel-level parity tests and the roofline measurement. */
+int ofx_tvl1_iterations(ofx_ctx *ctx, double *u1, double *u2, double *p11, double *p12, double *p21,
+                        double *p22, const double *I1wx, const double *I1wy, const double *rho_c,
+                        int nx, int ny, double tau, double lambda, double theta, int n_iter,
+                        double *error);
+
+/* ---- Horn-Schunck pyramidal (replace src/horn_schunck.h:15-48) --------------------------------*/
+int ofx_hs_single_scale(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v,
+                        int nx, int ny, double alpha, int warps, double TOL, int maxiter, int verbose);
+int ofx_hs_pyramidal(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v,
+                     int nx, int ny, double alpha, int nscales, double zfactor, int warps,
+                     double TOL, int maxiter, int verbose);
+
+/* ---- Brox spatial (replace src/brox_optic_flow.h:19-33) ---------------------------------------*/
+int ofx_brox_spatial(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v,
+                     int nxx, int nyy, double alpha, double gamma, int nscales, double nu,
+                     double TOL, int inner_iter, int outer_iter, int verbose);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFX_H */

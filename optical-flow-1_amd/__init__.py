@@ -1,0 +1,285 @@
+"""optical-flow-1_amd -- Python host-side mirror of the libofx.so C ABI (include/ofx.h).
+
+The package name is not a Python identifier; load it with
+``importlib.import_module("optical-flow-1_amd")`` (tests/conftest.py and bench.py do).
+
+`Ofx` wraps one `ofx_ctx` (one GPU + one HIP stream).  Method names, argument order and meaning
+follow the reference library functions they replace (src/tvl1flow.h, operators.h,
+bicubic_interpolation.h, zoom.h, utils.h); arrays are row-major float64 numpy arrays of shape
+(ny, nx).  There is no CPU fallback: if libofx.so is missing or no gfx950 device is usable, creating
+an `Ofx` raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libofx.so")
+
+F64, F32 = 0, 1
+MAX_SCALES, MAX_SOLVES = 32, 64
+
+_STATUS = {1: "invalid argument", 2: "GaussianSmooth: sigma too large", 3: "out of memory",
+           4: "HIP runtime error", 5: "no usable gfx950 device"}
+
+
+class OfxError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__("ofx status %d (%s)%s" % (status, _STATUS.get(status, "?"), ": " + detail if detail else ""))
+
+
+class Stats(C.Structure):
+    _fields_ = [("nscales", C.c_int), ("nsolves", C.c_int),
+                ("nx", C.c_int * MAX_SCALES), ("ny", C.c_int * MAX_SCALES),
+                ("iters", (C.c_int * MAX_SOLVES) * MAX_SCALES),
+                ("error", (C.c_double * MAX_SOLVES) * MAX_SCALES),
+                ("iter_ms", C.c_double * MAX_SCALES),
+                ("iter_launches", C.c_longlong * MAX_SCALES),
+                ("work_pix_iters", C.c_double), ("total_ms", C.c_double)]
+
+    def iterations(self):
+        return np.array([[self.iters[s][w] for w in range(min(self.nsolves, MAX_SOLVES))]
+                         for s in range(self.nscales)])
+
+    def errors(self):
+        return np.array([[self.error[s][w] for w in range(min(self.nsolves, MAX_SOLVES))]
+                         for s in range(self.nscales)])
+
+
+def build(verbose=False):
+    """Compile libofx.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", os.path.join(HERE, "csrc"), "-j4"], capture_output=True, text=True)
+    if verbose or out.returncode:
+        print(out.stdout, out.stderr)
+    if out.returncode:
+        raise RuntimeError("libofx.so build failed")
+
+
+_lib = None
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_vp = C.c_void_p
+_i, _d = C.c_int, C.c_double
+
+
+def lib():
+    """The loaded libofx.so with argtypes set (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError("%s not built -- run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    sig = {
+        "ofx_device_count": (_i, []),
+        "ofx_ctx_create": (_i, [C.POINTER(_vp), _i, _i]),
+        "ofx_ctx_destroy": (None, [_vp]),
+        "ofx_strerror": (C.c_char_p, [_i]),
+        "ofx_last_error": (C.c_char_p, [_vp]),
+        "ofx_ctx_stream": (_vp, [_vp]),
+        "ofx_ctx_precision": (_i, [_vp]),
+        "ofx_ctx_synchronize": (_i, [_vp]),
+        "ofx_set_option": (_i, [_vp, C.c_char_p, _d]),
+        "ofx_get_stats": (_i, [_vp, C.POINTER(Stats)]),
+        "ofx_divergence": (_i, [_vp, _dp, _dp, _dp, _i, _i]),
+        "ofx_forward_gradient": (_i, [_vp, _dp, _dp, _dp, _i, _i]),
+        "ofx_centered_gradient": (_i, [_vp, _dp, _dp, _dp, _i, _i]),
+        "ofx_dxx": (_i, [_vp, _dp, _dp, _i, _i]),
+        "ofx_dyy": (_i, [_vp, _dp, _dp, _i, _i]),
+        "ofx_dxy": (_i, [_vp, _dp, _dp, _i, _i]),
+        "ofx_gaussian": (_i, [_vp, _dp, _i, _i, _d]),
+        "ofx_bicubic_at": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _i]),
+        "ofx_bicubic_warp": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i]),
+        "ofx_zoom_size": (None, [_i, _i, C.POINTER(_i), C.POINTER(_i), _d]),
+        "ofx_zoom_out": (_i, [_vp, _dp, _dp, _i, _i, _d]),
+        "ofx_zoom_in": (_i, [_vp, _dp, _dp, _i, _i, _i, _i]),
+        "ofx_image_normalization_2": (_i, [_vp, _dp, _dp, _dp, _dp, _i]),
+        "ofx_tvl1_single_scale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _d, _i, _d, _i]),
+        "ofx_tvl1_multiscale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _d, _i, _d, _i, _d, _i]),
+        "ofx_tvl1_multiscale_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _d, _d, _i, _d, _i, _d, _i]),
+        "ofx_tvl1_iterations": (_i, [_vp] + [_dp] * 9 + [_i, _i, _d, _d, _d, _i, C.POINTER(_d)]),
+        "ofx_hs_single_scale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _i]),
+        "ofx_hs_pyramidal": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _d, _i, _i]),
+        "ofx_brox_spatial": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
+    }
+    L.ofx_missing = []
+    for name, (res, args) in sig.items():
+        if not hasattr(L, name):          # stale / incomplete build: tests/test_abi.py fails on this list
+            L.ofx_missing.append(name)
+            continue
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def zoom_size(nx, ny, factor):
+    a, b = _i(), _i()
+    lib().ofx_zoom_size(nx, ny, C.byref(a), C.byref(b), factor)
+    return a.value, b.value
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Ofx:
+    """One libofx context.  precision: F64 (strict) or F32 (fast, float storage)."""
+
+    def __init__(self, device=0, precision=F64):
+        self.L = lib()
+        h = _vp()
+        s = self.L.ofx_ctx_create(C.byref(h), device, precision)
+        if s:
+            raise OfxError(s, "ofx_ctx_create(device=%d)" % device)
+        self.h = h
+        self.precision = precision
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ofx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, s):
+        if s:
+            raise OfxError(s, (self.L.ofx_last_error(self.h) or b"").decode())
+
+    def set_option(self, name, value):
+        self._ck(self.L.ofx_set_option(self.h, name.encode(), float(value)))
+
+    def stats(self):
+        st = Stats()
+        self._ck(self.L.ofx_get_stats(self.h, C.byref(st)))
+        return st
+
+    def stream(self):
+        return self.L.ofx_ctx_stream(self.h)
+
+    def synchronize(self):
+        self._ck(self.L.ofx_ctx_synchronize(self.h))
+
+    # ---- operators ---------------------------------------------------------------------------
+    def divergence(self, v1, v2):
+        ny, nx = v1.shape
+        out = np.empty((ny, nx))
+        self._ck(self.L.ofx_divergence(self.h, _f64(v1), _f64(v2), out, nx, ny))
+        return out
+
+    def forward_gradient(self, f):
+        ny, nx = f.shape
+        fx, fy = np.empty((ny, nx)), np.empty((ny, nx))
+        self._ck(self.L.ofx_forward_gradient(self.h, _f64(f), fx, fy, nx, ny))
+        return fx, fy
+
+    def centered_gradient(self, f):
+        ny, nx = f.shape
+        fx, fy = np.empty((ny, nx)), np.empty((ny, nx))
+        self._ck(self.L.ofx_centered_gradient(self.h, _f64(f), fx, fy, nx, ny))
+        return fx, fy
+
+    def _second(self, fn, f):
+        ny, nx = f.shape
+        out = np.empty((ny, nx))
+        self._ck(fn(self.h, _f64(f), out, nx, ny))
+        return out
+
+    def dxx(self, f): return self._second(self.L.ofx_dxx, f)
+    def dyy(self, f): return self._second(self.L.ofx_dyy, f)
+    def dxy(self, f): return self._second(self.L.ofx_dxy, f)
+
+    def gaussian(self, I, sigma):
+        ny, nx = I.shape
+        out = _f64(I).copy()
+        self._ck(self.L.ofx_gaussian(self.h, out, nx, ny, sigma))
+        return out
+
+    def bicubic_at(self, I, uu, vv, border_out=False):
+        ny, nx = I.shape
+        uu, vv = _f64(np.atleast_1d(uu)), _f64(np.atleast_1d(vv))
+        out = np.empty(uu.shape)
+        self._ck(self.L.ofx_bicubic_at(self.h, _f64(I), uu, vv, out, uu.size, nx, ny, int(border_out)))
+        return out
+
+    def bicubic_warp(self, I, u, v, border_out=False):
+        ny, nx = I.shape
+        out = np.empty((ny, nx))
+        self._ck(self.L.ofx_bicubic_warp(self.h, _f64(I), _f64(u), _f64(v), out, nx, ny, int(border_out)))
+        return out
+
+    def zoom_out(self, I, factor):
+        ny, nx = I.shape
+        nxx, nyy = zoom_size(nx, ny, factor)
+        out = np.empty((nyy, nxx))
+        self._ck(self.L.ofx_zoom_out(self.h, _f64(I), out, nx, ny, factor))
+        return out
+
+    def zoom_in(self, I, nxx, nyy):
+        ny, nx = I.shape
+        out = np.empty((nyy, nxx))
+        self._ck(self.L.ofx_zoom_in(self.h, _f64(I), out, nx, ny, nxx, nyy))
+        return out
+
+    def image_normalization_2(self, I1, I2):
+        a, b = np.empty(I1.shape), np.empty(I2.shape)
+        self._ck(self.L.ofx_image_normalization_2(self.h, _f64(I1), _f64(I2), a, b, I1.size))
+        return a, b
+
+    # ---- TV-L1 ---------------------------------------------------------------------------------
+    def tvl1_single_scale(self, I0, I1, u1, u2, tau=0.25, lam=0.15, theta=0.3, warps=5, epsilon=0.01, verbose=0):
+        ny, nx = I0.shape
+        u1, u2 = _f64(u1).copy(), _f64(u2).copy()
+        self._ck(self.L.ofx_tvl1_single_scale(self.h, _f64(I0), _f64(I1), u1, u2, nx, ny, tau, lam, theta, warps,
+                                              epsilon, verbose))
+        return u1, u2
+
+    def tvl1_multiscale(self, I0, I1, tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5, epsilon=0.01,
+                        verbose=0):
+        ny, nx = I0.shape
+        u1, u2 = np.zeros((ny, nx)), np.zeros((ny, nx))
+        self._ck(self.L.ofx_tvl1_multiscale(self.h, _f64(I0), _f64(I1), u1, u2, nx, ny, tau, lam, theta, nscales,
+                                            zfactor, warps, epsilon, verbose))
+        return u1, u2
+
+    def tvl1_multiscale_dev(self, dI0, dI1, d_flo, nx, ny, tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5,
+                            warps=5, epsilon=0.01, verbose=0):
+        """dI0, dI1, d_flo: device pointers (ints).  Enqueues on the context's stream."""
+        self._ck(self.L.ofx_tvl1_multiscale_dev(self.h, dI0, dI1, d_flo, nx, ny, tau, lam, theta, nscales, zfactor,
+                                                warps, epsilon, verbose))
+
+    def tvl1_iterations(self, u1, u2, p11, p12, p21, p22, I1wx, I1wy, rho_c, tau, lam, theta, n_iter):
+        """In place on the six state arrays (float64, C-contiguous); returns the last error."""
+        ny, nx = u1.shape
+        err = _d()
+        self._ck(self.L.ofx_tvl1_iterations(self.h, u1, u2, p11, p12, p21, p22, _f64(I1wx), _f64(I1wy), _f64(rho_c),
+                                            nx, ny, tau, lam, theta, n_iter, C.byref(err)))
+        return err.value
+
+    # ---- Horn-Schunck / Brox ---------------------------------------------------------------------
+    def hs_single_scale(self, I1, I2, u, v, alpha=7.0, warps=10, TOL=1e-4, maxiter=150, verbose=0):
+        ny, nx = I1.shape
+        u, v = _f64(u).copy(), _f64(v).copy()
+        self._ck(self.L.ofx_hs_single_scale(self.h, _f64(I1), _f64(I2), u, v, nx, ny, alpha, warps, TOL, maxiter, verbose))
+        return u, v
+
+    def hs_pyramidal(self, I1, I2, alpha=7.0, nscales=10, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150, verbose=0):
+        ny, nx = I1.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        self._ck(self.L.ofx_hs_pyramidal(self.h, _f64(I1), _f64(I2), u, v, nx, ny, alpha, nscales, zfactor, warps, TOL,
+                                         maxiter, verbose))
+        return u, v
+
+    def brox_spatial(self, I1, I2, alpha=50.0, gamma=10.0, nscales=10, nu=0.5, TOL=1e-4, inner=1, outer=15, verbose=0):
+        ny, nx = I1.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        self._ck(self.L.ofx_brox_spatial(self.h, _f64(I1), _f64(I2), u, v, nx, ny, alpha, gamma, nscales, nu, TOL,
+                                         inner, outer, verbose))
+        return u, v

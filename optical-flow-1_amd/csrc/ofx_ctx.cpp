@@ -1,0 +1,199 @@
+// ofx_ctx.cpp -- context, device arena, pinned staging, error reporting (host side of libofx.so).
+#include "ofx_internal.h"
+
+#include <cstdarg>
+#include <cstdlib>
+#include <new>
+
+static const size_t kSlabAlign = 256;
+static const size_t kMinSlab = 32u << 20;
+
+int ofx_fail(ofx_ctx *ctx, int status, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->errmsg, sizeof(ctx->errmsg), fmt, ap);
+        va_end(ap);
+    }
+    return status;
+}
+
+extern "C" const char *ofx_strerror(int status)
+{
+    switch (status) {
+    case OFX_OK:        return "ok";
+    case OFX_ERR_ARG:   return "invalid argument";
+    case OFX_ERR_SIGMA: return "GaussianSmooth: sigma too large";
+    case OFX_ERR_NOMEM: return "out of memory";
+    case OFX_ERR_HIP:   return "HIP runtime error";
+    case OFX_ERR_NODEV: return "no usable gfx950 device";
+    default:            return "unknown status";
+    }
+}
+
+extern "C" const char *ofx_last_error(const ofx_ctx *ctx) { return ctx ? ctx->errmsg : ""; }
+
+extern "C" int ofx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
+{
+    if (!out) return OFX_ERR_ARG;
+    *out = nullptr;
+    if (precision != OFX_F64 && precision != OFX_F32) return OFX_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return OFX_ERR_NODEV;
+    if (hipSetDevice(device) != hipSuccess) return OFX_ERR_NODEV;
+
+    ofx_ctx *ctx = new (std::nothrow) ofx_ctx();
+    if (!ctx) return OFX_ERR_NOMEM;
+    ctx->device = device;
+    ctx->precision = precision;
+    ctx->cur_slab = 0;
+    ctx->cur_used = 0;
+    ctx->call_bytes = 0;
+    ctx->h_stage = nullptr;
+    ctx->h_stage_bytes = 0;
+    ctx->profile = 0;
+    ctx->rows_per_wave = 0;     // 0 = pick per level
+    ctx->chunk = 0;             // 0 = pick per level
+    ctx->fixed_work = 0;
+    ctx->poll_seq = 0;
+    ctx->errmsg[0] = 0;
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+
+    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc((void **) &ctx->d_err, sizeof(double) * OFX_TVL1_MAX_ITERATIONS * OFX_NSHARD) == hipSuccess;
+    ok = ok && hipMalloc((void **) &ctx->d_state, sizeof(OfxIterState)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **) &ctx->h_state, sizeof(OfxIterState) * OFX_NPOLL, hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; ok && i < OFX_NPOLL; i++)
+        ok = hipEventCreateWithFlags(&ctx->ev_poll[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreate(&ctx->ev_t0) == hipSuccess && hipEventCreate(&ctx->ev_t1) == hipSuccess;
+    if (!ok) {
+        (void) hipGetLastError();
+        delete ctx;          // leaks the partial HIP objects of a failed init; the process is about to give up anyway
+        return OFX_ERR_HIP;
+    }
+    *out = ctx;
+    return OFX_OK;
+}
+
+extern "C" void ofx_ctx_destroy(ofx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->slabs) (void) hipFree(s.base);
+    if (ctx->h_stage) (void) hipHostFree(ctx->h_stage);
+    (void) hipFree(ctx->d_err);
+    (void) hipFree(ctx->d_state);
+    (void) hipHostFree(ctx->h_state);
+    for (int i = 0; i < OFX_NPOLL; i++) (void) hipEventDestroy(ctx->ev_poll[i]);
+    (void) hipEventDestroy(ctx->ev_t0);
+    (void) hipEventDestroy(ctx->ev_t1);
+    (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" void *ofx_ctx_stream(const ofx_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+extern "C" int ofx_ctx_precision(const ofx_ctx *ctx) { return ctx ? ctx->precision : -1; }
+
+extern "C" int ofx_ctx_synchronize(ofx_ctx *ctx)
+{
+    if (!ctx) return OFX_ERR_ARG;
+    OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return OFX_OK;
+}
+
+extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
+{
+    if (!ctx || !name) return OFX_ERR_ARG;
+    if (!strcmp(name, "profile")) { ctx->profile = value != 0; return OFX_OK; }
+    if (!strcmp(name, "fixed_work")) { ctx->fixed_work = value != 0; return OFX_OK; }
+    if (!strcmp(name, "rows_per_wave")) {
+        if (value < 0 || value > 4096) return ofx_fail(ctx, OFX_ERR_ARG, "rows_per_wave out of range");
+        ctx->rows_per_wave = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "chunk")) {
+        if (value < 0 || value > OFX_TVL1_MAX_ITERATIONS) return ofx_fail(ctx, OFX_ERR_ARG, "chunk out of range");
+        ctx->chunk = (int) value;
+        return OFX_OK;
+    }
+    return ofx_fail(ctx, OFX_ERR_ARG, "unknown option '%s'", name);
+}
+
+extern "C" int ofx_get_stats(const ofx_ctx *ctx, ofx_stats *out)
+{
+    if (!ctx || !out) return OFX_ERR_ARG;
+    *out = ctx->stats;
+    return OFX_OK;
+}
+
+// ---- arena ---------------------------------------------------------------------------------------
+// Per-call bump allocation out of a few big hipMalloc slabs.  A call that outgrows the current slab
+// gets an additional one; the next reset coalesces everything into a single slab of the high-water
+// size, so in steady state (same image size call after call) no hipMalloc/hipFree happens at all.
+void ofx_arena_reset(ofx_ctx *ctx)
+{
+    if (ctx->slabs.size() > 1) {
+        size_t total = 0;
+        for (auto &s : ctx->slabs) { total += s.bytes; (void) hipFree(s.base); }
+        ctx->slabs.clear();
+        char *p = nullptr;
+        if (hipMalloc((void **) &p, total) == hipSuccess) ctx->slabs.push_back({p, total});
+        else (void) hipGetLastError();
+    }
+    ctx->cur_slab = 0;
+    ctx->cur_used = 0;
+    ctx->call_bytes = 0;
+}
+
+int ofx_arena_alloc(ofx_ctx *ctx, size_t bytes, void **out)
+{
+    bytes = (bytes + kSlabAlign - 1) / kSlabAlign * kSlabAlign;
+    if (bytes == 0) bytes = kSlabAlign;
+    while (ctx->cur_slab < ctx->slabs.size()) {
+        OfxSlab &s = ctx->slabs[ctx->cur_slab];
+        if (ctx->cur_used + bytes <= s.bytes) {
+            *out = s.base + ctx->cur_used;
+            ctx->cur_used += bytes;
+            ctx->call_bytes += bytes;
+            return OFX_OK;
+        }
+        ctx->cur_slab++;
+        ctx->cur_used = 0;
+    }
+    size_t want = bytes > kMinSlab ? bytes : kMinSlab;
+    if (want < ctx->call_bytes) want = ctx->call_bytes;        // geometric-ish growth inside one call
+    char *p = nullptr;
+    hipError_t e = hipMalloc((void **) &p, want);
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        return ofx_fail(ctx, OFX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    ctx->slabs.push_back({p, want});
+    ctx->cur_slab = ctx->slabs.size() - 1;
+    ctx->cur_used = bytes;
+    ctx->call_bytes += bytes;
+    *out = p;
+    return OFX_OK;
+}
+
+int ofx_stage_reserve(ofx_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->h_stage_bytes) return OFX_OK;
+    if (ctx->h_stage) { (void) hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
+    hipError_t e = hipHostMalloc(&ctx->h_stage, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        return ofx_fail(ctx, OFX_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    ctx->h_stage_bytes = bytes;
+    return OFX_OK;
+}

@@ -1,0 +1,179 @@
+// ofx_device.h -- device-side helpers shared by the gfx950 kernels.
+//
+// Arithmetic contract: every value is widened to double on load, all arithmetic is IEEE double in
+// the reference's association order (the library is built with -ffp-contract=off: no FMA
+// contraction), and results are rounded once on store to the storage type T (double: no-op).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#define OFX_DEV __device__ __forceinline__
+
+// ---- widening loads / narrowing stores --------------------------------------------------------
+OFX_DEV double  ldw(const double *p) { return *p; }
+OFX_DEV double  ldw(const float *p)  { return (double) *p; }
+OFX_DEV double2 ldw2(const double2 *p) { return *p; }
+OFX_DEV double2 ldw2(const float2 *p)  { float2 v = *p; return make_double2((double) v.x, (double) v.y); }
+OFX_DEV double4 ldw4(const double4 *p) { return *p; }
+OFX_DEV double4 ldw4(const float4 *p)
+{
+    float4 v = *p;
+    return make_double4((double) v.x, (double) v.y, (double) v.z, (double) v.w);
+}
+OFX_DEV void stn(double *p, double v) { *p = v; }
+OFX_DEV void stn(float *p, double v)  { *p = (float) v; }
+OFX_DEV void stn2(double2 *p, double2 v) { *p = v; }
+OFX_DEV void stn2(float2 *p, double2 v)  { *p = make_float2((float) v.x, (float) v.y); }
+OFX_DEV void stn4(double4 *p, double4 v) { *p = v; }
+OFX_DEV void stn4(float4 *p, double4 v)
+{
+    *p = make_float4((float) v.x, (float) v.y, (float) v.z, (float) v.w);
+}
+
+// ---- wave64 primitives --------------------------------------------------------------------------
+OFX_DEV double wave_shift_up(double v)      // value of lane-1 (lane 0 keeps its own)
+{
+    return __shfl_up(v, 1, 64);
+}
+OFX_DEV double wave_shift_down(double v)    // value of lane+1 (lane 63 keeps its own)
+{
+    return __shfl_down(v, 1, 64);
+}
+// Butterfly all-reduce: every lane ends with the same bits (each level adds the same two partial
+// sums in every lane, only the operand order differs and + is commutative).
+OFX_DEV double wave_allreduce_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+OFX_DEV double wave_allreduce_min(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m, 64); v = o < v ? o : v; }
+    return v;
+}
+OFX_DEV double wave_allreduce_max(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+    return v;
+}
+
+// ---- hypot --------------------------------------------------------------------------------------
+// The reference calls libm hypot() (src/tvl1flow.cpp:172-173).  glibc >= 2.35 (the image's libm)
+// computes it as a correctly-rounded sqrt(ax^2+ay^2) followed by one Newton-style correction
+// (Borges' algorithm, non-FMA branch); a bare sqrt(x*x+y*y) differs from it in the last bit for
+// ~12 % of inputs.  This is the same sequence of IEEE operations (checked against libm on 2e7
+// inputs, tests/test_host_logic.py), so the dual update stays bit-compatible.
+OFX_DEV double hypot_kernel(double ax, double ay)
+{
+    double h = sqrt(ax * ax + ay * ay);
+    double t1, t2;
+    if (h <= 2.0 * ay) {
+        const double delta = h - ay;
+        t1 = ax * (2.0 * delta - ax);
+        t2 = (delta - 2.0 * (ax - ay)) * delta;
+    } else {
+        const double delta = h - ax;
+        t1 = 2.0 * delta * (ax - 2.0 * ay);
+        t2 = (4.0 * delta - ay) * ay + delta * delta;
+    }
+    h -= (t1 + t2) / (2.0 * h);
+    return h;
+}
+
+OFX_DEV double hypot_ref(double x, double y)
+{
+    x = fabs(x);
+    y = fabs(y);
+    const double ax = x < y ? y : x;
+    const double ay = x < y ? x : y;
+    const double SCALE = 0x1p-600, LARGE = 0x1p+511, TINY = 0x1p-459, EPS = 0x1p-54;
+    if (ax > LARGE) {
+        if (ay <= ax * EPS) return ax + ay;
+        return hypot_kernel(ax * SCALE, ay * SCALE) / SCALE;
+    }
+    if (ay < TINY) {
+        if (ax >= ay / EPS) return ax + ay;
+        return hypot_kernel(ax / SCALE, ay / SCALE) * SCALE;
+    }
+    if (ax >= ay / EPS) return ax + ay;
+    return hypot_kernel(ax, ay);
+}
+
+// ---- bicubic sampling (src/bicubic_interpolation.cpp:24-39,108-245, Neumann boundary) -----------
+struct BicubicTaps {
+    int    col[4];   // mx, x, dx, ddx   (clamped)
+    int    row[4];   // my, y, dy, ddy   (clamped)
+    double fx, fy;   // offsets against the CLAMPED base index (:243)
+    bool   out;      // some tap was clamped (:24-39)
+};
+
+OFX_DEV int bc_clamp(int x, int n, bool &out)
+{
+    if (x < 0)  { out = true; return 0; }
+    if (x >= n) { out = true; return n - 1; }
+    return x;
+}
+
+// Quirks kept on purpose: (int) truncation toward zero (:170); tap direction follows the sign of the
+// coordinate (:162-163); `my` is offset by sx, not sy (:173).
+OFX_DEV BicubicTaps bicubic_taps(double uu, double vv, int nx, int ny)
+{
+    BicubicTaps t;
+    const int sx = (uu < 0) ? -1 : 1;
+    const int sy = (vv < 0) ? -1 : 1;
+    const int iu = (int) uu, iv = (int) vv;
+    bool out = false;
+    t.col[1] = bc_clamp(iu, nx, out);
+    t.row[1] = bc_clamp(iv, ny, out);
+    t.col[0] = bc_clamp(iu - sx, nx, out);
+    t.row[0] = bc_clamp(iv - sx, ny, out);
+    t.col[2] = bc_clamp(iu + sx, nx, out);
+    t.row[2] = bc_clamp(iv + sy, ny, out);
+    t.col[3] = bc_clamp(iu + 2 * sx, nx, out);
+    t.row[3] = bc_clamp(iv + 2 * sy, ny, out);
+    t.out = out;
+    t.fx = uu - t.col[1];
+    t.fy = vv - t.row[1];
+    return t;
+}
+
+// Keys cubic (a = -1/2) in the reference's Horner form (:108-123)
+OFX_DEV double cubic_cell(double v0, double v1, double v2, double v3, double x)
+{
+    return v1 + 0.5 * x * (v2 - v0 + x * (2.0 * v0 - 5.0 * v1 + 4.0 * v2 - v3 + x * (3.0 * (v1 - v2) + v3 - v0)));
+}
+
+// single-channel sample from a planar image: 4 cubics along y (one per tap column), then one in x
+template <typename T>
+OFX_DEV double bicubic_sample(const T *in, const BicubicTaps &t, int nx)
+{
+    double c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double v0 = ldw(in + (size_t) t.row[0] * nx + t.col[k]);
+        const double v1 = ldw(in + (size_t) t.row[1] * nx + t.col[k]);
+        const double v2 = ldw(in + (size_t) t.row[2] * nx + t.col[k]);
+        const double v3 = ldw(in + (size_t) t.row[3] * nx + t.col[k]);
+        c[k] = cubic_cell(v0, v1, v2, v3, t.fy);
+    }
+    return cubic_cell(c[0], c[1], c[2], c[3], t.fx);
+}
+
+// ---- stencil point functions ----------------------------------------------------------------------
+// Backward-difference divergence at one pixel, src/operators.cpp:35-78.
+//   ac = v1[p], al = v1[p-1], bc = v2[p], bu = v2[p-nx].
+// Interior columns keep the interior association dxv + (bc - bu) and only drop a v2 term on the
+// first / last row (:61-62); the first / last column are written by the reference as (a + b) - c
+// (:70-71), a different rounding, so they are separate branches.
+OFX_DEV double div_backward(double ac, double al, double bc, double bu, bool lef, bool rig, bool top, bool bot)
+{
+    if (!lef && !rig) {
+        const double dxv = ac - al;
+        return top ? dxv + bc : (bot ? dxv - bu : dxv + (bc - bu));
+    }
+    if (lef) return top ? ac + bc : (bot ? ac - bu : ac + bc - bu);
+    return top ? -al + bc : (bot ? -al - bu : -al + bc - bu);
+}

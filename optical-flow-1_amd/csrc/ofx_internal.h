@@ -1,0 +1,116 @@
+// ofx_internal.h -- private to libofx.so (host side of the HIP path; nothing here is ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <chrono>
+#include <vector>
+
+#include "ofx.h"
+
+#define OFX_NSHARD 64          // error-accumulator shards per iteration slot (= wave size)
+#define OFX_NPOLL  4           // in-flight convergence polls
+
+// What the finalize kernel publishes to the host after every chunk of iterations.
+struct OfxIterState {
+    int    n;        // iterations that did real work so far (== reference's `n`)
+    int    done;     // 1: the stopping test fired (or MAX reached)
+    double error;    // value of the stopping criterion after iteration n
+};
+
+struct OfxSlab {
+    char  *base;
+    size_t bytes;
+};
+
+struct ofx_ctx {
+    int device;
+    int precision;
+    hipStream_t stream;
+
+    // bump arena for all per-call device arrays (reset at the start of each API call)
+    std::vector<OfxSlab> slabs;
+    size_t cur_slab;
+    size_t cur_used;
+    size_t call_bytes;      // bytes handed out during this call (to coalesce next time)
+
+    // convergence machinery
+    double       *d_err;    // [max_iter][OFX_NSHARD] per-iteration squared-update sums
+    OfxIterState *d_state;  // device copy
+    OfxIterState *h_state;  // pinned ring [OFX_NPOLL]
+    hipEvent_t    ev_poll[OFX_NPOLL];
+    hipEvent_t    ev_t0, ev_t1;
+
+    // pinned staging for host<->device transfers of the host-pointer API
+    void  *h_stage;
+    size_t h_stage_bytes;
+
+    // options
+    int profile;
+    int rows_per_wave;
+    int chunk;
+    int fixed_work;
+    unsigned long long poll_seq;
+
+    ofx_stats stats;
+    char errmsg[256];
+};
+
+// ---- error plumbing ------------------------------------------------------------------------
+int ofx_fail(ofx_ctx *ctx, int status, const char *fmt, ...);
+
+#define OFX_HIP(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return ofx_fail((ctx), e__ == hipErrorOutOfMemory ? OFX_ERR_NOMEM : OFX_ERR_HIP,     \
+                            "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,   \
+                            __LINE__);                                                           \
+    } while (0)
+
+#define OFX_TRY(expr)                                                                            \
+    do {                                                                                         \
+        int s__ = (expr);                                                                        \
+        if (s__ != OFX_OK) return s__;                                                           \
+    } while (0)
+
+// ---- arena -----------------------------------------------------------------------------------
+void ofx_arena_reset(ofx_ctx *ctx);
+int  ofx_arena_alloc(ofx_ctx *ctx, size_t bytes, void **out);
+int  ofx_stage_reserve(ofx_ctx *ctx, size_t bytes);
+
+template <typename T>
+static inline int ofx_alloc(ofx_ctx *ctx, size_t count, T **out)
+{
+    void *p = nullptr;
+    int s = ofx_arena_alloc(ctx, count * sizeof(T), &p);
+    *out = static_cast<T *>(p);
+    return s;
+}
+
+// ---- storage-type traits -----------------------------------------------------------------------
+template <typename T> struct Pix;
+template <> struct Pix<double> { using v2 = double2; using v4 = double4; };
+template <> struct Pix<float>  { using v2 = float2;  using v4 = float4;  };
+
+static inline int ofx_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- API entry boilerplate ---------------------------------------------------------------------
+#define OFX_ENTER(ctx)                                                                           \
+    do {                                                                                         \
+        if (!(ctx)) return OFX_ERR_ARG;                                                          \
+        if (hipSetDevice((ctx)->device) != hipSuccess)                                           \
+            return ofx_fail((ctx), OFX_ERR_NODEV, "hipSetDevice(%d) failed", (ctx)->device);     \
+        (ctx)->errmsg[0] = 0;                                                                    \
+        ofx_arena_reset(ctx);                                                                    \
+    } while (0)
+
+static inline double ofx_now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}

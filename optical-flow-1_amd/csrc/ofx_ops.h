@@ -1,0 +1,54 @@
+// ofx_ops.h -- launchers of the operator / pyramid kernels (device pointers, enqueue on ctx->stream,
+// never synchronise).  T is the storage type (double | float); arithmetic is double.
+#pragma once
+
+#include "ofx_internal.h"
+
+#define OFX_GAUSS_MAX_TAPS 64
+
+struct GaussTaps {
+    int    size;                       // kernel radius + 1  == (int)(5 sigma) + 1
+    double B[OFX_GAUSS_MAX_TAPS];
+};
+
+// host-side tap computation (src/operators.cpp:515-539); returns OFX_ERR_ARG if > MAX taps
+int ofx_gauss_taps(double sigma, GaussTaps *t);
+
+template <typename T> int op_convert_in(ofx_ctx *ctx, const double *src, T *dst, size_t n);
+template <typename T> int op_convert_out(ofx_ctx *ctx, const T *src, double *dst, size_t n);
+template <typename T> int op_interleave2(ofx_ctx *ctx, const double *a, const double *b,
+                                         typename Pix<T>::v2 *dst, size_t n);
+template <typename T> int op_deinterleave2(ofx_ctx *ctx, const typename Pix<T>::v2 *src, double *a,
+                                           double *b, size_t n);
+template <typename T> int op_to_flo(ofx_ctx *ctx, const typename Pix<T>::v2 *src, float2 *dst, size_t n);
+template <typename T> int op_fill2(ofx_ctx *ctx, typename Pix<T>::v2 *dst, size_t n);   // zero
+
+// image_normalization_2 (src/utils.cpp:283-326); scratch: 4 * 1024 T-sized... see .hip (own alloc)
+template <typename T> int op_normalize2(ofx_ctx *ctx, const T *I1, const T *I2, T *o1, T *o2, int size,
+                                        double *d_scratch /* >= 2*2048+2 doubles */);
+
+// gaussian (src/operators.cpp:506-624): I updated in place, tmp is an nx*ny scratch image
+template <typename T> int op_gaussian(ofx_ctx *ctx, T *I, T *tmp, int nx, int ny, double sigma);
+
+// generic bicubic resampling out(i1,j1) = bicubic(in, j1/fx, i1/fy, border_out=false)
+// (zoom_out: fx=fy=factor, src/zoom.cpp:67-75; zoom_in: per-axis factors, src/zoom.cpp:142-154)
+template <typename T> int op_resample(ofx_ctx *ctx, const T *in, T *out, int nx, int ny, int nxx, int nyy,
+                                      double fx, double fy);
+// zoom_in of an interleaved flow field + `*= scale` (src/tvl1flow.cpp:302-309)
+template <typename T> int op_zoom_in_flow(ofx_ctx *ctx, const typename Pix<T>::v2 *U, typename Pix<T>::v2 *Uout,
+                                          int nx, int ny, int nxx, int nyy, double scale);
+// zoom_out (src/zoom.cpp:41-78): tmpA, tmpB are nx*ny scratch images
+template <typename T> int op_zoom_out(ofx_ctx *ctx, const T *I, T *Iout, T *tmpA, T *tmpB, int nx, int ny,
+                                      double factor);
+
+// planar operators for the operator-level API
+template <typename T> int op_divergence(ofx_ctx *ctx, const T *v1, const T *v2, T *div, int nx, int ny);
+template <typename T> int op_forward_gradient(ofx_ctx *ctx, const T *f, T *fx, T *fy, int nx, int ny);
+template <typename T> int op_centered_gradient(ofx_ctx *ctx, const T *f, T *dx, T *dy, int nx, int ny);
+template <typename T> int op_second_derivative(ofx_ctx *ctx, const T *f, T *out, int nx, int ny, int which);
+template <typename T> int op_bicubic_warp(ofx_ctx *ctx, const T *in, const T *u, const T *v, T *out, int nx,
+                                          int ny, int border_out);
+template <typename T> int op_bicubic_at(ofx_ctx *ctx, const T *in, const double *uu, const double *vv,
+                                        double *out, int n, int nx, int ny, int border_out);
+
+static inline hipError_t ofx_launch_status() { return hipGetLastError(); }

@@ -1,0 +1,477 @@
+// ofx_ops.hip -- gfx950 kernels + launchers for the shared operators and the pyramid
+// (reference: src/operators.cpp, src/bicubic_interpolation.cpp, src/zoom.cpp, src/utils.cpp).
+//
+// All of these are HBM-bound elementwise / small-stencil / gather kernels: one pixel per lane,
+// x fastest so every wave touches 64 consecutive pixels of a row (coalesced), 64x4 blocks so a
+// block's four waves share their vertical neighbours through L1.  They run once per pyramid level
+// or once per warp, never inside the inner iteration.
+#include "ofx_ops.h"
+#include "ofx_device.h"
+
+#include <cmath>
+
+#define BX 64
+#define BY 4
+
+static inline dim3 grid2d(int nx, int ny) { return dim3(ofx_cdiv(nx, BX), ofx_cdiv(ny, BY)); }
+static inline dim3 block2d() { return dim3(BX, BY); }
+static inline int grid1d(size_t n) { return (int) ((n + 255) / 256); }
+
+#define OFX_LAUNCH_CHECK(ctx)                                                                    \
+    do {                                                                                         \
+        hipError_t e__ = hipGetLastError();                                                      \
+        if (e__ != hipSuccess)                                                                   \
+            return ofx_fail((ctx), OFX_ERR_HIP, "kernel launch failed: %s (%s:%d)",              \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                         \
+    } while (0)
+
+// ---- layout conversions ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_convert_in(const double *__restrict__ src, T *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stn(dst + i, src[i]);
+}
+
+template <typename T>
+__global__ void k_convert_out(const T *__restrict__ src, double *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = ldw(src + i);
+}
+
+template <typename T>
+__global__ void k_interleave2(const double *__restrict__ a, const double *__restrict__ b,
+                              typename Pix<T>::v2 *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stn2(dst + i, make_double2(a[i], b[i]));
+}
+
+template <typename T>
+__global__ void k_deinterleave2(const typename Pix<T>::v2 *__restrict__ src, double *__restrict__ a,
+                                double *__restrict__ b, size_t n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double2 v = ldw2(src + i);
+        a[i] = v.x;
+        b[i] = v.y;
+    }
+}
+
+// (u,v) -> float32 pairs: the cast of src/tvl1flow_main.cpp:209-213
+template <typename T>
+__global__ void k_to_flo(const typename Pix<T>::v2 *__restrict__ src, float2 *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double2 v = ldw2(src + i);
+        dst[i] = make_float2((float) v.x, (float) v.y);
+    }
+}
+
+template <typename T> int op_convert_in(ofx_ctx *ctx, const double *src, T *dst, size_t n)
+{
+    hipLaunchKernelGGL(k_convert_in<T>, dim3(grid1d(n)), dim3(256), 0, ctx->stream, src, dst, n);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+template <typename T> int op_convert_out(ofx_ctx *ctx, const T *src, double *dst, size_t n)
+{
+    hipLaunchKernelGGL(k_convert_out<T>, dim3(grid1d(n)), dim3(256), 0, ctx->stream, src, dst, n);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+template <typename T>
+int op_interleave2(ofx_ctx *ctx, const double *a, const double *b, typename Pix<T>::v2 *dst, size_t n)
+{
+    hipLaunchKernelGGL(k_interleave2<T>, dim3(grid1d(n)), dim3(256), 0, ctx->stream, a, b, dst, n);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+template <typename T>
+int op_deinterleave2(ofx_ctx *ctx, const typename Pix<T>::v2 *src, double *a, double *b, size_t n)
+{
+    hipLaunchKernelGGL(k_deinterleave2<T>, dim3(grid1d(n)), dim3(256), 0, ctx->stream, src, a, b, n);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+template <typename T> int op_to_flo(ofx_ctx *ctx, const typename Pix<T>::v2 *src, float2 *dst, size_t n)
+{
+    hipLaunchKernelGGL(k_to_flo<T>, dim3(grid1d(n)), dim3(256), 0, ctx->stream, src, dst, n);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+template <typename T> int op_fill2(ofx_ctx *ctx, typename Pix<T>::v2 *dst, size_t n)
+{
+    OFX_HIP(ctx, hipMemsetAsync(dst, 0, n * sizeof(typename Pix<T>::v2), ctx->stream));
+    return OFX_OK;
+}
+
+// ---- image_normalization_2 (src/utils.cpp:283-326, getminmax :509-525) -----------------------------
+// min/max are exact (order-independent); two-stage reduction: per-block partials, then one block.
+#define MM_BLOCKS 1024
+template <typename T>
+__global__ void k_minmax_partial(const T *__restrict__ I1, const T *__restrict__ I2, int size,
+                                 double *__restrict__ part /* [2][MM_BLOCKS] */)
+{
+    double lo = ldw(I1), hi = lo;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < (size_t) size;
+         i += (size_t) gridDim.x * blockDim.x) {
+        const double a = ldw(I1 + i), b = ldw(I2 + i);
+        lo = a < lo ? a : lo; hi = a > hi ? a : hi;
+        lo = b < lo ? b : lo; hi = b > hi ? b : hi;
+    }
+    lo = wave_allreduce_min(lo);
+    hi = wave_allreduce_max(hi);
+    __shared__ double slo[4], shi[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { slo[w] = lo; shi[w] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) { lo = slo[k] < lo ? slo[k] : lo; hi = shi[k] > hi ? shi[k] : hi; }
+        part[blockIdx.x] = lo;
+        part[MM_BLOCKS + blockIdx.x] = hi;
+    }
+}
+
+__global__ void k_minmax_final(const double *__restrict__ part, int nblocks, double *__restrict__ mm)
+{
+    double lo = part[0], hi = part[MM_BLOCKS];
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+        lo = part[i] < lo ? part[i] : lo;
+        hi = part[MM_BLOCKS + i] > hi ? part[MM_BLOCKS + i] : hi;
+    }
+    lo = wave_allreduce_min(lo);
+    hi = wave_allreduce_max(hi);
+    __shared__ double slo[4], shi[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { slo[w] = lo; shi[w] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) { lo = slo[k] < lo ? slo[k] : lo; hi = shi[k] > hi ? shi[k] : hi; }
+        mm[0] = lo;
+        mm[1] = hi;
+    }
+}
+
+template <typename T>
+__global__ void k_normalize2(const T *__restrict__ I1, const T *__restrict__ I2, T *__restrict__ o1,
+                             T *__restrict__ o2, int size, const double *__restrict__ mm)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t) size) return;
+    const double lo = mm[0], den = mm[1] - mm[0];
+    const double a = ldw(I1 + i), b = ldw(I2 + i);
+    if (den > 0) {
+        stn(o1 + i, 255.0 * (a - lo) / den);
+        stn(o2 + i, 255.0 * (b - lo) / den);
+    } else {
+        stn(o1 + i, a);
+        stn(o2 + i, b);
+    }
+}
+
+template <typename T>
+int op_normalize2(ofx_ctx *ctx, const T *I1, const T *I2, T *o1, T *o2, int size, double *scr)
+{
+    int nb = grid1d((size_t) size);
+    if (nb > MM_BLOCKS) nb = MM_BLOCKS;
+    double *part = scr, *mm = scr + 2 * MM_BLOCKS;
+    hipLaunchKernelGGL(k_minmax_partial<T>, dim3(nb), dim3(256), 0, ctx->stream, I1, I2, size, part);
+    OFX_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, ctx->stream, part, nb, mm);
+    OFX_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_normalize2<T>, dim3(grid1d((size_t) size)), dim3(256), 0, ctx->stream, I1, I2, o1, o2,
+                       size, mm);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+
+// ---- gaussian (src/operators.cpp:506-624) -----------------------------------------------------------
+int ofx_gauss_taps(double sigma, GaussTaps *t)
+{
+    const double den = 2 * sigma * sigma;
+    const int size = (int) (5 * sigma) + 1;                 // DEFAULT_GAUSSIAN_WINDOW_SIZE, operators.h:120
+    if (size < 1 || size > OFX_GAUSS_MAX_TAPS) return OFX_ERR_ARG;
+    t->size = size;
+    for (int i = 0; i < size; i++)
+        t->B[i] = 1 / (sigma * sqrt(2.0 * 3.1415926)) * exp(-i * i / den);   // :527 (pi truncated)
+    double norm = 0;
+    for (int i = 0; i < size; i++) norm += t->B[i];
+    norm *= 2;
+    norm -= t->B[0];
+    for (int i = 0; i < size; i++) t->B[i] /= norm;
+    return OFX_OK;
+}
+
+// reflecting boundary of :557-562: left of the image the edge sample is NOT repeated (t=-1 -> 1),
+// right of it it IS repeated (t=n -> n-1).
+OFX_DEV int gauss_reflect(int t, int n) { return t < 0 ? -t : (t >= n ? 2 * n - 1 - t : t); }
+
+template <typename T, bool ALONG_X>
+__global__ void k_gauss_pass(const T *__restrict__ in, T *__restrict__ out, int nx, int ny, GaussTaps taps)
+{
+    const int j = blockIdx.x * BX + threadIdx.x;
+    const int i = blockIdx.y * BY + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t p = (size_t) i * nx + j;
+    double sum = taps.B[0] * ldw(in + p);
+    if (ALONG_X) {
+        const T *row = in + (size_t) i * nx;
+        for (int k = 1; k < taps.size; k++)
+            sum += taps.B[k] * (ldw(row + gauss_reflect(j - k, nx)) + ldw(row + gauss_reflect(j + k, nx)));
+    } else {
+        for (int k = 1; k < taps.size; k++)
+            sum += taps.B[k] * (ldw(in + (size_t) gauss_reflect(i - k, ny) * nx + j) +
+                                ldw(in + (size_t) gauss_reflect(i + k, ny) * nx + j));
+    }
+    stn(out + p, sum);
+}
+
+template <typename T> int op_gaussian(ofx_ctx *ctx, T *I, T *tmp, int nx, int ny, double sigma)
+{
+    GaussTaps taps;
+    if (ofx_gauss_taps(sigma, &taps) != OFX_OK)
+        return ofx_fail(ctx, OFX_ERR_ARG, "gaussian: sigma %g needs more than %d taps", sigma, OFX_GAUSS_MAX_TAPS);
+    // reference: throws when size > xdim (:520-522); reads out of bounds when size == xdim or
+    // size >= ydim -- all three are reported as OFX_ERR_SIGMA here.
+    if (taps.size >= nx || taps.size >= ny)
+        return ofx_fail(ctx, OFX_ERR_SIGMA, "GaussianSmooth: sigma too large (radius %d, image %dx%d)",
+                        taps.size, nx, ny);
+    hipLaunchKernelGGL((k_gauss_pass<T, true>), grid2d(nx, ny), block2d(), 0, ctx->stream, (const T *) I, tmp,
+                       nx, ny, taps);
+    OFX_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL((k_gauss_pass<T, false>), grid2d(nx, ny), block2d(), 0, ctx->stream, (const T *) tmp, I,
+                       nx, ny, taps);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+
+// ---- bicubic resampling: zoom_out / zoom_in (src/zoom.cpp:41-78,132-155) ---------------------------
+template <typename T>
+__global__ void k_resample(const T *__restrict__ in, T *__restrict__ out, int nx, int ny, int nxx, int nyy,
+                           double fx, double fy)
+{
+    const int j1 = blockIdx.x * BX + threadIdx.x;
+    const int i1 = blockIdx.y * BY + threadIdx.y;
+    if (j1 >= nxx || i1 >= nyy) return;
+    const double i2 = i1 / fy, j2 = j1 / fx;
+    const BicubicTaps t = bicubic_taps(j2, i2, nx, ny);
+    stn(out + (size_t) i1 * nxx + j1, bicubic_sample(in, t, nx));
+}
+
+template <typename T>
+__global__ void k_zoom_in_flow(const typename Pix<T>::v2 *__restrict__ U, typename Pix<T>::v2 *__restrict__ Uout,
+                               int nx, int ny, int nxx, int nyy, double fx, double fy, double scale)
+{
+    const int j1 = blockIdx.x * BX + threadIdx.x;
+    const int i1 = blockIdx.y * BY + threadIdx.y;
+    if (j1 >= nxx || i1 >= nyy) return;
+    const double i2 = i1 / fy, j2 = j1 / fx;
+    const BicubicTaps t = bicubic_taps(j2, i2, nx, ny);
+    double c1[4], c2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double2 v0 = ldw2(U + (size_t) t.row[0] * nx + t.col[k]);
+        const double2 v1 = ldw2(U + (size_t) t.row[1] * nx + t.col[k]);
+        const double2 v2 = ldw2(U + (size_t) t.row[2] * nx + t.col[k]);
+        const double2 v3 = ldw2(U + (size_t) t.row[3] * nx + t.col[k]);
+        c1[k] = cubic_cell(v0.x, v1.x, v2.x, v3.x, t.fy);
+        c2[k] = cubic_cell(v0.y, v1.y, v2.y, v3.y, t.fy);
+    }
+    double2 r;
+    // In float storage the reference-equivalent value would be rounded to T between zoom_in and the
+    // `*= 1/zfactor` loop; in double storage both are exact IEEE steps, so one fused store is identical.
+    r.x = cubic_cell(c1[0], c1[1], c1[2], c1[3], t.fx) * scale;
+    r.y = cubic_cell(c2[0], c2[1], c2[2], c2[3], t.fx) * scale;
+    stn2(Uout + (size_t) i1 * nxx + j1, r);
+}
+
+template <typename T>
+int op_resample(ofx_ctx *ctx, const T *in, T *out, int nx, int ny, int nxx, int nyy, double fx, double fy)
+{
+    hipLaunchKernelGGL(k_resample<T>, grid2d(nxx, nyy), block2d(), 0, ctx->stream, in, out, nx, ny, nxx, nyy, fx, fy);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+
+template <typename T>
+int op_zoom_in_flow(ofx_ctx *ctx, const typename Pix<T>::v2 *U, typename Pix<T>::v2 *Uout, int nx, int ny,
+                    int nxx, int nyy, double scale)
+{
+    const double fx = ((double) nxx / nx), fy = ((double) nyy / ny);     // zoom.cpp:141-142
+    hipLaunchKernelGGL(k_zoom_in_flow<T>, grid2d(nxx, nyy), block2d(), 0, ctx->stream, U, Uout, nx, ny, nxx, nyy,
+                       fx, fy, scale);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+
+template <typename T>
+int op_zoom_out(ofx_ctx *ctx, const T *I, T *Iout, T *tmpA, T *tmpB, int nx, int ny, double factor)
+{
+    int nxx, nyy;
+    ofx_zoom_size(nx, ny, &nxx, &nyy, factor);
+    const double sigma = 0.6 * sqrt(1.0 / (factor * factor) - 1.0);      // ZOOM_SIGMA_ZERO, zoom.cpp:15,60
+    OFX_HIP(ctx, hipMemcpyAsync(tmpA, I, (size_t) nx * ny * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    OFX_TRY(op_gaussian<T>(ctx, tmpA, tmpB, nx, ny, sigma));
+    return op_resample<T>(ctx, tmpA, Iout, nx, ny, nxx, nyy, factor, factor);
+}
+
+// ---- planar stencil operators (operator-level API) --------------------------------------------------
+template <typename T>
+__global__ void k_divergence(const T *__restrict__ v1, const T *__restrict__ v2, T *__restrict__ div, int nx, int ny)
+{
+    const int j = blockIdx.x * BX + threadIdx.x;
+    const int i = blockIdx.y * BY + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t p = (size_t) i * nx + j;
+    const double ac = ldw(v1 + p), bc = ldw(v2 + p);
+    const double al = j > 0 ? ldw(v1 + p - 1) : 0.0;
+    const double bu = i > 0 ? ldw(v2 + p - nx) : 0.0;
+    stn(div + p, div_backward(ac, al, bc, bu, j == 0, j == nx - 1, i == 0, i == ny - 1));
+}
+
+// src/operators.cpp:86-125
+template <typename T>
+__global__ void k_forward_gradient(const T *__restrict__ f, T *__restrict__ fx, T *__restrict__ fy, int nx, int ny)
+{
+    const int j = blockIdx.x * BX + threadIdx.x;
+    const int i = blockIdx.y * BY + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t p = (size_t) i * nx + j;
+    const double c = ldw(f + p);
+    stn(fx + p, j < nx - 1 ? ldw(f + p + 1) - c : 0.0);
+    stn(fy + p, i < ny - 1 ? ldw(f + p + nx) - c : 0.0);
+}
+
+// src/operators.cpp:335-406 (nz = 1): the missing neighbour at a border is the pixel itself, factor 1/2 kept
+template <typename T>
+__global__ void k_centered_gradient(const T *__restrict__ f, T *__restrict__ dx, T *__restrict__ dy, int nx, int ny)
+{
+    const int j = blockIdx.x * BX + threadIdx.x;
+    const int i = blockIdx.y * BY + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+    const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+    const size_t p = (size_t) i * nx + j;
+    stn(dx + p, 0.5 * (ldw(f + (size_t) i * nx + jr) - ldw(f + (size_t) i * nx + jl)));
+    stn(dy + p, 0.5 * (ldw(f + (size_t) id * nx + j) - ldw(f + (size_t) iu * nx + j)));
+}
+
+// Dxx / Dyy / Dxy = mask3x3 (src/operators.cpp:132-328) specialised to the three fixed masks.  Taps
+// that fall outside fold onto the edge sample and their weights are summed before the multiply, so
+// e.g. Dxx at j=0 is in[0]*(1-2) + in[1]; zero-weight taps add +-0 and drop out.
+template <typename T>
+__global__ void k_second_derivative(const T *__restrict__ f, T *__restrict__ out, int nx, int ny, int which)
+{
+    const int j = blockIdx.x * BX + threadIdx.x;
+    const int i = blockIdx.y * BY + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t p = (size_t) i * nx + j;
+    double r;
+    if (which == 0) {                       // Dxx: 1 -2 1 along x
+        if (j == 0)            r = ldw(f + p) * -1.0 + ldw(f + p + 1);
+        else if (j == nx - 1)  r = ldw(f + p - 1) + ldw(f + p) * -1.0;
+        else                   r = ldw(f + p - 1) + ldw(f + p) * -2.0 + ldw(f + p + 1);
+    } else if (which == 1) {                // Dyy: 1 -2 1 along y
+        if (i == 0)            r = ldw(f + p) * -1.0 + ldw(f + p + nx);
+        else if (i == ny - 1)  r = ldw(f + p - nx) + ldw(f + p) * -1.0;
+        else                   r = ldw(f + p - nx) + ldw(f + p) * -2.0 + ldw(f + p + nx);
+    } else {                                // Dxy: +-1/4 on the four diagonal neighbours (clamped)
+        const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+        const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+        r = ldw(f + (size_t) iu * nx + jl) * 0.25 + ldw(f + (size_t) iu * nx + jr) * -0.25 +
+            ldw(f + (size_t) id * nx + jl) * -0.25 + ldw(f + (size_t) id * nx + jr) * 0.25;
+    }
+    stn(out + p, r);
+}
+
+// src/bicubic_interpolation.cpp:352-374
+template <typename T>
+__global__ void k_bicubic_warp(const T *__restrict__ in, const T *__restrict__ u, const T *__restrict__ v,
+                               T *__restrict__ out, int nx, int ny, int border_out)
+{
+    const int j = blockIdx.x * BX + threadIdx.x;
+    const int i = blockIdx.y * BY + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t p = (size_t) i * nx + j;
+    const double uu = j + ldw(u + p), vv = i + ldw(v + p);
+    const BicubicTaps t = bicubic_taps(uu, vv, nx, ny);
+    stn(out + p, (t.out && border_out) ? 0.0 : bicubic_sample(in, t, nx));
+}
+
+template <typename T>
+__global__ void k_bicubic_at(const T *__restrict__ in, const double *__restrict__ uu, const double *__restrict__ vv,
+                             double *__restrict__ out, int n, int nx, int ny, int border_out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const BicubicTaps t = bicubic_taps(uu[k], vv[k], nx, ny);
+    out[k] = (t.out && border_out) ? 0.0 : bicubic_sample(in, t, nx);
+}
+
+template <typename T> int op_divergence(ofx_ctx *ctx, const T *v1, const T *v2, T *div, int nx, int ny)
+{
+    hipLaunchKernelGGL(k_divergence<T>, grid2d(nx, ny), block2d(), 0, ctx->stream, v1, v2, div, nx, ny);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+template <typename T> int op_forward_gradient(ofx_ctx *ctx, const T *f, T *fx, T *fy, int nx, int ny)
+{
+    hipLaunchKernelGGL(k_forward_gradient<T>, grid2d(nx, ny), block2d(), 0, ctx->stream, f, fx, fy, nx, ny);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+template <typename T> int op_centered_gradient(ofx_ctx *ctx, const T *f, T *dx, T *dy, int nx, int ny)
+{
+    hipLaunchKernelGGL(k_centered_gradient<T>, grid2d(nx, ny), block2d(), 0, ctx->stream, f, dx, dy, nx, ny);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+template <typename T> int op_second_derivative(ofx_ctx *ctx, const T *f, T *out, int nx, int ny, int which)
+{
+    hipLaunchKernelGGL(k_second_derivative<T>, grid2d(nx, ny), block2d(), 0, ctx->stream, f, out, nx, ny, which);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+template <typename T>
+int op_bicubic_warp(ofx_ctx *ctx, const T *in, const T *u, const T *v, T *out, int nx, int ny, int border_out)
+{
+    hipLaunchKernelGGL(k_bicubic_warp<T>, grid2d(nx, ny), block2d(), 0, ctx->stream, in, u, v, out, nx, ny, border_out);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+template <typename T>
+int op_bicubic_at(ofx_ctx *ctx, const T *in, const double *uu, const double *vv, double *out, int n, int nx,
+                  int ny, int border_out)
+{
+    hipLaunchKernelGGL(k_bicubic_at<T>, dim3(grid1d((size_t) n)), dim3(256), 0, ctx->stream, in, uu, vv, out, n, nx,
+                       ny, border_out);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+
+// ---- explicit instantiations -----------------------------------------------------------------------
+#define OFX_INSTANTIATE(T)                                                                                           \
+    template int op_convert_in<T>(ofx_ctx *, const double *, T *, size_t);                                            \
+    template int op_convert_out<T>(ofx_ctx *, const T *, double *, size_t);                                           \
+    template int op_interleave2<T>(ofx_ctx *, const double *, const double *, Pix<T>::v2 *, size_t);                  \
+    template int op_deinterleave2<T>(ofx_ctx *, const Pix<T>::v2 *, double *, double *, size_t);                      \
+    template int op_to_flo<T>(ofx_ctx *, const Pix<T>::v2 *, float2 *, size_t);                                       \
+    template int op_fill2<T>(ofx_ctx *, Pix<T>::v2 *, size_t);                                                        \
+    template int op_normalize2<T>(ofx_ctx *, const T *, const T *, T *, T *, int, double *);                          \
+    template int op_gaussian<T>(ofx_ctx *, T *, T *, int, int, double);                                               \
+    template int op_resample<T>(ofx_ctx *, const T *, T *, int, int, int, int, double, double);                       \
+    template int op_zoom_in_flow<T>(ofx_ctx *, const Pix<T>::v2 *, Pix<T>::v2 *, int, int, int, int, double);         \
+    template int op_zoom_out<T>(ofx_ctx *, const T *, T *, T *, T *, int, int, double);                               \
+    template int op_divergence<T>(ofx_ctx *, const T *, const T *, T *, int, int);                                    \
+    template int op_forward_gradient<T>(ofx_ctx *, const T *, T *, T *, int, int);                                    \
+    template int op_centered_gradient<T>(ofx_ctx *, const T *, T *, T *, int, int);                                   \
+    template int op_second_derivative<T>(ofx_ctx *, const T *, T *, int, int, int);                                   \
+    template int op_bicubic_warp<T>(ofx_ctx *, const T *, const T *, const T *, T *, int, int, int);                  \
+    template int op_bicubic_at<T>(ofx_ctx *, const T *, const double *, const double *, double *, int, int, int, int);
+
+OFX_INSTANTIATE(double)
+OFX_INSTANTIATE(float)

@@ -1,0 +1,679 @@
+// ofx_tvl1.hip -- TV-L1 primal-dual solver on gfx950 (reference: src/tvl1flow.cpp).
+//
+// Device data layout of one pyramid level (T = storage type, N = nx*ny, row-major):
+//   U[2]   : (u1,u2)        interleaved pairs, ping-pong          2 T / px each
+//   P1[2]  : (p11,p12)      interleaved pairs, ping-pong          2 T / px each
+//   P2[2]  : (p21,p22)      interleaved pairs, ping-pong          2 T / px each
+//   A      : (I1wx,I1wy)    warped gradient, constant per warp    2 T / px
+//   R      : rho_c          constant part of rho, per warp        1 T / px
+//   I1pack : (I1,I1x,I1y,0) target image + centred gradient       4 T / px (gathered by the warp)
+//   I0     : source image                                          1 T / px
+// Every stream is read/written as whole 16-byte (f64) pairs per lane with unit stride, i.e. each
+// wave-instruction moves one contiguous 1 KiB segment.
+//
+// k_tvl1_iter = ONE launch per inner iteration of src/tvl1flow.cpp:113-182, fusing all five sweeps
+// (threshold, div p, u update + error, grad u, dual update).  Compulsory traffic per pixel and
+// iteration: read U,P1,P2,A,R (9 T) + write U,P1,P2 (6 T) = 15 T = 120 B (f64) / 60 B (f32); `grad`
+// is recomputed from A (bit-identical in f64).  The as-written reference moves 40 T.
+//
+// Work decomposition: one WAVE owns a strip of 62 output columns (64 lanes = 62 + one halo column on
+// each side) and marches down `rows` image rows.  Vertical neighbours (p12/p22 of the row above,
+// u_new of the row below) live in the lane's own registers across marching steps; horizontal
+// neighbours (p11/p21 of the left column, u_new of the right column) come from the adjacent lane
+// through a wave shift.  No LDS, no barriers, no inter-wave communication; the only redundant work
+// is the two halo lanes (3 %) and one extra row per strip (u_new of the row below the strip).
+// u and p are ping-pong buffered because neighbouring strips read this strip's old values.
+//
+// Convergence test without per-iteration host sync: each wave adds its partial sum of |du|^2 into
+// err[k][wave % 64] (one f64 atomic per wave); the NEXT launch begins by summing the 64 shards of
+// err[k-1] in a fixed order and returns immediately if `error > eps^2` is false -- once one iteration
+// is "done" every later launch sees an untouched (zero) slot and is a no-op too.  The host enqueues
+// iterations in chunks, each followed by a one-block finalize kernel that publishes {n, done, error};
+// it polls that record one chunk behind, so the GPU never idles and `n` is exactly the reference's.
+#include "ofx_ops.h"
+#include "ofx_device.h"
+
+#include <chrono>
+#include <cmath>
+
+#define TVL1_GRAD_IS_ZERO 1E-10          // src/tvl1flow.cpp:24
+#define TVL1_PRESMOOTHING_SIGMA 0.8      // src/tvl1flow.cpp:23
+#define STRIP_OUT 62                     // output columns per wave
+
+#define OFX_LAUNCH_CHECK(ctx)                                                                    \
+    do {                                                                                         \
+        hipError_t e__ = hipGetLastError();                                                      \
+        if (e__ != hipSuccess)                                                                   \
+            return ofx_fail((ctx), OFX_ERR_HIP, "kernel launch failed: %s (%s:%d)",              \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                         \
+    } while (0)
+
+template <typename T> OFX_DEV double rnd_to(double x);
+template <> OFX_DEV double rnd_to<double>(double x) { return x; }
+template <> OFX_DEV double rnd_to<float>(double x) { return (double) (float) x; }
+
+// error of iteration slot `k`: sum of the 64 shards in a fixed butterfly order, then `/ size`
+// exactly like src/tvl1flow.cpp:162.  Must be called by a full wave.
+OFX_DEV double tvl1_slot_error(const double *err, int k, int size)
+{
+    const int lane = threadIdx.x & 63;
+    const double e = wave_allreduce_sum(err[(size_t) k * OFX_NSHARD + lane]);
+    return e / size;
+}
+
+template <typename T> struct RowIn {
+    double2 u, p1, p2, a;
+    double r;
+};
+
+template <typename T>
+OFX_DEV RowIn<T> tvl1_load_row(const typename Pix<T>::v2 *U, const typename Pix<T>::v2 *P1,
+                               const typename Pix<T>::v2 *P2, const typename Pix<T>::v2 *A, const T *R, size_t p)
+{
+    RowIn<T> r;
+    r.u = ldw2(U + p);
+    r.p1 = ldw2(P1 + p);
+    r.p2 = ldw2(P2 + p);
+    r.a = ldw2(A + p);
+    r.r = ldw(R + p);
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_tvl1_iter(
+    const typename Pix<T>::v2 *__restrict__ Uin, typename Pix<T>::v2 *__restrict__ Uout,
+    const typename Pix<T>::v2 *__restrict__ P1in, typename Pix<T>::v2 *__restrict__ P1out,
+    const typename Pix<T>::v2 *__restrict__ P2in, typename Pix<T>::v2 *__restrict__ P2out,
+    const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ R, double *__restrict__ err, int k, int nx,
+    int ny, int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2)
+{
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+
+    // stopping test of src/tvl1flow.cpp:113 on the previous iteration's error
+    if (k > 0) {
+        const double error = tvl1_slot_error(err, k - 1, nx * ny);
+        if (!(error > eps2)) return;
+    }
+
+    const int strip = gw % strips_pad, band = gw / strips_pad;
+    if (strip >= strips_x) return;
+    const int y0 = band * rows;
+    if (y0 >= ny) return;
+    const int yend = (y0 + rows < ny) ? y0 + rows : ny;     // rows [y0, yend) are written by this wave
+
+    const int c = strip * STRIP_OUT - 1 + lane;             // lane 0 / 63 are the left / right halo columns
+    const int cc = c < 0 ? 0 : (c > nx - 1 ? nx - 1 : c);
+    const bool lef = (c == 0), rig = (c == nx - 1);
+    const bool owner = (lane >= 1) && (lane <= STRIP_OUT) && (c < nx);
+
+    // p12 / p22 of the row above the strip (dropped by the top-row rule when y0 == 0)
+    double up12 = 0.0, up22 = 0.0;
+    if (y0 > 0) {
+        const size_t pu = (size_t) (y0 - 1) * nx + cc;
+        up12 = ldw2(P1in + pu).y;
+        up22 = ldw2(P2in + pu).y;
+    }
+
+    double acc = 0.0;
+    double2 un_prev = make_double2(0.0, 0.0);                // u_new of row y-1
+    double2 p1_prev = make_double2(0.0, 0.0), p2_prev = make_double2(0.0, 0.0);
+
+    RowIn<T> cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) y0 * nx + cc);
+    for (int y = y0; y <= yend; y++) {
+        // prefetch the next row while this one is being processed
+        RowIn<T> nxt = cur;
+        if (y + 1 <= yend && y + 1 < ny) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) (y + 1) * nx + cc);
+
+        double2 un = make_double2(0.0, 0.0);
+        if (y < ny) {
+            // (ii) divergence of p, src/operators.cpp:35-78
+            const double l11 = wave_shift_up(cur.p1.x);
+            const double l21 = wave_shift_up(cur.p2.x);
+            const bool top = (y == 0), bot = (y == ny - 1);
+            const double div1 = div_backward(cur.p1.x, l11, cur.p1.y, up12, lef, rig, top, bot);
+            const double div2 = div_backward(cur.p2.x, l21, cur.p2.y, up22, lef, rig, top, bot);
+
+            // (i) thresholding operator TH, src/tvl1flow.cpp:117-143
+            const double ix = cur.a.x, iy = cur.a.y;
+            const double grad = ix * ix + iy * iy;                      // :100-104
+            const double rho = cur.r + (ix * cur.u.x + iy * cur.u.y);   // :119-120
+            const double ltg = l_t * grad;
+            const double fi = -rho / grad;
+            double d1, d2;
+            if (rho < -ltg)                     { d1 = l_t * ix;  d2 = l_t * iy; }
+            else if (rho > ltg)                 { d1 = -l_t * ix; d2 = -l_t * iy; }
+            else if (grad < TVL1_GRAD_IS_ZERO)  { d1 = 0.0;       d2 = 0.0; }
+            else                                { d1 = fi * ix;   d2 = fi * iy; }
+            const double v1 = cur.u.x + d1, v2 = cur.u.y + d2;
+
+            // (iii) primal update + error, :150-162
+            un.x = rnd_to<T>(v1 + theta * div1);
+            un.y = rnd_to<T>(v2 + theta * div2);
+            if (owner && y < yend) {
+                stn2(Uout + (size_t) y * nx + c, un);
+                acc += (un.x - cur.u.x) * (un.x - cur.u.x) + (un.y - cur.u.y) * (un.y - cur.u.y);
+            }
+        }
+
+        if (y > y0) {
+            // (iv) forward gradient of the NEW u at row y-1 (src/operators.cpp:86-125) and
+            // (v) dual update (src/tvl1flow.cpp:169-181)
+            const double r1 = wave_shift_down(un_prev.x);
+            const double r2 = wave_shift_down(un_prev.y);
+            const bool lastrow = (y - 1 == ny - 1);
+            const double u1x = rig ? 0.0 : r1 - un_prev.x;
+            const double u2x = rig ? 0.0 : r2 - un_prev.y;
+            const double u1y = lastrow ? 0.0 : un.x - un_prev.x;
+            const double u2y = lastrow ? 0.0 : un.y - un_prev.y;
+            const double g1 = hypot_ref(u1x, u1y);
+            const double g2 = hypot_ref(u2x, u2y);
+            const double ng1 = 1.0 + taut * g1;
+            const double ng2 = 1.0 + taut * g2;
+            double2 q1, q2;
+            q1.x = (p1_prev.x + taut * u1x) / ng1;
+            q1.y = (p1_prev.y + taut * u1y) / ng1;
+            q2.x = (p2_prev.x + taut * u2x) / ng2;
+            q2.y = (p2_prev.y + taut * u2y) / ng2;
+            if (owner) {
+                const size_t pp = (size_t) (y - 1) * nx + c;
+                stn2(P1out + pp, q1);
+                stn2(P2out + pp, q2);
+            }
+        }
+
+        un_prev = un;
+        p1_prev = cur.p1;
+        p2_prev = cur.p2;
+        up12 = cur.p1.y;
+        up22 = cur.p2.y;
+        cur = nxt;
+    }
+
+    acc = wave_allreduce_sum(acc);
+    if (lane == 0) atomicAdd(err + (size_t) k * OFX_NSHARD + (gw & (OFX_NSHARD - 1)), acc);
+}
+
+// One block (16 waves).  Scans the error slots of iterations [start, launched) and publishes how many
+// iterations really ran (the reference's `n`), whether the loop is over, and the error at exit.
+__global__ __launch_bounds__(1024) void k_tvl1_finalize(const double *__restrict__ err, int start, int launched,
+                                                        int max_iter, int size, double eps2, OfxIterState *st)
+{
+    __shared__ double s_err[OFX_TVL1_MAX_ITERATIONS];
+    if (st->done) return;                                   // an earlier chunk already ended the loop
+    const int w = threadIdx.x >> 6;
+    for (int k = start + w; k < launched; k += 16) {
+        const double e = tvl1_slot_error(err, k, size);
+        if ((threadIdx.x & 63) == 0) s_err[k - start] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = launched, done = (launched >= max_iter);
+        double error = launched > start ? s_err[launched - start - 1] : st->error;
+        for (int k = start; k < launched; k++) {
+            if (!(s_err[k - start] > eps2)) { n = k + 1; done = 1; error = s_err[k - start]; break; }
+        }
+        st->n = n;
+        st->done = done;
+        st->error = error;
+    }
+}
+
+// centred gradient of I1 packed next to I1 (src/tvl1flow.cpp:84 -> src/operators.cpp:335-406)
+template <typename T>
+__global__ void k_grad_pack(const T *__restrict__ I1, typename Pix<T>::v4 *__restrict__ pack, int nx, int ny)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+    const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+    const size_t p = (size_t) i * nx + j;
+    double4 o;
+    o.x = ldw(I1 + p);
+    o.y = 0.5 * (ldw(I1 + (size_t) i * nx + jr) - ldw(I1 + (size_t) i * nx + jl));
+    o.z = 0.5 * (ldw(I1 + (size_t) id * nx + j) - ldw(I1 + (size_t) iu * nx + j));
+    o.w = 0.0;
+    stn4(pack + p, o);
+}
+
+// Warp + linearisation (src/tvl1flow.cpp:94-109): the three bicubic warps of I1, I1x, I1y share one
+// set of tap indices and one 4-wide gather per tap; writes A = (I1wx, I1wy) and R = rho_c.
+template <typename T>
+__global__ void k_tvl1_warp(const typename Pix<T>::v4 *__restrict__ pack, const T *__restrict__ I0,
+                            const typename Pix<T>::v2 *__restrict__ U, typename Pix<T>::v2 *__restrict__ A,
+                            T *__restrict__ R, int nx, int ny)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t p = (size_t) i * nx + j;
+    const double2 u = ldw2(U + p);
+    const BicubicTaps t = bicubic_taps(j + u.x, i + u.y, nx, ny);
+    double I1w = 0.0, I1wx = 0.0, I1wy = 0.0;
+    if (!t.out) {                                            // border_out = true, :94-96
+        double c0[4], c1[4], c2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double4 v0 = ldw4(pack + (size_t) t.row[0] * nx + t.col[k]);
+            const double4 v1 = ldw4(pack + (size_t) t.row[1] * nx + t.col[k]);
+            const double4 v2 = ldw4(pack + (size_t) t.row[2] * nx + t.col[k]);
+            const double4 v3 = ldw4(pack + (size_t) t.row[3] * nx + t.col[k]);
+            c0[k] = cubic_cell(v0.x, v1.x, v2.x, v3.x, t.fy);
+            c1[k] = cubic_cell(v0.y, v1.y, v2.y, v3.y, t.fy);
+            c2[k] = cubic_cell(v0.z, v1.z, v2.z, v3.z, t.fy);
+        }
+        I1w = cubic_cell(c0[0], c0[1], c0[2], c0[3], t.fx);
+        I1wx = rnd_to<T>(cubic_cell(c1[0], c1[1], c1[2], c1[3], t.fx));
+        I1wy = rnd_to<T>(cubic_cell(c2[0], c2[1], c2[2], c2[3], t.fx));
+    }
+    stn2(A + p, make_double2(I1wx, I1wy));
+    stn(R + p, (I1w - I1wx * u.x - I1wy * u.y - ldw(I0 + p)));       // :107-108
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+template <typename T> struct Tvl1Level {
+    using v2 = typename Pix<T>::v2;
+    using v4 = typename Pix<T>::v4;
+    int nx, ny;
+    T  *I0, *I1;
+    v4 *pack;
+    v2 *U[2], *P1[2], *P2[2], *A;
+    T  *R;
+    int cur;        // which ping-pong half holds the live u / p
+};
+
+struct Tvl1Params {
+    double tau, lambda, theta, epsilon;
+    int warps, verbose, max_iter;
+    bool fixed;     // run exactly max_iter iterations (stopping test disabled)
+};
+
+template <typename T> static int tvl1_level_alloc(ofx_ctx *ctx, Tvl1Level<T> &L, int nx, int ny, bool images)
+{
+    const size_t n = (size_t) nx * ny;
+    L.nx = nx;
+    L.ny = ny;
+    L.cur = 0;
+    L.I0 = L.I1 = nullptr;
+    L.pack = nullptr;
+    if (images) {
+        OFX_TRY(ofx_alloc(ctx, n, &L.I0));
+        OFX_TRY(ofx_alloc(ctx, n, &L.I1));
+        OFX_TRY(ofx_alloc(ctx, n, &L.pack));
+    }
+    for (int h = 0; h < 2; h++) {
+        OFX_TRY(ofx_alloc(ctx, n, &L.U[h]));
+        OFX_TRY(ofx_alloc(ctx, n, &L.P1[h]));
+        OFX_TRY(ofx_alloc(ctx, n, &L.P2[h]));
+    }
+    OFX_TRY(ofx_alloc(ctx, n, &L.A));
+    OFX_TRY(ofx_alloc(ctx, n, &L.R));
+    return OFX_OK;
+}
+
+static int tvl1_pick_rows(const ofx_ctx *ctx, int nx, int ny)
+{
+    if (ctx->rows_per_wave > 0) return ctx->rows_per_wave;
+    // enough waves to fill 256 CUs several times over, but strips long enough to amortise the halo row
+    const int strips = ofx_cdiv(nx, STRIP_OUT);
+    int rows = 32;
+    while (rows > 4 && (long) strips * ofx_cdiv(ny, rows) < 4096) rows >>= 1;
+    return rows;
+}
+
+static int tvl1_pick_chunk(const ofx_ctx *ctx, int nx, int ny)
+{
+    if (ctx->chunk > 0) return ctx->chunk;
+    const double est_us = fmax(2.5, (double) nx * ny * 120.0 / 4.0e6);   // ~4 TB/s, launch floor 2.5 us
+    int c = (int) (80.0 / est_us);
+    return c < 4 ? 4 : (c > 50 ? 50 : c);
+}
+
+// The inner loop of one warp: launches iterations until the device reports the stopping test fired.
+// On return L.cur points at the half holding the result; *n_out / *err_out as the reference prints.
+template <typename T>
+static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, int *n_out, double *err_out,
+                               float *ms_out)
+{
+    const int nx = L.nx, ny = L.ny, size = nx * ny;
+    const int max_iter = P.max_iter;
+    const double l_t = P.lambda * P.theta, taut = P.tau / P.theta;
+    const double eps2 = P.fixed ? -1.0 : P.epsilon * P.epsilon;
+    const int rows = tvl1_pick_rows(ctx, nx, ny);
+    const int strips_x = ofx_cdiv(nx, STRIP_OUT), strips_pad = ofx_cdiv(strips_x, 4) * 4;
+    const int bands = ofx_cdiv(ny, rows);
+    const dim3 grid((unsigned) (strips_pad / 4) * bands), block(256);
+    const int chunk = tvl1_pick_chunk(ctx, nx, ny);
+    OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) max_iter * OFX_NSHARD, ctx->stream));
+    OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
+    if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+
+    // head / tail count the convergence polls issued / consumed; at most two are outstanding (the one
+    // the host waits for and one chunk of lookahead that keeps the GPU busy meanwhile).
+    int launched = 0, head = 0, tail = 0, slot_of[2] = {0, 0};
+    bool stop = false;
+    OfxIterState fin = {0, 0, 0.0};
+    const int base = L.cur;
+    for (;;) {
+        while (launched < max_iter && head - tail < 2) {
+            const int c = (max_iter - launched < chunk) ? max_iter - launched : chunk;
+            for (int q = 0; q < c; q++) {
+                const int k = launched + q;
+                const int in = (base + k) & 1, out = in ^ 1;
+                hipLaunchKernelGGL(k_tvl1_iter<T>, grid, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out],
+                                   L.P2[in], L.P2[out], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows, strips_x,
+                                   strips_pad, l_t, P.theta, taut, eps2);
+            }
+            OFX_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(k_tvl1_finalize, dim3(1), dim3(1024), 0, ctx->stream, (const double *) ctx->d_err,
+                               launched, launched + c, max_iter, size, eps2, ctx->d_state);
+            OFX_LAUNCH_CHECK(ctx);
+            launched += c;
+            const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
+            slot_of[head & 1] = slot;
+            OFX_HIP(ctx, hipMemcpyAsync(&ctx->h_state[slot], ctx->d_state, sizeof(OfxIterState),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+            OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
+            head++;
+        }
+        if (tail == head) break;
+        const int slot = slot_of[tail & 1];
+        OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
+        const OfxIterState st = ctx->h_state[slot];
+        tail++;
+        if (st.done) {
+            // A poll still in flight covers launches that are no-ops (their stopping test already
+            // fails); it is not drained -- stream order keeps it ahead of whatever is enqueued next.
+            stop = true;
+            fin = st;
+            break;
+        }
+    }
+    if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+    if (!stop) return ofx_fail(ctx, OFX_ERR_HIP, "tvl1: iteration loop ended without a final state");
+    L.cur = (base + fin.n) & 1;
+    *n_out = fin.n;
+    *err_out = fin.error;
+    if (ms_out) {
+        OFX_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
+        OFX_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev_t0, ctx->ev_t1));
+    }
+    return OFX_OK;
+}
+
+// src/tvl1flow.cpp:46-212 on device-resident level data; L.U[L.cur] holds the incoming flow.
+template <typename T>
+static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, int scale)
+{
+    const int nx = L.nx, ny = L.ny;
+    const size_t n = (size_t) nx * ny;
+    const dim3 g2(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), b2(64, 4);
+    if (nx < 2 || ny < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: level %dx%d too small", nx, ny);
+
+    hipLaunchKernelGGL(k_grad_pack<T>, g2, b2, 0, ctx->stream, (const T *) L.I1, L.pack, nx, ny);     // :84
+    OFX_LAUNCH_CHECK(ctx);
+    OFX_TRY(op_fill2<T>(ctx, L.P1[L.cur], n));                                                          // :87-90
+    OFX_TRY(op_fill2<T>(ctx, L.P2[L.cur], n));
+
+    ofx_stats &S = ctx->stats;
+    for (int w = 0; w < P.warps; w++) {
+        hipLaunchKernelGGL(k_tvl1_warp<T>, g2, b2, 0, ctx->stream, L.pack, (const T *) L.I0, L.U[L.cur], L.A, L.R,
+                           nx, ny);                                                                      // :94-109
+        OFX_LAUNCH_CHECK(ctx);
+        // p lives in the same ping-pong half as u
+        int it = 0;
+        double error = 0.0;
+        float ms = 0.f;
+        OFX_TRY(tvl1_run_iterations<T>(ctx, L, P, &it, &error, ctx->profile ? &ms : nullptr));
+        if (P.verbose) fprintf(stderr, "Warping: %d, Iterations: %d, Error: %f\n", w, it, error);      // :184-188
+        if (scale < OFX_MAX_SCALES) {
+            if (w < OFX_MAX_SOLVES) { S.iters[scale][w] = it; S.error[scale][w] = error; }
+            S.iter_ms[scale] += ms;
+            S.iter_launches[scale] += it;
+        }
+        S.work_pix_iters += (double) it * nx * ny;
+    }
+    return OFX_OK;
+}
+
+static void stats_begin(ofx_ctx *ctx, int nscales, int nsolves)
+{
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    ctx->stats.nscales = nscales;
+    ctx->stats.nsolves = nsolves;
+}
+
+// src/tvl1flow.cpp:219-328.  dI0 / dI1: device images of storage type T.  On success *Lout[0] holds the flow.
+template <typename T>
+static int tvl1_multiscale_dev(ofx_ctx *ctx, const T *dI0, const T *dI1, int nxx, int nyy, const Tvl1Params &P,
+                               int nscales, double zfactor, std::vector<Tvl1Level<T>> &lv)
+{
+    if (nscales < 1 || nscales > OFX_MAX_SCALES) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: nscales=%d", nscales);
+    if (nxx < 2 || nyy < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: image %dx%d too small", nxx, nyy);
+    if (!(zfactor > 0.0) || !(zfactor < 1.0)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: zfactor=%g", zfactor);
+    if (P.warps < 1) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: warps=%d", P.warps);
+
+    stats_begin(ctx, nscales, P.warps);
+    lv.resize(nscales);
+    int nx = nxx, ny = nyy;
+    for (int s = 0; s < nscales; s++) {
+        if (s) ofx_zoom_size(lv[s - 1].nx, lv[s - 1].ny, &nx, &ny, zfactor);                 // :263
+        if (nx < 2 || ny < 2) return ofx_fail(ctx, OFX_ERR_SIGMA, "tvl1: scale %d is %dx%d", s, nx, ny);
+        OFX_TRY(tvl1_level_alloc<T>(ctx, lv[s], nx, ny, true));
+        ctx->stats.nx[s] = nx;
+        ctx->stats.ny[s] = ny;
+    }
+    T *tmpA, *tmpB;
+    double *scr;
+    OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpA));
+    OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpB));
+    OFX_TRY(ofx_alloc(ctx, (size_t) 2 * 1024 + 2, &scr));
+
+    OFX_TRY(op_normalize2<T>(ctx, dI0, dI1, lv[0].I0, lv[0].I1, nxx * nyy, scr));               // :255
+    OFX_TRY(op_gaussian<T>(ctx, lv[0].I0, tmpA, nxx, nyy, TVL1_PRESMOOTHING_SIGMA));            // :258-259
+    OFX_TRY(op_gaussian<T>(ctx, lv[0].I1, tmpA, nxx, nyy, TVL1_PRESMOOTHING_SIGMA));
+    for (int s = 1; s < nscales; s++) {                                                          // :262-275
+        OFX_TRY(op_zoom_out<T>(ctx, lv[s - 1].I0, lv[s].I0, tmpA, tmpB, lv[s - 1].nx, lv[s - 1].ny, zfactor));
+        OFX_TRY(op_zoom_out<T>(ctx, lv[s - 1].I1, lv[s].I1, tmpA, tmpB, lv[s - 1].nx, lv[s - 1].ny, zfactor));
+    }
+    Tvl1Level<T> &C = lv[nscales - 1];
+    OFX_TRY(op_fill2<T>(ctx, C.U[0], (size_t) C.nx * C.ny));                                     // :278-280
+
+    for (int s = nscales - 1; s >= 0; s--) {                                                     // :283
+        if (P.verbose) fprintf(stderr, "Scale %d: %dx%d\n", s, lv[s].nx, lv[s].ny);
+        OFX_TRY(tvl1_single_scale_dev<T>(ctx, lv[s], P, s));
+        if (!s) break;
+        lv[s - 1].cur = 0;
+        OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U[lv[s].cur], lv[s - 1].U[0], lv[s].nx, lv[s].ny, lv[s - 1].nx,
+                                   lv[s - 1].ny, 1.0 / zfactor));                                // :302-309
+    }
+    return OFX_OK;
+}
+
+static Tvl1Params make_params(const ofx_ctx *ctx, double tau, double lambda, double theta, int warps,
+                               double epsilon, int verbose)
+{
+    Tvl1Params P;
+    P.tau = tau; P.lambda = lambda; P.theta = theta; P.epsilon = epsilon;
+    P.warps = warps; P.verbose = verbose;
+    P.max_iter = OFX_TVL1_MAX_ITERATIONS;
+    P.fixed = ctx->fixed_work != 0;     // option "fixed_work": every warp runs exactly MAX_ITERATIONS
+    return P;
+}
+
+template <typename T>
+static int upload_image(ofx_ctx *ctx, const double *h, size_t n, T **out)
+{
+    double *stage;
+    OFX_TRY(ofx_alloc(ctx, n, &stage));
+    OFX_TRY(ofx_alloc(ctx, n, out));
+    OFX_HIP(ctx, hipMemcpyAsync(stage, h, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return op_convert_in<T>(ctx, stage, *out, n);
+}
+
+template <typename T>
+static int tvl1_multiscale_host(ofx_ctx *ctx, const double *I0, const double *I1, double *u1, double *u2, int nx,
+                                int ny, const Tvl1Params &P, int nscales, double zfactor)
+{
+    const size_t n = (size_t) nx * ny;
+    T *dI0, *dI1;
+    OFX_TRY(upload_image<T>(ctx, I0, n, &dI0));
+    OFX_TRY(upload_image<T>(ctx, I1, n, &dI1));
+    std::vector<Tvl1Level<T>> lv;
+    OFX_TRY(tvl1_multiscale_dev<T>(ctx, dI0, dI1, nx, ny, P, nscales, zfactor, lv));
+    double *d1, *d2;
+    OFX_TRY(ofx_alloc(ctx, n, &d1));
+    OFX_TRY(ofx_alloc(ctx, n, &d2));
+    OFX_TRY(op_deinterleave2<T>(ctx, lv[0].U[lv[0].cur], d1, d2, n));
+    OFX_HIP(ctx, hipMemcpyAsync(u1, d1, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipMemcpyAsync(u2, d2, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return OFX_OK;
+}
+
+extern "C" int ofx_tvl1_multiscale(ofx_ctx *ctx, const double *I0, const double *I1, double *u1, double *u2, int nx,
+                                   int ny, double tau, double lambda, double theta, int nscales, double zfactor,
+                                   int warps, double epsilon, int verbose)
+{
+    OFX_ENTER(ctx);
+    if (!I0 || !I1 || !u1 || !u2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: NULL pointer");
+    const double t0 = ofx_now_ms();
+    const Tvl1Params P = make_params(ctx, tau, lambda, theta, warps, epsilon, verbose);
+    int s = ctx->precision == OFX_F64
+                ? tvl1_multiscale_host<double>(ctx, I0, I1, u1, u2, nx, ny, P, nscales, zfactor)
+                : tvl1_multiscale_host<float>(ctx, I0, I1, u1, u2, nx, ny, P, nscales, zfactor);
+    ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}
+
+template <typename T>
+static int tvl1_multiscale_devapi(ofx_ctx *ctx, const void *dI0, const void *dI1, void *d_flo, int nx, int ny,
+                                  const Tvl1Params &P, int nscales, double zfactor)
+{
+    std::vector<Tvl1Level<T>> lv;
+    OFX_TRY(tvl1_multiscale_dev<T>(ctx, (const T *) dI0, (const T *) dI1, nx, ny, P, nscales, zfactor, lv));
+    return op_to_flo<T>(ctx, lv[0].U[lv[0].cur], (float2 *) d_flo, (size_t) nx * ny);
+}
+
+extern "C" int ofx_tvl1_multiscale_dev(ofx_ctx *ctx, const void *dI0, const void *dI1, void *d_flo, int nx, int ny,
+                                       double tau, double lambda, double theta, int nscales, double zfactor,
+                                       int warps, double epsilon, int verbose)
+{
+    OFX_ENTER(ctx);
+    if (!dI0 || !dI1 || !d_flo) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: NULL pointer");
+    const double t0 = ofx_now_ms();
+    const Tvl1Params P = make_params(ctx, tau, lambda, theta, warps, epsilon, verbose);
+    int s = ctx->precision == OFX_F64 ? tvl1_multiscale_devapi<double>(ctx, dI0, dI1, d_flo, nx, ny, P, nscales, zfactor)
+                                      : tvl1_multiscale_devapi<float>(ctx, dI0, dI1, d_flo, nx, ny, P, nscales, zfactor);
+    ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}
+
+template <typename T>
+static int tvl1_single_scale_host(ofx_ctx *ctx, const double *I0, const double *I1, double *u1, double *u2, int nx,
+                                  int ny, const Tvl1Params &P)
+{
+    const size_t n = (size_t) nx * ny;
+    stats_begin(ctx, 1, P.warps);
+    ctx->stats.nx[0] = nx;
+    ctx->stats.ny[0] = ny;
+    Tvl1Level<T> L;
+    OFX_TRY(tvl1_level_alloc<T>(ctx, L, nx, ny, false));
+    OFX_TRY(upload_image<T>(ctx, I0, n, &L.I0));
+    OFX_TRY(upload_image<T>(ctx, I1, n, &L.I1));
+    OFX_TRY(ofx_alloc(ctx, n, &L.pack));
+    double *d1, *d2;
+    OFX_TRY(ofx_alloc(ctx, n, &d1));
+    OFX_TRY(ofx_alloc(ctx, n, &d2));
+    OFX_HIP(ctx, hipMemcpyAsync(d1, u1, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    OFX_HIP(ctx, hipMemcpyAsync(d2, u2, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    OFX_TRY(op_interleave2<T>(ctx, d1, d2, L.U[0], n));
+    OFX_TRY(tvl1_single_scale_dev<T>(ctx, L, P, 0));
+    OFX_TRY(op_deinterleave2<T>(ctx, L.U[L.cur], d1, d2, n));
+    OFX_HIP(ctx, hipMemcpyAsync(u1, d1, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipMemcpyAsync(u2, d2, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return OFX_OK;
+}
+
+extern "C" int ofx_tvl1_single_scale(ofx_ctx *ctx, const double *I0, const double *I1, double *u1, double *u2,
+                                     int nx, int ny, double tau, double lambda, double theta, int warps,
+                                     double epsilon, int verbose)
+{
+    OFX_ENTER(ctx);
+    if (!I0 || !I1 || !u1 || !u2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: NULL pointer");
+    if (nx < 2 || ny < 2 || warps < 1) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: bad size / warps");
+    const double t0 = ofx_now_ms();
+    const Tvl1Params P = make_params(ctx, tau, lambda, theta, warps, epsilon, verbose);
+    int s = ctx->precision == OFX_F64 ? tvl1_single_scale_host<double>(ctx, I0, I1, u1, u2, nx, ny, P)
+                                      : tvl1_single_scale_host<float>(ctx, I0, I1, u1, u2, nx, ny, P);
+    ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}
+
+template <typename T>
+static int tvl1_iterations_host(ofx_ctx *ctx, double *u1, double *u2, double *p11, double *p12, double *p21,
+                                double *p22, const double *I1wx, const double *I1wy, const double *rho_c, int nx,
+                                int ny, const Tvl1Params &P, double *error)
+{
+    const size_t n = (size_t) nx * ny;
+    stats_begin(ctx, 1, 1);
+    ctx->stats.nx[0] = nx;
+    ctx->stats.ny[0] = ny;
+    Tvl1Level<T> L;
+    OFX_TRY(tvl1_level_alloc<T>(ctx, L, nx, ny, false));
+    double *d[2];
+    OFX_TRY(ofx_alloc(ctx, n, &d[0]));
+    OFX_TRY(ofx_alloc(ctx, n, &d[1]));
+    struct { const double *a, *b; typename Pix<T>::v2 *dst; } up[4] = {
+        {u1, u2, L.U[0]}, {p11, p12, L.P1[0]}, {p21, p22, L.P2[0]}, {I1wx, I1wy, L.A}};
+    for (auto &e : up) {
+        OFX_HIP(ctx, hipMemcpyAsync(d[0], e.a, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        OFX_HIP(ctx, hipMemcpyAsync(d[1], e.b, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        OFX_TRY(op_interleave2<T>(ctx, d[0], d[1], e.dst, n));
+    }
+    OFX_HIP(ctx, hipMemcpyAsync(d[0], rho_c, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    OFX_TRY(op_convert_in<T>(ctx, d[0], L.R, n));
+
+    int it = 0;
+    double err = 0.0;
+    float ms = 0.f;
+    OFX_TRY(tvl1_run_iterations<T>(ctx, L, P, &it, &err, ctx->profile ? &ms : nullptr));
+    ctx->stats.iters[0][0] = it;
+    ctx->stats.error[0][0] = err;
+    ctx->stats.iter_ms[0] = ms;
+    ctx->stats.iter_launches[0] = it;
+    ctx->stats.work_pix_iters = (double) it * nx * ny;
+    if (error) *error = err;
+
+    struct { double *a, *b; typename Pix<T>::v2 *src; } down[3] = {
+        {u1, u2, L.U[L.cur]}, {p11, p12, L.P1[L.cur]}, {p21, p22, L.P2[L.cur]}};
+    for (auto &e : down) {
+        OFX_TRY(op_deinterleave2<T>(ctx, e.src, d[0], d[1], n));
+        OFX_HIP(ctx, hipMemcpyAsync(e.a, d[0], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        OFX_HIP(ctx, hipMemcpyAsync(e.b, d[1], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return OFX_OK;
+}
+
+extern "C" int ofx_tvl1_iterations(ofx_ctx *ctx, double *u1, double *u2, double *p11, double *p12, double *p21,
+                                   double *p22, const double *I1wx, const double *I1wy, const double *rho_c, int nx,
+                                   int ny, double tau, double lambda, double theta, int n_iter, double *error)
+{
+    OFX_ENTER(ctx);
+    if (!u1 || !u2 || !p11 || !p12 || !p21 || !p22 || !I1wx || !I1wy || !rho_c)
+        return ofx_fail(ctx, OFX_ERR_ARG, "tvl1_iterations: NULL pointer");
+    if (nx < 2 || ny < 2 || n_iter < 1 || n_iter > OFX_TVL1_MAX_ITERATIONS)
+        return ofx_fail(ctx, OFX_ERR_ARG, "tvl1_iterations: bad size / n_iter");
+    const double t0 = ofx_now_ms();
+    Tvl1Params P = make_params(ctx, tau, lambda, theta, 1, 0.0, 0);
+    P.max_iter = n_iter;
+    P.fixed = true;
+    int s = ctx->precision == OFX_F64
+                ? tvl1_iterations_host<double>(ctx, u1, u2, p11, p12, p21, p22, I1wx, I1wy, rho_c, nx, ny, P, error)
+                : tvl1_iterations_host<float>(ctx, u1, u2, p11, p12, p21, p22, I1wx, I1wy, rho_c, nx, ny, P, error);
+    ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}

@@ -1,0 +1,65 @@
+"""Shared fixtures.  `-m gpu` tests need a real MI355X and call the product through the C ABI;
+everything else runs on the CPU-only build container."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def ofx_mod():
+    return importlib.import_module("optical-flow-1_amd")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("optical-flow-1_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    if not os.path.exists(oracle.ORACLE_SO):
+        oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def orc(oracle_mod):
+    o = oracle_mod.Oracle()
+    o.set_num_threads(1)
+    return o
+
+
+@pytest.fixture(scope="session")
+def ref(oracle_mod):
+    if not oracle_mod.have_ref():
+        pytest.skip("oracle/_ref/libofref.so not built (needs /root/reference)")
+    r = oracle_mod.Ref()
+    r.set_num_threads(1)
+    return r
+
+
+@pytest.fixture(scope="session")
+def gpu64(ofx_mod):
+    """f64-storage context on cuda:0.  Fails loudly (no CPU fallback) if libofx.so or the GPU is missing."""
+    return ofx_mod.Ofx(0, ofx_mod.F64)
+
+
+@pytest.fixture(scope="session")
+def gpu32(ofx_mod):
+    return ofx_mod.Ofx(0, ofx_mod.F32)
+
+
+def aepe(u1, v1, u2, v2):
+    return float(np.mean(np.hypot(u1 - u2, v1 - v2)))
