@@ -90,16 +90,14 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
 
-    // stopping test of src/tvl1flow.cpp:113 on the previous iteration's error
-    if (k > 0) {
-        const double error = tvl1_slot_error(err, k - 1, nx * ny);
-        if (!(error > eps2)) return;
-    }
+    // The previous iteration's error shards are fetched first and tested last, so the ~2 us memory
+    // round trip overlaps with the first row's loads instead of preceding them.
+    double err_shard = 1.0;
+    if (k > 0) err_shard = err[(size_t) (k - 1) * OFX_NSHARD + lane];
 
     const int strip = gw % strips_pad, band = gw / strips_pad;
-    if (strip >= strips_x) return;
     const int y0 = band * rows;
-    if (y0 >= ny) return;
+    const bool idle = (strip >= strips_x) || (y0 >= ny);
     const int yend = (y0 + rows < ny) ? y0 + rows : ny;     // rows [y0, yend) are written by this wave
 
     const int c = strip * STRIP_OUT - 1 + lane;             // lane 0 / 63 are the left / right halo columns
@@ -109,17 +107,27 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
 
     // p12 / p22 of the row above the strip (dropped by the top-row rule when y0 == 0)
     double up12 = 0.0, up22 = 0.0;
-    if (y0 > 0) {
-        const size_t pu = (size_t) (y0 - 1) * nx + cc;
-        up12 = ldw2(P1in + pu).y;
-        up22 = ldw2(P2in + pu).y;
+    RowIn<T> cur;
+    if (!idle) {
+        if (y0 > 0) {
+            const size_t pu = (size_t) (y0 - 1) * nx + cc;
+            up12 = ldw2(P1in + pu).y;
+            up22 = ldw2(P2in + pu).y;
+        }
+        cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) y0 * nx + cc);
     }
+
+    // stopping test of src/tvl1flow.cpp:113 on the previous iteration's error
+    if (k > 0) {
+        const double error = wave_allreduce_sum(err_shard) / (nx * ny);
+        if (!(error > eps2)) return;
+    }
+    if (idle) return;
 
     double acc = 0.0;
     double2 un_prev = make_double2(0.0, 0.0);                // u_new of row y-1
     double2 p1_prev = make_double2(0.0, 0.0), p2_prev = make_double2(0.0, 0.0);
 
-    RowIn<T> cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) y0 * nx + cc);
     for (int y = y0; y <= yend; y++) {
         // prefetch the next row while this one is being processed
         RowIn<T> nxt = cur;
@@ -197,10 +205,14 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
 // One block (16 waves).  Scans the error slots of iterations [start, launched) and publishes how many
 // iterations really ran (the reference's `n`), whether the loop is over, and the error at exit.
 __global__ __launch_bounds__(1024) void k_tvl1_finalize(const double *__restrict__ err, int start, int launched,
-                                                        int max_iter, int size, double eps2, OfxIterState *st)
+                                                        int max_iter, int size, double eps2, OfxIterState *st,
+                                                        OfxIterState *host_st)
 {
     __shared__ double s_err[OFX_TVL1_MAX_ITERATIONS];
-    if (st->done) return;                                   // an earlier chunk already ended the loop
+    if (st->done) {                                         // an earlier chunk already ended the loop
+        if (threadIdx.x == 0) *host_st = *st;
+        return;
+    }
     const int w = threadIdx.x >> 6;
     for (int k = start + w; k < launched; k += 16) {
         const double e = tvl1_slot_error(err, k, size);
@@ -216,6 +228,9 @@ __global__ __launch_bounds__(1024) void k_tvl1_finalize(const double *__restrict
         st->n = n;
         st->done = done;
         st->error = error;
+        host_st->n = n;                                     // pinned host memory: visible once the kernel retires
+        host_st->error = error;
+        host_st->done = done;
     }
 }
 
@@ -315,18 +330,23 @@ template <typename T> static int tvl1_level_alloc(ofx_ctx *ctx, Tvl1Level<T> &L,
 static int tvl1_pick_rows(const ofx_ctx *ctx, int nx, int ny)
 {
     if (ctx->rows_per_wave > 0) return ctx->rows_per_wave;
-    // enough waves to fill 256 CUs several times over, but strips long enough to amortise the halo row
+    // Measured on MI355X (tools/tune_iter.py, profiles/r01_b_rows_sweep.txt): short strips win.  Many
+    // short-lived waves hide memory latency better than few long ones (each wave keeps only one row of
+    // prefetch in flight), and on the small pyramid levels the launch is a pure latency chain of
+    // (rows + 1) dependent marching steps, so the strip height must shrink with the image.
     const int strips = ofx_cdiv(nx, STRIP_OUT);
-    int rows = 32;
-    while (rows > 4 && (long) strips * ofx_cdiv(ny, rows) < 4096) rows >>= 1;
-    return rows;
+    if ((long) strips * ofx_cdiv(ny, 4) >= 2048) return 4;
+    if ((long) strips * ofx_cdiv(ny, 2) >= 1024) return 2;
+    return 1;
 }
 
 static int tvl1_pick_chunk(const ofx_ctx *ctx, int nx, int ny)
 {
     if (ctx->chunk > 0) return ctx->chunk;
-    const double est_us = fmax(2.5, (double) nx * ny * 120.0 / 4.0e6);   // ~4 TB/s, launch floor 2.5 us
-    int c = (int) (80.0 / est_us);
+    // one poll (event wait + host wake-up) costs 20-40 us: a chunk should take about that long, because
+    // every launch behind the iteration that ends the loop is a wasted ~2.5 us no-op
+    const double est_us = fmax(5.0, (double) nx * ny * 120.0 / 4.0e6);   // ~4 TB/s, small-level floor 5 us
+    int c = (int) (40.0 / est_us);
     return c < 4 ? 4 : (c > 50 ? 50 : c);
 }
 
@@ -366,14 +386,12 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
                                    strips_pad, l_t, P.theta, taut, eps2);
             }
             OFX_LAUNCH_CHECK(ctx);
+            const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
             hipLaunchKernelGGL(k_tvl1_finalize, dim3(1), dim3(1024), 0, ctx->stream, (const double *) ctx->d_err,
-                               launched, launched + c, max_iter, size, eps2, ctx->d_state);
+                               launched, launched + c, max_iter, size, eps2, ctx->d_state, &ctx->h_state[slot]);
             OFX_LAUNCH_CHECK(ctx);
             launched += c;
-            const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
             slot_of[head & 1] = slot;
-            OFX_HIP(ctx, hipMemcpyAsync(&ctx->h_state[slot], ctx->d_state, sizeof(OfxIterState),
-                                        hipMemcpyDeviceToHost, ctx->stream));
             OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
             head++;
         }

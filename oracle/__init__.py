@@ -33,6 +33,21 @@ def build(verbose=False):
         raise RuntimeError("oracle build failed")
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota
+    (a GPU box hands one GPU's share of the host, not the whole machine) and OFX_CPU_THREADS."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("OFX_CPU_THREADS"):
+        n = max(1, int(os.environ["OFX_CPU_THREADS"]))
+    return n
+
+
 def have_ref():
     return os.path.exists(REF_SO)
 
