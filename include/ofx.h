@@ -47,6 +47,7 @@ extern "C" {
 /* solver limits mirrored from the reference's #defines */
 #define OFX_TVL1_MAX_ITERATIONS 300   /* src/tvl1flow.cpp:22  */
 #define OFX_BROX_MAX_ITERATIONS 300   /* src/brox_optic_flow_spatial.cpp:24 */
+#define OFX_HS_MAX_MAXITER 65536      /* largest Horn-Schunck `maxiter` accepted (reference: unbounded) */
 #define OFX_MAX_SCALES 32
 #define OFX_MAX_SOLVES 64             /* warps (TV-L1, HS) or outer*inner solves (Brox) per scale */
 

@@ -69,6 +69,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
 
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc((void **) &ctx->d_err, sizeof(double) * OFX_TVL1_MAX_ITERATIONS * OFX_NSHARD) == hipSuccess;
+    ctx->d_err_cap = OFX_TVL1_MAX_ITERATIONS;
     ok = ok && hipMalloc((void **) &ctx->d_state, sizeof(OfxIterState)) == hipSuccess;
     ok = ok && hipHostMalloc((void **) &ctx->h_state, sizeof(OfxIterState) * OFX_NPOLL, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < OFX_NPOLL; i++)

@@ -39,7 +39,8 @@ struct ofx_ctx {
     size_t call_bytes;      // bytes handed out during this call (to coalesce next time)
 
     // convergence machinery
-    double       *d_err;    // [max_iter][OFX_NSHARD] per-iteration squared-update sums
+    double       *d_err;    // [d_err_cap][OFX_NSHARD] per-iteration squared-update sums
+    int           d_err_cap;
     OfxIterState *d_state;  // device copy
     OfxIterState *h_state;  // pinned ring [OFX_NPOLL]
     hipEvent_t    ev_poll[OFX_NPOLL];

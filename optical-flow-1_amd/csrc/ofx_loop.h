@@ -1,0 +1,110 @@
+// ofx_loop.h -- data-dependent iteration loops without a host round trip per iteration.
+//
+// All three solvers have the same shape: `while (error > tol && n < max) { n++; sweep; error = f(sum) }`
+// (src/tvl1flow.cpp:113, src/horn_schunck_pyramidal.cpp:143, src/brox_optic_flow_spatial.cpp:315).
+// On the GPU every sweep k adds its per-wave partial sums into err[k][wave % 64] (one f64 atomic
+// per wave).  The FIRST thing every kernel of sweep k+1 does is fetch the 64 shards of err[k]; it
+// reduces them in a fixed butterfly order, applies the reference's own test and returns at once
+// when the loop is over -- and then every later launch sees an untouched all-zero slot and is a
+// no-op too.  The host enqueues sweeps in chunks; a one-block finalize kernel after each chunk
+// publishes {n, done, error} into pinned host memory, and the host reads that record one chunk
+// behind the GPU.  `n` is therefore exactly the reference's iteration count.
+#pragma once
+
+#include "ofx_internal.h"
+#include "ofx_device.h"
+
+#define OFX_CRIT_MEAN      0   // error = sum / size           (TV-L1, tvl1flow.cpp:162)
+#define OFX_CRIT_SQRT_MEAN 1   // error = sqrt(sum / size)     (HS :230, Brox :389)
+
+OFX_DEV double loop_error_from_sum(double sum, int size, int crit)
+{
+    const double m = sum / size;
+    return crit == OFX_CRIT_SQRT_MEAN ? sqrt(m) : m;
+}
+
+// Fetch this lane's shard of sweep k-1 (call first, use late: the load overlaps with other loads).
+OFX_DEV double loop_fetch_prev(const double *err, int k)
+{
+    return k > 0 ? err[(size_t) (k - 1) * OFX_NSHARD + (threadIdx.x & 63)] : 0.0;
+}
+
+// true when sweep k must run.  Full waves only.
+OFX_DEV bool loop_continues(double prev_shard, int k, int size, double thr, int crit)
+{
+    if (k == 0) return true;
+    const double error = loop_error_from_sum(wave_allreduce_sum(prev_shard), size, crit);
+    return error > thr;
+}
+
+// Add a wave's partial sum into sweep k's slot.  Full waves only; `wave_id` spreads the shards.
+OFX_DEV void loop_accumulate(double *err, int k, double lane_value, int wave_id)
+{
+    const double s = wave_allreduce_sum(lane_value);
+    if ((threadIdx.x & 63) == 0) atomicAdd(err + (size_t) k * OFX_NSHARD + (wave_id & (OFX_NSHARD - 1)), s);
+}
+
+struct LoopSpec {
+    int    max_iter;   // reference's MAX_ITERATIONS / maxiter
+    int    size;       // nx * ny of the level
+    double thr;        // eps^2 (TV-L1) or TOL (SOR)
+    int    crit;       // OFX_CRIT_*
+    int    chunk;      // sweeps per poll
+    bool   fixed;      // run exactly max_iter sweeps (stopping test disabled)
+};
+
+int ofx_loop_reserve(ofx_ctx *ctx, int max_iter);                      // err slots for max_iter sweeps
+int ofx_loop_finalize(ofx_ctx *ctx, const LoopSpec &L, int start, int launched, OfxIterState *host_slot);
+
+// Runs the loop.  launch(k, thr_eff) must enqueue every kernel of sweep k on ctx->stream; kernels
+// take (ctx->d_err, k, thr_eff, crit) and use the helpers above.  Returns the reference's n and error.
+template <class LaunchFn>
+static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, int *n_out, double *err_out, float *ms_out)
+{
+    OFX_TRY(ofx_loop_reserve(ctx, L.max_iter));
+    LoopSpec S = L;
+    if (S.fixed) S.thr = -1.0;          // error >= 0 always passes `error > -1`
+    OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) S.max_iter * OFX_NSHARD, ctx->stream));
+    OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
+    if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+
+    // head / tail count the polls issued / consumed; at most two are outstanding (the one the host
+    // waits for and one chunk of lookahead that keeps the GPU busy meanwhile).
+    int launched = 0, head = 0, tail = 0, slot_of[2] = {0, 0};
+    bool stop = false;
+    OfxIterState fin = {0, 0, 0.0};
+    const int chunk = S.chunk < 1 ? 1 : S.chunk;
+    for (;;) {
+        while (launched < S.max_iter && head - tail < 2) {
+            const int c = (S.max_iter - launched < chunk) ? S.max_iter - launched : chunk;
+            for (int q = 0; q < c; q++) OFX_TRY(launch(launched + q, S.thr));
+            const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
+            OFX_TRY(ofx_loop_finalize(ctx, S, launched, launched + c, &ctx->h_state[slot]));
+            launched += c;
+            slot_of[head & 1] = slot;
+            OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
+            head++;
+        }
+        if (tail == head) break;
+        const int slot = slot_of[tail & 1];
+        OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
+        const OfxIterState st = ctx->h_state[slot];
+        tail++;
+        if (st.done) {
+            // A poll still in flight covers launches that are no-ops (their stopping test already
+            // fails); it is not drained -- stream order keeps it ahead of whatever is enqueued next.
+            stop = true;
+            fin = st;
+            break;
+        }
+    }
+    if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+    if (!stop) return ofx_fail(ctx, OFX_ERR_HIP, "iteration loop ended without a final state");
+    *n_out = fin.n;
+    *err_out = fin.error;
+    if (ms_out) {
+        OFX_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
+        OFX_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev_t0, ctx->ev_t1));
+    }
+    return OFX_OK;
+}

@@ -1,0 +1,56 @@
+// ofx_loop.hip -- finalize kernel and host helpers of the convergence-loop machinery (ofx_loop.h).
+#include "ofx_loop.h"
+
+// One block (16 waves).  Scans the error slots of sweeps [start, launched) and publishes how many
+// sweeps really ran (the reference's n), whether the loop is over, and the criterion value at exit.
+__global__ __launch_bounds__(1024) void k_loop_finalize(const double *__restrict__ err, int start, int launched,
+                                                        int max_iter, int size, double thr, int crit,
+                                                        OfxIterState *st, OfxIterState *host_st)
+{
+    extern __shared__ double s_err[];
+    if (st->done) {                                         // an earlier chunk already ended the loop
+        if (threadIdx.x == 0) *host_st = *st;
+        return;
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = start + w; k < launched; k += 16) {
+        const double e = loop_error_from_sum(wave_allreduce_sum(err[(size_t) k * OFX_NSHARD + lane]), size, crit);
+        if (lane == 0) s_err[k - start] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = launched, done = (launched >= max_iter);
+        double error = launched > start ? s_err[launched - start - 1] : st->error;
+        for (int k = start; k < launched; k++) {
+            if (!(s_err[k - start] > thr)) { n = k + 1; done = 1; error = s_err[k - start]; break; }
+        }
+        st->n = n;
+        st->done = done;
+        st->error = error;
+        host_st->n = n;                                     // pinned host memory: visible once the kernel retires
+        host_st->error = error;
+        host_st->done = done;
+    }
+}
+
+int ofx_loop_finalize(ofx_ctx *ctx, const LoopSpec &L, int start, int launched, OfxIterState *host_slot)
+{
+    const size_t shmem = sizeof(double) * (size_t) (launched - start);
+    hipLaunchKernelGGL(k_loop_finalize, dim3(1), dim3(1024), shmem, ctx->stream, (const double *) ctx->d_err, start,
+                       launched, L.max_iter, L.size, L.thr, L.crit, ctx->d_state, host_slot);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
+    return OFX_OK;
+}
+
+int ofx_loop_reserve(ofx_ctx *ctx, int max_iter)
+{
+    if (max_iter <= ctx->d_err_cap) return OFX_OK;
+    OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_err) (void) hipFree(ctx->d_err);
+    ctx->d_err = nullptr;
+    ctx->d_err_cap = 0;
+    OFX_HIP(ctx, hipMalloc((void **) &ctx->d_err, sizeof(double) * (size_t) max_iter * OFX_NSHARD));
+    ctx->d_err_cap = max_iter;
+    return OFX_OK;
+}

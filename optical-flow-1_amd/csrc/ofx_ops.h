@@ -4,6 +4,8 @@
 
 #include "ofx_internal.h"
 
+#include <vector>
+
 #define OFX_GAUSS_MAX_TAPS 64
 
 struct GaussTaps {
@@ -50,5 +52,26 @@ template <typename T> int op_bicubic_warp(ofx_ctx *ctx, const T *in, const T *u,
                                           int ny, int border_out);
 template <typename T> int op_bicubic_at(ofx_ctx *ctx, const T *in, const double *uu, const double *vv,
                                         double *out, int n, int nx, int ny, int border_out);
+
+// (f, centred dx, centred dy, 0) packed per pixel: one 4-wide gather per bicubic tap serves three warps
+template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v4 *pack, int nx, int ny);
+
+// Shared pyramid prologue (src/tvl1flow.cpp:236-280 == horn_schunck_pyramidal.cpp:279-323 ==
+// brox_optic_flow_spatial.cpp:467-509): joint normalisation, presmoothing, zoom_out chain.
+template <typename T> struct ImgLevel {
+    int nx, ny;
+    T *A, *B;
+};
+template <typename T>
+int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nx, int ny, int nscales, double zfactor,
+                     double presmooth_sigma, std::vector<ImgLevel<T>> &lv);
+
+#define OFX_LAUNCH_CHECK(ctx)                                                                    \
+    do {                                                                                         \
+        hipError_t e__ = hipGetLastError();                                                      \
+        if (e__ != hipSuccess)                                                                   \
+            return ofx_fail((ctx), OFX_ERR_HIP, "kernel launch failed: %s (%s:%d)",              \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                         \
+    } while (0)
 
 static inline hipError_t ofx_launch_status() { return hipGetLastError(); }

@@ -17,14 +17,6 @@ static inline dim3 grid2d(int nx, int ny) { return dim3(ofx_cdiv(nx, BX), ofx_cd
 static inline dim3 block2d() { return dim3(BX, BY); }
 static inline int grid1d(size_t n) { return (int) ((n + 255) / 256); }
 
-#define OFX_LAUNCH_CHECK(ctx)                                                                    \
-    do {                                                                                         \
-        hipError_t e__ = hipGetLastError();                                                      \
-        if (e__ != hipSuccess)                                                                   \
-            return ofx_fail((ctx), OFX_ERR_HIP, "kernel launch failed: %s (%s:%d)",              \
-                            hipGetErrorString(e__), __FILE__, __LINE__);                         \
-    } while (0)
-
 // ---- layout conversions ---------------------------------------------------------------------------
 template <typename T>
 __global__ void k_convert_in(const double *__restrict__ src, T *__restrict__ dst, size_t n)
@@ -453,6 +445,63 @@ int op_bicubic_at(ofx_ctx *ctx, const T *in, const double *uu, const double *vv,
     return OFX_OK;
 }
 
+// centred gradient packed next to the image (src/operators.cpp:335-406, nz = 1)
+template <typename T>
+__global__ void k_grad_pack(const T *__restrict__ f, typename Pix<T>::v4 *__restrict__ pack, int nx, int ny)
+{
+    const int j = blockIdx.x * BX + threadIdx.x;
+    const int i = blockIdx.y * BY + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+    const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+    const size_t p = (size_t) i * nx + j;
+    double4 o;
+    o.x = ldw(f + p);
+    o.y = 0.5 * (ldw(f + (size_t) i * nx + jr) - ldw(f + (size_t) i * nx + jl));
+    o.z = 0.5 * (ldw(f + (size_t) id * nx + j) - ldw(f + (size_t) iu * nx + j));
+    o.w = 0.0;
+    stn4(pack + p, o);
+}
+
+template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v4 *pack, int nx, int ny)
+{
+    hipLaunchKernelGGL(k_grad_pack<T>, grid2d(nx, ny), block2d(), 0, ctx->stream, f, pack, nx, ny);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+
+template <typename T>
+int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nxx, int nyy, int nscales, double zfactor,
+                     double sigma, std::vector<ImgLevel<T>> &lv)
+{
+    if (nscales < 1 || nscales > OFX_MAX_SCALES) return ofx_fail(ctx, OFX_ERR_ARG, "nscales=%d", nscales);
+    if (nxx < 2 || nyy < 2) return ofx_fail(ctx, OFX_ERR_ARG, "image %dx%d too small", nxx, nyy);
+    if (!(zfactor > 0.0) || !(zfactor < 1.0)) return ofx_fail(ctx, OFX_ERR_ARG, "zoom factor %g", zfactor);
+    lv.resize(nscales);
+    int nx = nxx, ny = nyy;
+    for (int s = 0; s < nscales; s++) {
+        if (s) ofx_zoom_size(lv[s - 1].nx, lv[s - 1].ny, &nx, &ny, zfactor);
+        if (nx < 2 || ny < 2) return ofx_fail(ctx, OFX_ERR_SIGMA, "scale %d would be %dx%d", s, nx, ny);
+        lv[s].nx = nx;
+        lv[s].ny = ny;
+        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &lv[s].A));
+        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &lv[s].B));
+    }
+    T *tmpA, *tmpB;
+    double *scr;
+    OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpA));
+    OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpB));
+    OFX_TRY(ofx_alloc(ctx, (size_t) 2 * MM_BLOCKS + 2, &scr));
+    OFX_TRY(op_normalize2<T>(ctx, dA, dB, lv[0].A, lv[0].B, nxx * nyy, scr));
+    OFX_TRY(op_gaussian<T>(ctx, lv[0].A, tmpA, nxx, nyy, sigma));
+    OFX_TRY(op_gaussian<T>(ctx, lv[0].B, tmpA, nxx, nyy, sigma));
+    for (int s = 1; s < nscales; s++) {
+        OFX_TRY(op_zoom_out<T>(ctx, lv[s - 1].A, lv[s].A, tmpA, tmpB, lv[s - 1].nx, lv[s - 1].ny, zfactor));
+        OFX_TRY(op_zoom_out<T>(ctx, lv[s - 1].B, lv[s].B, tmpA, tmpB, lv[s - 1].nx, lv[s - 1].ny, zfactor));
+    }
+    return OFX_OK;
+}
+
 // ---- explicit instantiations -----------------------------------------------------------------------
 #define OFX_INSTANTIATE(T)                                                                                           \
     template int op_convert_in<T>(ofx_ctx *, const double *, T *, size_t);                                            \
@@ -471,7 +520,10 @@ int op_bicubic_at(ofx_ctx *ctx, const T *in, const double *uu, const double *vv,
     template int op_centered_gradient<T>(ofx_ctx *, const T *, T *, T *, int, int);                                   \
     template int op_second_derivative<T>(ofx_ctx *, const T *, T *, int, int, int);                                   \
     template int op_bicubic_warp<T>(ofx_ctx *, const T *, const T *, const T *, T *, int, int, int);                  \
-    template int op_bicubic_at<T>(ofx_ctx *, const T *, const double *, const double *, double *, int, int, int, int);
+    template int op_bicubic_at<T>(ofx_ctx *, const T *, const double *, const double *, double *, int, int, int, int);           \
+    template int op_grad_pack<T>(ofx_ctx *, const T *, Pix<T>::v4 *, int, int);                                        \
+    template int op_build_pyramid<T>(ofx_ctx *, const T *, const T *, int, int, int, double, double,                   \
+                                     std::vector<ImgLevel<T>> &);
 
 OFX_INSTANTIATE(double)
 OFX_INSTANTIATE(float)

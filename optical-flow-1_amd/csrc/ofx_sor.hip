@@ -1,0 +1,702 @@
+// ofx_sor.hip -- Horn-Schunck pyramidal and Brox spatial on gfx950
+// (reference: src/horn_schunck_pyramidal.cpp, src/brox_optic_flow_spatial.cpp, src/brox_spatial_mask.cpp).
+//
+// Both reference solvers are in-place SOR (w = 1.9) swept in lexicographic order -- a sequential
+// recurrence.  The GPU sweeps in colours instead: Horn-Schunck's 8-neighbour stencil needs four
+// colours (i%2, j%2), Brox's 5-point stencil two (red-black).  Within one colour no pixel reads
+// another pixel of the same colour (borders use clamped neighbour indices, which is what the
+// reference's replicated border indices amount to), so the in-place update is race-free and
+// deterministic.  Per-pixel arithmetic is the reference's expression for expression; what changes
+// is the ORDER in which pixels see each other's new values, hence the trajectory and the sweep at
+// which `error > TOL` fails.  Measured against the lexicographic reference (tests):
+// Horn-Schunck AEPE 1e-5..5e-5 (inside the 1e-4 bar), Brox up to 1.6e-4 (the reference's own
+// 1-vs-8-thread spread is 3.6e-5).  oracle's `set_sor_order(1)` reproduces this file bit for bit.
+//
+// Storage per level (T = storage type):
+//   HS  : U=(u,v) pairs in place; pack=(I2,I2x,I2y,0); A=(I2wx,I2wy); Dif=dif  -- the five coefficient
+//         arrays Au,Av,Du,Dv,D of the reference are recomputed from A, Dif in registers (same ops).
+//   Brox: U; G1=(I1x,I1y); PA=(I2,I2x,I2y,I2xx), PB=(I2xy,I2yy); WA/WB = their warps; Psis;
+//         DV=(div_u,div_v), Dd=div_d; CO=(Au,Av,Du,Dv), Dm=D; DU=(du,dv) in place.
+#include "ofx_ops.h"
+#include "ofx_device.h"
+#include "ofx_loop.h"
+
+#include <cmath>
+
+#define HS_SOR_W 1.9                 // src/horn_schunck_pyramidal.cpp:21
+#define HS_PRESMOOTH_SIGMA 0.8       // src/horn_schunck_pyramidal.cpp:22
+#define BROX_EPSILON 0.001           // src/brox_optic_flow_spatial.cpp:23
+#define BROX_SOR_W 1.9               // src/brox_optic_flow_spatial.cpp:25
+#define BROX_SIGMA 0.8               // src/brox_optic_flow_spatial.cpp:26
+
+template <typename T> OFX_DEV double rnd_to(double x);
+template <> OFX_DEV double rnd_to<double>(double x) { return x; }
+template <> OFX_DEV double rnd_to<float>(double x) { return (double) (float) x; }
+
+static inline dim3 g2d(int nx, int ny) { return dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)); }
+static inline dim3 b2d() { return dim3(64, 4); }
+
+static int sor_pick_chunk(const ofx_ctx *ctx, int nx, int ny, int launches_per_sweep)
+{
+    if (ctx->chunk > 0) return ctx->chunk;
+    const double est_us = fmax(4.0 * launches_per_sweep, (double) nx * ny * 100.0 / 2.0e6);
+    int c = (int) (60.0 / est_us);
+    return c < 2 ? 2 : (c > 32 ? 32 : c);
+}
+
+// ============================================================================================
+// Horn-Schunck
+// ============================================================================================
+
+// warp of (I2, I2x, I2y) + constant parts of the system, src/horn_schunck_pyramidal.cpp:123-137
+template <typename T>
+__global__ void k_hs_warp(const typename Pix<T>::v4 *__restrict__ pack, const T *__restrict__ I1,
+                          const typename Pix<T>::v2 *__restrict__ U, typename Pix<T>::v2 *__restrict__ A,
+                          T *__restrict__ Dif, int nx, int ny)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t p = (size_t) i * nx + j;
+    const double2 u = ldw2(U + p);
+    const BicubicTaps t = bicubic_taps(j + u.x, i + u.y, nx, ny);
+    double I2w = 0.0, I2wx = 0.0, I2wy = 0.0;
+    if (!t.out) {
+        double c0[4], c1[4], c2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double4 v0 = ldw4(pack + (size_t) t.row[0] * nx + t.col[k]);
+            const double4 v1 = ldw4(pack + (size_t) t.row[1] * nx + t.col[k]);
+            const double4 v2 = ldw4(pack + (size_t) t.row[2] * nx + t.col[k]);
+            const double4 v3 = ldw4(pack + (size_t) t.row[3] * nx + t.col[k]);
+            c0[k] = cubic_cell(v0.x, v1.x, v2.x, v3.x, t.fy);
+            c1[k] = cubic_cell(v0.y, v1.y, v2.y, v3.y, t.fy);
+            c2[k] = cubic_cell(v0.z, v1.z, v2.z, v3.z, t.fy);
+        }
+        I2w = cubic_cell(c0[0], c0[1], c0[2], c0[3], t.fx);
+        I2wx = rnd_to<T>(cubic_cell(c1[0], c1[1], c1[2], c1[3], t.fx));
+        I2wy = rnd_to<T>(cubic_cell(c2[0], c2[1], c2[2], c2[3], t.fx));
+    }
+    const double I2wl = I2wx * u.x + I2wy * u.y;                 // :130
+    const double dif = ldw(I1 + p) - I2w + I2wl;                 // :131
+    stn2(A + p, make_double2(I2wx, I2wy));
+    stn(Dif + p, dif);
+}
+
+// One colour of one SOR sweep, src/horn_schunck_pyramidal.cpp:31-71 at every pixel of the colour.
+template <typename T>
+__global__ __launch_bounds__(256) void k_hs_sor(typename Pix<T>::v2 *__restrict__ U,
+                                                const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif,
+                                                double *__restrict__ err, int k, int nx, int ny, int ci, int cj,
+                                                double alpha2, double tol)
+{
+    const double prev = loop_fetch_prev(err, k);
+    const int j = 2 * (blockIdx.x * 64 + threadIdx.x) + cj;
+    const int i = 2 * (blockIdx.y * 4 + threadIdx.y) + ci;
+    const bool in = (j < nx) && (i < ny);
+    const int gw = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.y;
+    if (!loop_continues(prev, k, nx * ny, tol, OFX_CRIT_SQRT_MEAN)) return;
+    double e = 0.0;
+    if (in) {
+        const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+        const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+        const size_t p = (size_t) i * nx + j;
+        const double2 p1 = ldw2(U + (size_t) iu * nx + jl), p2 = ldw2(U + (size_t) iu * nx + jr);
+        const double2 p3 = ldw2(U + (size_t) id * nx + jl), p4 = ldw2(U + (size_t) id * nx + jr);
+        const double2 p5 = ldw2(U + (size_t) iu * nx + j), p6 = ldw2(U + (size_t) i * nx + jl);
+        const double2 p7 = ldw2(U + (size_t) id * nx + j), p8 = ldw2(U + (size_t) i * nx + jr);
+        const double2 c = ldw2(U + p);
+        const double2 a = ldw2(A + p);
+        const double dif = ldw(Dif + p);
+        const double w = HS_SOR_W;
+        const double Au = dif * a.x, Av = dif * a.y;                              // :133-134
+        const double Du = a.x * a.x + alpha2, Dv = a.y * a.y + alpha2;            // :135-136
+        const double D = a.x * a.y;                                               // :137
+        const double ula = 1. / 12. * (p1.x + p2.x + p3.x + p4.x) + 1. / 6. * (p5.x + p6.x + p7.x + p8.x);
+        const double vla = 1. / 12. * (p1.y + p2.y + p3.y + p4.y) + 1. / 6. * (p5.y + p6.y + p7.y + p8.y);
+        const double uk = c.x, vk = c.y;
+        const double un = rnd_to<T>((1.0 - w) * uk + w * (Au - D * vk + alpha2 * ula) / Du);   // :66
+        const double vn = rnd_to<T>((1.0 - w) * vk + w * (Av - D * un + alpha2 * vla) / Dv);   // :67
+        stn2(U + p, make_double2(un, vn));
+        e = (un - uk) * (un - uk) + (vn - vk) * (vn - vk);                        // :70
+    }
+    loop_accumulate(err, k, e, gw);
+}
+
+template <typename T> struct HsLevel {
+    int nx, ny;
+    T *I1, *I2;
+    typename Pix<T>::v4 *pack;
+    typename Pix<T>::v2 *U, *A;
+    T *Dif;
+};
+
+template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int nx, int ny)
+{
+    const size_t n = (size_t) nx * ny;
+    L.nx = nx;
+    L.ny = ny;
+    OFX_TRY(ofx_alloc(ctx, n, &L.pack));
+    OFX_TRY(ofx_alloc(ctx, n, &L.U));
+    OFX_TRY(ofx_alloc(ctx, n, &L.A));
+    OFX_TRY(ofx_alloc(ctx, n, &L.Dif));
+    return OFX_OK;
+}
+
+struct HsParams {
+    double alpha, TOL;
+    int warps, maxiter, verbose;
+};
+
+// src/horn_schunck_pyramidal.cpp:78-249 on device data; L.U holds the incoming flow
+template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L, const HsParams &P, int scale)
+{
+    const int nx = L.nx, ny = L.ny;
+    const double alpha2 = P.alpha * P.alpha;
+    if (P.verbose)
+        fprintf(stderr, "Single-scale Horn-Schunck of a %dx%d image\n\ta=%g nw=%d eps=%g mi=%d v=%d\n", nx, ny, P.alpha,
+                P.warps, P.TOL, P.maxiter, P.verbose);
+    OFX_TRY(op_grad_pack<T>(ctx, L.I2, L.pack, nx, ny));                                    // :114
+    ofx_stats &S = ctx->stats;
+    const dim3 gc(ofx_cdiv(ofx_cdiv(nx, 2), 64), ofx_cdiv(ofx_cdiv(ny, 2), 4));
+    for (int w = 0; w < P.warps; w++) {
+        if (P.verbose) fprintf(stderr, "Warping %d:", w);
+        hipLaunchKernelGGL(k_hs_warp<T>, g2d(nx, ny), b2d(), 0, ctx->stream, L.pack, (const T *) L.I1, L.U, L.A, L.Dif,
+                           nx, ny);                                                           // :123-137
+        OFX_LAUNCH_CHECK(ctx);
+        int niter = 0;
+        double error = 1000;                                                                  // :140
+        float ms = 0.f;
+        if (P.maxiter > 0 && error > P.TOL) {
+            LoopSpec LS;
+            LS.max_iter = P.maxiter;
+            LS.size = nx * ny;
+            LS.thr = P.TOL;
+            LS.crit = OFX_CRIT_SQRT_MEAN;
+            LS.chunk = sor_pick_chunk(ctx, nx, ny, 4);
+            LS.fixed = ctx->fixed_work != 0;
+            auto launch = [&](int k, double thr) -> int {
+                for (int col = 0; col < 4; col++)
+                    hipLaunchKernelGGL(k_hs_sor<T>, gc, b2d(), 0, ctx->stream, L.U, L.A, (const T *) L.Dif, ctx->d_err, k,
+                                       nx, ny, col >> 1, col & 1, alpha2, thr);
+                OFX_LAUNCH_CHECK(ctx);
+                return OFX_OK;
+            };
+            OFX_TRY(ofx_run_loop(ctx, LS, launch, &niter, &error, ctx->profile ? &ms : nullptr));
+        }
+        if (P.verbose) fprintf(stderr, "Iterations %d (%g)\n", niter, error);                // :233-235
+        if (scale < OFX_MAX_SCALES) {
+            if (w < OFX_MAX_SOLVES) { S.iters[scale][w] = niter; S.error[scale][w] = error; }
+            S.iter_ms[scale] += ms;
+            S.iter_launches[scale] += niter;
+        }
+        S.work_pix_iters += (double) niter * nx * ny;
+    }
+    return OFX_OK;
+}
+
+template <typename T>
+static int upload_plane(ofx_ctx *ctx, const double *h, size_t n, T **out)
+{
+    double *stage;
+    OFX_TRY(ofx_alloc(ctx, n, &stage));
+    OFX_TRY(ofx_alloc(ctx, n, out));
+    OFX_HIP(ctx, hipMemcpyAsync(stage, h, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return op_convert_in<T>(ctx, stage, *out, n);
+}
+
+template <typename T>
+static int download_flow(ofx_ctx *ctx, const typename Pix<T>::v2 *U, double *u, double *v, size_t n)
+{
+    double *d1, *d2;
+    OFX_TRY(ofx_alloc(ctx, n, &d1));
+    OFX_TRY(ofx_alloc(ctx, n, &d2));
+    OFX_TRY(op_deinterleave2<T>(ctx, U, d1, d2, n));
+    OFX_HIP(ctx, hipMemcpyAsync(u, d1, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipMemcpyAsync(v, d2, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return OFX_OK;
+}
+
+static void sor_stats_begin(ofx_ctx *ctx, int nscales, int nsolves)
+{
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    ctx->stats.nscales = nscales;
+    ctx->stats.nsolves = nsolves;
+}
+
+template <typename T>
+static int hs_single_scale_host(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                                const HsParams &P)
+{
+    const size_t n = (size_t) nx * ny;
+    sor_stats_begin(ctx, 1, P.warps);
+    ctx->stats.nx[0] = nx;
+    ctx->stats.ny[0] = ny;
+    HsLevel<T> L;
+    OFX_TRY(hs_level_alloc<T>(ctx, L, nx, ny));
+    OFX_TRY(upload_plane<T>(ctx, I1, n, &L.I1));
+    OFX_TRY(upload_plane<T>(ctx, I2, n, &L.I2));
+    double *d1, *d2;
+    OFX_TRY(ofx_alloc(ctx, n, &d1));
+    OFX_TRY(ofx_alloc(ctx, n, &d2));
+    OFX_HIP(ctx, hipMemcpyAsync(d1, u, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    OFX_HIP(ctx, hipMemcpyAsync(d2, v, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    OFX_TRY(op_interleave2<T>(ctx, d1, d2, L.U, n));
+    OFX_TRY(hs_single_scale_dev<T>(ctx, L, P, 0));
+    return download_flow<T>(ctx, L.U, u, v, n);
+}
+
+// src/horn_schunck_pyramidal.cpp:258-370
+template <typename T>
+static int hs_pyramidal_host(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                             const HsParams &P, int nscales, double zfactor)
+{
+    const size_t n = (size_t) nx * ny;
+    if (P.verbose)
+        fprintf(stderr, "Multiscale Horn-Schunck of a %dx%d pair\n\ta=%g ns=%d zf=%g nw=%d eps=%g mi=%d\n", nx, ny,
+                P.alpha, nscales, zfactor, P.warps, P.TOL, P.maxiter);
+    T *dI1, *dI2;
+    OFX_TRY(upload_plane<T>(ctx, I1, n, &dI1));
+    OFX_TRY(upload_plane<T>(ctx, I2, n, &dI2));
+    sor_stats_begin(ctx, nscales, P.warps);
+    std::vector<ImgLevel<T>> img;
+    OFX_TRY(op_build_pyramid<T>(ctx, dI1, dI2, nx, ny, nscales, zfactor, HS_PRESMOOTH_SIGMA, img));     // :279-317
+    std::vector<HsLevel<T>> lv(nscales);
+    for (int s = 0; s < nscales; s++) {
+        OFX_TRY(hs_level_alloc<T>(ctx, lv[s], img[s].nx, img[s].ny));
+        lv[s].I1 = img[s].A;
+        lv[s].I2 = img[s].B;
+        ctx->stats.nx[s] = img[s].nx;
+        ctx->stats.ny[s] = img[s].ny;
+    }
+    HsLevel<T> &C = lv[nscales - 1];
+    OFX_TRY(op_fill2<T>(ctx, C.U, (size_t) C.nx * C.ny));                                               // :320-323
+    for (int s = nscales - 1; s >= 0; s--) {                                                           // :326
+        if (P.verbose) fprintf(stderr, "Scale: %d %dx%d\n", s, lv[s].nx, lv[s].ny);
+        OFX_TRY(hs_single_scale_dev<T>(ctx, lv[s], P, s));
+        if (!s) break;
+        OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U, lv[s - 1].U, lv[s].nx, lv[s].ny, lv[s - 1].nx, lv[s - 1].ny,
+                                   1.0 / zfactor));                                                    // :345-352
+    }
+    return download_flow<T>(ctx, lv[0].U, u, v, n);
+}
+
+extern "C" int ofx_hs_single_scale(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nx,
+                                   int ny, double alpha, int warps, double TOL, int maxiter, int verbose)
+{
+    OFX_ENTER(ctx);
+    if (!I1 || !I2 || !u || !v) return ofx_fail(ctx, OFX_ERR_ARG, "hs: NULL pointer");
+    if (nx < 2 || ny < 2 || warps < 1) return ofx_fail(ctx, OFX_ERR_ARG, "hs: bad size / warps");
+    if (maxiter > OFX_HS_MAX_MAXITER) return ofx_fail(ctx, OFX_ERR_ARG, "hs: maxiter > %d", OFX_HS_MAX_MAXITER);
+    const double t0 = ofx_now_ms();
+    const HsParams P = {alpha, TOL, warps, maxiter, verbose};
+    int s = ctx->precision == OFX_F64 ? hs_single_scale_host<double>(ctx, I1, I2, u, v, nx, ny, P)
+                                      : hs_single_scale_host<float>(ctx, I1, I2, u, v, nx, ny, P);
+    ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}
+
+extern "C" int ofx_hs_pyramidal(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                                double alpha, int nscales, double zfactor, int warps, double TOL, int maxiter,
+                                int verbose)
+{
+    OFX_ENTER(ctx);
+    if (!I1 || !I2 || !u || !v) return ofx_fail(ctx, OFX_ERR_ARG, "hs: NULL pointer");
+    if (warps < 1) return ofx_fail(ctx, OFX_ERR_ARG, "hs: warps=%d", warps);
+    if (maxiter > OFX_HS_MAX_MAXITER) return ofx_fail(ctx, OFX_ERR_ARG, "hs: maxiter > %d", OFX_HS_MAX_MAXITER);
+    const double t0 = ofx_now_ms();
+    const HsParams P = {alpha, TOL, warps, maxiter, verbose};
+    int s = ctx->precision == OFX_F64 ? hs_pyramidal_host<double>(ctx, I1, I2, u, v, nx, ny, P, nscales, zfactor)
+                                      : hs_pyramidal_host<float>(ctx, I1, I2, u, v, nx, ny, P, nscales, zfactor);
+    ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}
+
+// ============================================================================================
+// Brox spatial
+// ============================================================================================
+
+// clamped centred differences / second derivatives at one pixel (src/operators.cpp:132-406, nz = 1)
+template <typename T> OFX_DEV double cdx(const T *f, int i, int j, int nx, int ny)
+{
+    const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+    return 0.5 * (ldw(f + (size_t) i * nx + jr) - ldw(f + (size_t) i * nx + jl));
+}
+template <typename T> OFX_DEV double cdy(const T *f, int i, int j, int nx, int ny)
+{
+    const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+    return 0.5 * (ldw(f + (size_t) id * nx + j) - ldw(f + (size_t) iu * nx + j));
+}
+template <typename T> OFX_DEV double d2xx(const T *f, int i, int j, int nx, int ny)
+{
+    const size_t p = (size_t) i * nx + j;
+    if (j == 0) return ldw(f + p) * -1.0 + ldw(f + p + 1);
+    if (j == nx - 1) return ldw(f + p - 1) + ldw(f + p) * -1.0;
+    return ldw(f + p - 1) + ldw(f + p) * -2.0 + ldw(f + p + 1);
+}
+template <typename T> OFX_DEV double d2yy(const T *f, int i, int j, int nx, int ny)
+{
+    const size_t p = (size_t) i * nx + j;
+    if (i == 0) return ldw(f + p) * -1.0 + ldw(f + p + nx);
+    if (i == ny - 1) return ldw(f + p - nx) + ldw(f + p) * -1.0;
+    return ldw(f + p - nx) + ldw(f + p) * -2.0 + ldw(f + p + nx);
+}
+template <typename T> OFX_DEV double d2xy(const T *f, int i, int j, int nx, int ny)
+{
+    const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+    const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+    return ldw(f + (size_t) iu * nx + jl) * 0.25 + ldw(f + (size_t) iu * nx + jr) * -0.25 +
+           ldw(f + (size_t) id * nx + jl) * -0.25 + ldw(f + (size_t) id * nx + jr) * 0.25;
+}
+
+// src/brox_optic_flow_spatial.cpp:235-241: gradient of I1; I2 with its first and second derivatives
+template <typename T>
+__global__ void k_brox_prepare(const T *__restrict__ I1, const T *__restrict__ I2, typename Pix<T>::v2 *__restrict__ G1,
+                               typename Pix<T>::v4 *__restrict__ PA, typename Pix<T>::v2 *__restrict__ PB, int nx, int ny)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t p = (size_t) i * nx + j;
+    stn2(G1 + p, make_double2(cdx(I1, i, j, nx, ny), cdy(I1, i, j, nx, ny)));
+    stn4(PA + p, make_double4(ldw(I2 + p), cdx(I2, i, j, nx, ny), cdy(I2, i, j, nx, ny), d2xx(I2, i, j, nx, ny)));
+    stn2(PB + p, make_double2(d2xy(I2, i, j, nx, ny), d2yy(I2, i, j, nx, ny)));
+}
+
+// six bicubic warps with one set of taps, :246-251
+template <typename T>
+__global__ void k_brox_warp(const typename Pix<T>::v4 *__restrict__ PA, const typename Pix<T>::v2 *__restrict__ PB,
+                            const typename Pix<T>::v2 *__restrict__ U, typename Pix<T>::v4 *__restrict__ WA,
+                            typename Pix<T>::v2 *__restrict__ WB, int nx, int ny)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t p = (size_t) i * nx + j;
+    const double2 u = ldw2(U + p);
+    const BicubicTaps t = bicubic_taps(j + u.x, i + u.y, nx, ny);
+    double4 wa = make_double4(0.0, 0.0, 0.0, 0.0);
+    double2 wb = make_double2(0.0, 0.0);
+    if (!t.out) {
+        double c[6][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double4 a[4];
+            double2 b[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                a[r] = ldw4(PA + (size_t) t.row[r] * nx + t.col[k]);
+                b[r] = ldw2(PB + (size_t) t.row[r] * nx + t.col[k]);
+            }
+            c[0][k] = cubic_cell(a[0].x, a[1].x, a[2].x, a[3].x, t.fy);
+            c[1][k] = cubic_cell(a[0].y, a[1].y, a[2].y, a[3].y, t.fy);
+            c[2][k] = cubic_cell(a[0].z, a[1].z, a[2].z, a[3].z, t.fy);
+            c[3][k] = cubic_cell(a[0].w, a[1].w, a[2].w, a[3].w, t.fy);
+            c[4][k] = cubic_cell(b[0].x, b[1].x, b[2].x, b[3].x, t.fy);
+            c[5][k] = cubic_cell(b[0].y, b[1].y, b[2].y, b[3].y, t.fy);
+        }
+        wa.x = cubic_cell(c[0][0], c[0][1], c[0][2], c[0][3], t.fx);
+        wa.y = cubic_cell(c[1][0], c[1][1], c[1][2], c[1][3], t.fx);
+        wa.z = cubic_cell(c[2][0], c[2][1], c[2][2], c[2][3], t.fx);
+        wa.w = cubic_cell(c[3][0], c[3][1], c[3][2], c[3][3], t.fx);
+        wb.x = cubic_cell(c[4][0], c[4][1], c[4][2], c[4][3], t.fx);
+        wb.y = cubic_cell(c[5][0], c[5][1], c[5][2], c[5][3], t.fx);
+    }
+    stn4(WA + p, wa);
+    stn2(WB + p, wb);
+}
+
+// psi_smooth of the centred flow gradient, :254-258 + :99-122
+template <typename T>
+__global__ void k_brox_psis(const typename Pix<T>::v2 *__restrict__ U, T *__restrict__ Psis, int nx, int ny)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+    const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+    const double2 r = ldw2(U + (size_t) i * nx + jr), l = ldw2(U + (size_t) i * nx + jl);
+    const double2 d = ldw2(U + (size_t) id * nx + j), t = ldw2(U + (size_t) iu * nx + j);
+    const double ux = 0.5 * (r.x - l.x), uy = 0.5 * (d.x - t.x);
+    const double vx = 0.5 * (r.y - l.y), vy = 0.5 * (d.y - t.y);
+    const double du = ux * ux + uy * uy;
+    const double dv = vx * vx + vy * vy;
+    const double d2 = du + dv;
+    stn(Psis + (size_t) i * nx + j, 1. / sqrt(d2 + BROX_EPSILON * BROX_EPSILON));
+}
+
+// psi1..4 of src/brox_spatial_mask.cpp:16-93 at one pixel (0 across the image border)
+struct Psi4 { double p1, p2, p3, p4; };
+template <typename T> OFX_DEV Psi4 brox_psi4(const T *Psis, int i, int j, int nx, int ny)
+{
+    const size_t k = (size_t) i * nx + j;
+    const double c = ldw(Psis + k);
+    Psi4 r;
+    r.p1 = (i < ny - 1) ? 0.5 * (ldw(Psis + k + nx) + c) : 0.0;
+    r.p2 = (i > 0) ? 0.5 * (ldw(Psis + k - nx) + c) : 0.0;
+    r.p3 = (j < nx - 1) ? 0.5 * (ldw(Psis + k + 1) + c) : 0.0;
+    r.p4 = (j > 0) ? 0.5 * (ldw(Psis + k - 1) + c) : 0.0;
+    return r;
+}
+
+// div_u, div_v (src/brox_spatial_mask.cpp:100-171), div_d and du = dv = 0 (:261-274)
+template <typename T>
+__global__ void k_brox_div(const typename Pix<T>::v2 *__restrict__ U, const T *__restrict__ Psis,
+                           typename Pix<T>::v2 *__restrict__ DV, T *__restrict__ Dd, typename Pix<T>::v2 *__restrict__ DU,
+                           int nx, int ny, double alpha)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t k = (size_t) i * nx + j;
+    const Psi4 s = brox_psi4(Psis, i, j, nx, ny);
+    const double2 c = ldw2(U + k);
+    // terms that exist, accumulated in the order down, up, right, left; missing terms are left out
+    double du = 0.0, dv = 0.0;
+    bool have = false;
+    if (i < ny - 1) { const double2 q = ldw2(U + k + nx); du = s.p1 * (q.x - c.x); dv = s.p1 * (q.y - c.y); have = true; }
+    if (i > 0) {
+        const double2 q = ldw2(U + k - nx);
+        const double a = s.p2 * (q.x - c.x), b = s.p2 * (q.y - c.y);
+        du = have ? du + a : a; dv = have ? dv + b : b; have = true;
+    }
+    if (j < nx - 1) {
+        const double2 q = ldw2(U + k + 1);
+        const double a = s.p3 * (q.x - c.x), b = s.p3 * (q.y - c.y);
+        du = have ? du + a : a; dv = have ? dv + b : b; have = true;
+    }
+    if (j > 0) {
+        const double2 q = ldw2(U + k - 1);
+        const double a = s.p4 * (q.x - c.x), b = s.p4 * (q.y - c.y);
+        du = have ? du + a : a; dv = have ? dv + b : b; have = true;
+    }
+    stn2(DV + k, make_double2(du, dv));
+    stn(Dd + k, alpha * (s.p1 + s.p2 + s.p3 + s.p4));                  // :270
+    stn2(DU + k, make_double2(0.0, 0.0));                               // :273
+}
+
+// psi_data, psi_gradient and the constant parts of the scheme, :279-309 (+ :33-92)
+template <typename T>
+__global__ void k_brox_coeff(const T *__restrict__ I1, const typename Pix<T>::v2 *__restrict__ G1,
+                             const typename Pix<T>::v4 *__restrict__ WA, const typename Pix<T>::v2 *__restrict__ WB,
+                             const typename Pix<T>::v2 *__restrict__ DU, const typename Pix<T>::v2 *__restrict__ DV,
+                             const T *__restrict__ Dd, typename Pix<T>::v4 *__restrict__ CO, T *__restrict__ Dm, int n,
+                             double alpha, double gamma)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t) n) return;
+    const double i1 = ldw(I1 + i);
+    const double2 g1 = ldw2(G1 + i);
+    const double4 wa = ldw4(WA + i);
+    const double2 wb = ldw2(WB + i);
+    const double2 d = ldw2(DU + i);
+    const double I2w = wa.x, I2wx = wa.y, I2wy = wa.z, I2wxx = wa.w, I2wxy = wb.x, I2wyy = wb.y;
+    const double eps2 = BROX_EPSILON * BROX_EPSILON;
+    const double dI = I2w - i1 + I2wx * d.x + I2wy * d.y;                              // psi_data :51
+    const double psid = rnd_to<T>(1. / sqrt(dI * dI + eps2));
+    const double dIx = I2wx - g1.x + I2wxx * d.x + I2wxy * d.y;                        // psi_gradient :86-87
+    const double dIy = I2wy - g1.y + I2wxy * d.x + I2wyy * d.y;
+    const double dI2 = dIx * dIx + dIy * dIy;
+    const double psig = rnd_to<T>(1. / sqrt(dI2 + eps2));
+    const double p = psid;
+    const double g = gamma * psig;
+    const double dif = I2w - i1;
+    const double BNu = -p * dif * I2wx;
+    const double BNv = -p * dif * I2wy;
+    const double BDu = p * I2wx * I2wx;
+    const double BDv = p * I2wy * I2wy;
+    const double dx = (I2wx - g1.x);
+    const double dy = (I2wy - g1.y);
+    const double GNu = -g * (dx * I2wxx + dy * I2wxy);
+    const double GNv = -g * (dx * I2wxy + dy * I2wyy);
+    const double GDu = g * (I2wxx * I2wxx + I2wxy * I2wxy);
+    const double GDv = g * (I2wyy * I2wyy + I2wxy * I2wxy);
+    const double DI = (I2wxx + I2wyy) * I2wxy;
+    const double Duv = p * I2wy * I2wx + g * DI;
+    const double2 dv = ldw2(DV + i);
+    const double dd = ldw(Dd + i);
+    stn4(CO + i, make_double4(BNu + GNu + alpha * dv.x, BNv + GNv + alpha * dv.y, BDu + GDu + dd, BDv + GDv + dd));
+    stn(Dm + i, Duv);
+}
+
+// one colour of one SOR sweep, :129-172 at every pixel with (i + j) % 2 == colour
+template <typename T>
+__global__ __launch_bounds__(256) void k_brox_sor(typename Pix<T>::v2 *__restrict__ DU,
+                                                  const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
+                                                  const T *__restrict__ Psis, double *__restrict__ err, int k, int nx,
+                                                  int ny, int colour, double alpha, double tol)
+{
+    const double prev = loop_fetch_prev(err, k);
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    const int j = 2 * (blockIdx.x * 64 + threadIdx.x) + ((i + colour) & 1);
+    const bool in = (j < nx) && (i < ny);
+    const int gw = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.y;
+    if (!loop_continues(prev, k, nx * ny, tol, OFX_CRIT_SQRT_MEAN)) return;
+    double e = 0.0;
+    if (in) {
+        const size_t p = (size_t) i * nx + j;
+        const Psi4 s = brox_psi4(Psis, i, j, nx, ny);
+        // a missing neighbour is addressed as the pixel itself (offset 0) with psi = 0, :332-388
+        const double2 c = ldw2(DU + p);
+        const double2 dn = (i < ny - 1) ? ldw2(DU + p + nx) : c, up = (i > 0) ? ldw2(DU + p - nx) : c;
+        const double2 rt = (j < nx - 1) ? ldw2(DU + p + 1) : c, lf = (j > 0) ? ldw2(DU + p - 1) : c;
+        const double4 co = ldw4(CO + p);
+        const double D = ldw(Dm + p);
+        const double w = BROX_SOR_W;
+        const double div_du = s.p1 * dn.x + s.p2 * up.x + s.p3 * rt.x + s.p4 * lf.x;      // :153-154
+        const double div_dv = s.p1 * dn.y + s.p2 * up.y + s.p3 * rt.y + s.p4 * lf.y;      // :155-156
+        const double duk = c.x, dvk = c.y;
+        const double dun = rnd_to<T>((1. - w) * duk + w * (co.x - D * dvk + alpha * div_du) / co.z);   // :162
+        const double dvn = rnd_to<T>((1. - w) * dvk + w * (co.y - D * dun + alpha * div_dv) / co.w);   // :163
+        stn2(DU + p, make_double2(dun, dvn));
+        e = (dun - duk) * (dun - duk) + (dvn - dvk) * (dvn - dvk);                        // :166
+    }
+    loop_accumulate(err, k, e, gw);
+}
+
+// u += du, v += dv, :398-401
+template <typename T>
+__global__ void k_brox_add(typename Pix<T>::v2 *__restrict__ U, const typename Pix<T>::v2 *__restrict__ DU, int n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t) n) return;
+    const double2 u = ldw2(U + i), d = ldw2(DU + i);
+    stn2(U + i, make_double2(u.x + d.x, u.y + d.y));
+}
+
+template <typename T> struct BroxLevel {
+    using v2 = typename Pix<T>::v2;
+    using v4 = typename Pix<T>::v4;
+    int nx, ny;
+    T *I1, *I2, *Psis, *Dd, *Dm;
+    v2 *G1, *PB, *WB, *U, *DV, *DU;
+    v4 *PA, *WA, *CO;
+};
+
+template <typename T> static int brox_level_alloc(ofx_ctx *ctx, BroxLevel<T> &L, int nx, int ny)
+{
+    const size_t n = (size_t) nx * ny;
+    L.nx = nx;
+    L.ny = ny;
+    OFX_TRY(ofx_alloc(ctx, n, &L.Psis));
+    OFX_TRY(ofx_alloc(ctx, n, &L.Dd));
+    OFX_TRY(ofx_alloc(ctx, n, &L.Dm));
+    OFX_TRY(ofx_alloc(ctx, n, &L.G1));
+    OFX_TRY(ofx_alloc(ctx, n, &L.PB));
+    OFX_TRY(ofx_alloc(ctx, n, &L.WB));
+    OFX_TRY(ofx_alloc(ctx, n, &L.U));
+    OFX_TRY(ofx_alloc(ctx, n, &L.DV));
+    OFX_TRY(ofx_alloc(ctx, n, &L.DU));
+    OFX_TRY(ofx_alloc(ctx, n, &L.PA));
+    OFX_TRY(ofx_alloc(ctx, n, &L.WA));
+    OFX_TRY(ofx_alloc(ctx, n, &L.CO));
+    return OFX_OK;
+}
+
+struct BroxParams {
+    double alpha, gamma, TOL;
+    int inner_iter, outer_iter, verbose;
+};
+
+// src/brox_optic_flow_spatial.cpp:179-444 on device data
+template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams &P, int scale)
+{
+    const int nx = L.nx, ny = L.ny, n = nx * ny;
+    const dim3 g = g2d(nx, ny), b = b2d();
+    const dim3 g1((n + 255) / 256), b1(256);
+    const dim3 gc(ofx_cdiv(ofx_cdiv(nx, 2) + 1, 64), ofx_cdiv(ny, 4));
+    ofx_stats &S = ctx->stats;
+    int solve = 0;
+    hipLaunchKernelGGL(k_brox_prepare<T>, g, b, 0, ctx->stream, (const T *) L.I1, (const T *) L.I2, L.G1, L.PA, L.PB, nx, ny);
+    OFX_LAUNCH_CHECK(ctx);
+    for (int no = 0; no < P.outer_iter; no++) {                                                   // :244
+        hipLaunchKernelGGL(k_brox_warp<T>, g, b, 0, ctx->stream, L.PA, L.PB, L.U, L.WA, L.WB, nx, ny);
+        hipLaunchKernelGGL(k_brox_psis<T>, g, b, 0, ctx->stream, L.U, L.Psis, nx, ny);
+        hipLaunchKernelGGL(k_brox_div<T>, g, b, 0, ctx->stream, L.U, (const T *) L.Psis, L.DV, L.Dd, L.DU, nx, ny, P.alpha);
+        OFX_LAUNCH_CHECK(ctx);
+        for (int ni = 0; ni < P.inner_iter; ni++) {                                               // :277
+            hipLaunchKernelGGL(k_brox_coeff<T>, g1, b1, 0, ctx->stream, (const T *) L.I1, L.G1, L.WA, L.WB, L.DU, L.DV,
+                               (const T *) L.Dd, L.CO, L.Dm, n, P.alpha, P.gamma);
+            OFX_LAUNCH_CHECK(ctx);
+            int nsor = 0;
+            double error = 1000;                                                                  // :312
+            float ms = 0.f;
+            if (error > P.TOL) {
+                LoopSpec LS;
+                LS.max_iter = OFX_BROX_MAX_ITERATIONS;
+                LS.size = n;
+                LS.thr = P.TOL;
+                LS.crit = OFX_CRIT_SQRT_MEAN;
+                LS.chunk = sor_pick_chunk(ctx, nx, ny, 2);
+                LS.fixed = ctx->fixed_work != 0;
+                auto launch = [&](int k, double thr) -> int {
+                    for (int col = 0; col < 2; col++)
+                        hipLaunchKernelGGL(k_brox_sor<T>, gc, b, 0, ctx->stream, L.DU, L.CO, (const T *) L.Dm,
+                                           (const T *) L.Psis, ctx->d_err, k, nx, ny, col, P.alpha, thr);
+                    OFX_LAUNCH_CHECK(ctx);
+                    return OFX_OK;
+                };
+                OFX_TRY(ofx_run_loop(ctx, LS, launch, &nsor, &error, ctx->profile ? &ms : nullptr));
+            }
+            if (P.verbose) { printf("Iterations: %d\n", nsor); fflush(stdout); }                  // :392-394
+            if (scale < OFX_MAX_SCALES) {
+                if (solve < OFX_MAX_SOLVES) { S.iters[scale][solve] = nsor; S.error[scale][solve] = error; }
+                S.iter_ms[scale] += ms;
+                S.iter_launches[scale] += nsor;
+            }
+            S.work_pix_iters += (double) nsor * n;
+            solve++;
+        }
+        hipLaunchKernelGGL(k_brox_add<T>, g1, b1, 0, ctx->stream, L.U, L.DU, n);                  // :398-401
+        OFX_LAUNCH_CHECK(ctx);
+    }
+    return OFX_OK;
+}
+
+// src/brox_optic_flow_spatial.cpp:451-549
+template <typename T>
+static int brox_spatial_host(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nx, int ny,
+                             const BroxParams &P, int nscales, double nu)
+{
+    const size_t n = (size_t) nx * ny;
+    T *dI1, *dI2;
+    OFX_TRY(upload_plane<T>(ctx, I1, n, &dI1));
+    OFX_TRY(upload_plane<T>(ctx, I2, n, &dI2));
+    sor_stats_begin(ctx, nscales, P.inner_iter * P.outer_iter);
+    std::vector<ImgLevel<T>> img;
+    OFX_TRY(op_build_pyramid<T>(ctx, dI1, dI2, nx, ny, nscales, nu, BROX_SIGMA, img));             // :467-504
+    std::vector<BroxLevel<T>> lv(nscales);
+    for (int s = 0; s < nscales; s++) {
+        OFX_TRY(brox_level_alloc<T>(ctx, lv[s], img[s].nx, img[s].ny));
+        lv[s].I1 = img[s].A;
+        lv[s].I2 = img[s].B;
+        ctx->stats.nx[s] = img[s].nx;
+        ctx->stats.ny[s] = img[s].ny;
+    }
+    BroxLevel<T> &C = lv[nscales - 1];
+    OFX_TRY(op_fill2<T>(ctx, C.U, (size_t) C.nx * C.ny));                                          // :507-509
+    for (int s = nscales - 1; s >= 0; s--) {                                                      // :516
+        if (P.verbose) { printf("Scale: %d\n", s); fflush(stdout); }
+        OFX_TRY(brox_single_scale_dev<T>(ctx, lv[s], P, s));
+        if (s)
+            OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U, lv[s - 1].U, lv[s].nx, lv[s].ny, lv[s - 1].nx, lv[s - 1].ny,
+                                       1.0 / nu));                                                // :529-535
+    }
+    return download_flow<T>(ctx, lv[0].U, u, v, n);
+}
+
+extern "C" int ofx_brox_spatial(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nxx,
+                                int nyy, double alpha, double gamma, int nscales, double nu, double TOL,
+                                int inner_iter, int outer_iter, int verbose)
+{
+    OFX_ENTER(ctx);
+    if (!I1 || !I2 || !u || !v) return ofx_fail(ctx, OFX_ERR_ARG, "brox: NULL pointer");
+    if (inner_iter < 0 || outer_iter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "brox: negative iteration count");
+    const double t0 = ofx_now_ms();
+    const BroxParams P = {alpha, gamma, TOL, inner_iter, outer_iter, verbose};
+    int s = ctx->precision == OFX_F64 ? brox_spatial_host<double>(ctx, I1, I2, u, v, nxx, nyy, P, nscales, nu)
+                                      : brox_spatial_host<float>(ctx, I1, I2, u, v, nxx, nyy, P, nscales, nu);
+    ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}

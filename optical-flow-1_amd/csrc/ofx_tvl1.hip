@@ -32,6 +32,7 @@
 // it polls that record one chunk behind, so the GPU never idles and `n` is exactly the reference's.
 #include "ofx_ops.h"
 #include "ofx_device.h"
+#include "ofx_loop.h"
 
 #include <chrono>
 #include <cmath>
@@ -40,26 +41,9 @@
 #define TVL1_PRESMOOTHING_SIGMA 0.8      // src/tvl1flow.cpp:23
 #define STRIP_OUT 62                     // output columns per wave
 
-#define OFX_LAUNCH_CHECK(ctx)                                                                    \
-    do {                                                                                         \
-        hipError_t e__ = hipGetLastError();                                                      \
-        if (e__ != hipSuccess)                                                                   \
-            return ofx_fail((ctx), OFX_ERR_HIP, "kernel launch failed: %s (%s:%d)",              \
-                            hipGetErrorString(e__), __FILE__, __LINE__);                         \
-    } while (0)
-
 template <typename T> OFX_DEV double rnd_to(double x);
 template <> OFX_DEV double rnd_to<double>(double x) { return x; }
 template <> OFX_DEV double rnd_to<float>(double x) { return (double) (float) x; }
-
-// error of iteration slot `k`: sum of the 64 shards in a fixed butterfly order, then `/ size`
-// exactly like src/tvl1flow.cpp:162.  Must be called by a full wave.
-OFX_DEV double tvl1_slot_error(const double *err, int k, int size)
-{
-    const int lane = threadIdx.x & 63;
-    const double e = wave_allreduce_sum(err[(size_t) k * OFX_NSHARD + lane]);
-    return e / size;
-}
 
 template <typename T> struct RowIn {
     double2 u, p1, p2, a;
@@ -92,8 +76,7 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
 
     // The previous iteration's error shards are fetched first and tested last, so the ~2 us memory
     // round trip overlaps with the first row's loads instead of preceding them.
-    double err_shard = 1.0;
-    if (k > 0) err_shard = err[(size_t) (k - 1) * OFX_NSHARD + lane];
+    const double err_shard = loop_fetch_prev(err, k);
 
     const int strip = gw % strips_pad, band = gw / strips_pad;
     const int y0 = band * rows;
@@ -118,10 +101,7 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
     }
 
     // stopping test of src/tvl1flow.cpp:113 on the previous iteration's error
-    if (k > 0) {
-        const double error = wave_allreduce_sum(err_shard) / (nx * ny);
-        if (!(error > eps2)) return;
-    }
+    if (!loop_continues(err_shard, k, nx * ny, eps2, OFX_CRIT_MEAN)) return;
     if (idle) return;
 
     double acc = 0.0;
@@ -198,58 +178,7 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
         cur = nxt;
     }
 
-    acc = wave_allreduce_sum(acc);
-    if (lane == 0) atomicAdd(err + (size_t) k * OFX_NSHARD + (gw & (OFX_NSHARD - 1)), acc);
-}
-
-// One block (16 waves).  Scans the error slots of iterations [start, launched) and publishes how many
-// iterations really ran (the reference's `n`), whether the loop is over, and the error at exit.
-__global__ __launch_bounds__(1024) void k_tvl1_finalize(const double *__restrict__ err, int start, int launched,
-                                                        int max_iter, int size, double eps2, OfxIterState *st,
-                                                        OfxIterState *host_st)
-{
-    __shared__ double s_err[OFX_TVL1_MAX_ITERATIONS];
-    if (st->done) {                                         // an earlier chunk already ended the loop
-        if (threadIdx.x == 0) *host_st = *st;
-        return;
-    }
-    const int w = threadIdx.x >> 6;
-    for (int k = start + w; k < launched; k += 16) {
-        const double e = tvl1_slot_error(err, k, size);
-        if ((threadIdx.x & 63) == 0) s_err[k - start] = e;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int n = launched, done = (launched >= max_iter);
-        double error = launched > start ? s_err[launched - start - 1] : st->error;
-        for (int k = start; k < launched; k++) {
-            if (!(s_err[k - start] > eps2)) { n = k + 1; done = 1; error = s_err[k - start]; break; }
-        }
-        st->n = n;
-        st->done = done;
-        st->error = error;
-        host_st->n = n;                                     // pinned host memory: visible once the kernel retires
-        host_st->error = error;
-        host_st->done = done;
-    }
-}
-
-// centred gradient of I1 packed next to I1 (src/tvl1flow.cpp:84 -> src/operators.cpp:335-406)
-template <typename T>
-__global__ void k_grad_pack(const T *__restrict__ I1, typename Pix<T>::v4 *__restrict__ pack, int nx, int ny)
-{
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    const int i = blockIdx.y * 4 + threadIdx.y;
-    if (j >= nx || i >= ny) return;
-    const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
-    const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
-    const size_t p = (size_t) i * nx + j;
-    double4 o;
-    o.x = ldw(I1 + p);
-    o.y = 0.5 * (ldw(I1 + (size_t) i * nx + jr) - ldw(I1 + (size_t) i * nx + jl));
-    o.z = 0.5 * (ldw(I1 + (size_t) id * nx + j) - ldw(I1 + (size_t) iu * nx + j));
-    o.w = 0.0;
-    stn4(pack + p, o);
+    loop_accumulate(err, k, acc, gw);
 }
 
 // Warp + linearisation (src/tvl1flow.cpp:94-109): the three bicubic warps of I1, I1x, I1y share one
@@ -350,73 +279,36 @@ static int tvl1_pick_chunk(const ofx_ctx *ctx, int nx, int ny)
     return c < 4 ? 4 : (c > 50 ? 50 : c);
 }
 
-// The inner loop of one warp: launches iterations until the device reports the stopping test fired.
-// On return L.cur points at the half holding the result; *n_out / *err_out as the reference prints.
+// The inner loop of one warp (src/tvl1flow.cpp:111-182).  On return L.cur points at the half holding
+// the result; *n_out / *err_out are what the reference prints.
 template <typename T>
 static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, int *n_out, double *err_out,
                                float *ms_out)
 {
-    const int nx = L.nx, ny = L.ny, size = nx * ny;
-    const int max_iter = P.max_iter;
-    const double l_t = P.lambda * P.theta, taut = P.tau / P.theta;
-    const double eps2 = P.fixed ? -1.0 : P.epsilon * P.epsilon;
+    const int nx = L.nx, ny = L.ny;
+    const double l_t = P.lambda * P.theta, taut = P.tau / P.theta, theta = P.theta;
     const int rows = tvl1_pick_rows(ctx, nx, ny);
     const int strips_x = ofx_cdiv(nx, STRIP_OUT), strips_pad = ofx_cdiv(strips_x, 4) * 4;
     const int bands = ofx_cdiv(ny, rows);
     const dim3 grid((unsigned) (strips_pad / 4) * bands), block(256);
-    const int chunk = tvl1_pick_chunk(ctx, nx, ny);
-    OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) max_iter * OFX_NSHARD, ctx->stream));
-    OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
-    if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
-
-    // head / tail count the convergence polls issued / consumed; at most two are outstanding (the one
-    // the host waits for and one chunk of lookahead that keeps the GPU busy meanwhile).
-    int launched = 0, head = 0, tail = 0, slot_of[2] = {0, 0};
-    bool stop = false;
-    OfxIterState fin = {0, 0, 0.0};
+    LoopSpec S;
+    S.max_iter = P.max_iter;
+    S.size = nx * ny;
+    S.thr = P.epsilon * P.epsilon;
+    S.crit = OFX_CRIT_MEAN;
+    S.chunk = tvl1_pick_chunk(ctx, nx, ny);
+    S.fixed = P.fixed;
     const int base = L.cur;
-    for (;;) {
-        while (launched < max_iter && head - tail < 2) {
-            const int c = (max_iter - launched < chunk) ? max_iter - launched : chunk;
-            for (int q = 0; q < c; q++) {
-                const int k = launched + q;
-                const int in = (base + k) & 1, out = in ^ 1;
-                hipLaunchKernelGGL(k_tvl1_iter<T>, grid, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out],
-                                   L.P2[in], L.P2[out], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows, strips_x,
-                                   strips_pad, l_t, P.theta, taut, eps2);
-            }
-            OFX_LAUNCH_CHECK(ctx);
-            const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
-            hipLaunchKernelGGL(k_tvl1_finalize, dim3(1), dim3(1024), 0, ctx->stream, (const double *) ctx->d_err,
-                               launched, launched + c, max_iter, size, eps2, ctx->d_state, &ctx->h_state[slot]);
-            OFX_LAUNCH_CHECK(ctx);
-            launched += c;
-            slot_of[head & 1] = slot;
-            OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
-            head++;
-        }
-        if (tail == head) break;
-        const int slot = slot_of[tail & 1];
-        OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
-        const OfxIterState st = ctx->h_state[slot];
-        tail++;
-        if (st.done) {
-            // A poll still in flight covers launches that are no-ops (their stopping test already
-            // fails); it is not drained -- stream order keeps it ahead of whatever is enqueued next.
-            stop = true;
-            fin = st;
-            break;
-        }
-    }
-    if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
-    if (!stop) return ofx_fail(ctx, OFX_ERR_HIP, "tvl1: iteration loop ended without a final state");
-    L.cur = (base + fin.n) & 1;
-    *n_out = fin.n;
-    *err_out = fin.error;
-    if (ms_out) {
-        OFX_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
-        OFX_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev_t0, ctx->ev_t1));
-    }
+    auto launch = [&](int k, double thr) -> int {
+        const int in = (base + k) & 1, out = in ^ 1;
+        hipLaunchKernelGGL(k_tvl1_iter<T>, grid, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out], L.P2[in],
+                           L.P2[out], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows, strips_x, strips_pad, l_t, theta,
+                           taut, thr);
+        OFX_LAUNCH_CHECK(ctx);
+        return OFX_OK;
+    };
+    OFX_TRY(ofx_run_loop(ctx, S, launch, n_out, err_out, ms_out));
+    L.cur = (base + *n_out) & 1;
     return OFX_OK;
 }
 
@@ -429,8 +321,7 @@ static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params
     const dim3 g2(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), b2(64, 4);
     if (nx < 2 || ny < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: level %dx%d too small", nx, ny);
 
-    hipLaunchKernelGGL(k_grad_pack<T>, g2, b2, 0, ctx->stream, (const T *) L.I1, L.pack, nx, ny);     // :84
-    OFX_LAUNCH_CHECK(ctx);
+    OFX_TRY(op_grad_pack<T>(ctx, L.I1, L.pack, nx, ny));                                                // :84
     OFX_TRY(op_fill2<T>(ctx, L.P1[L.cur], n));                                                          // :87-90
     OFX_TRY(op_fill2<T>(ctx, L.P2[L.cur], n));
 
@@ -467,33 +358,19 @@ template <typename T>
 static int tvl1_multiscale_dev(ofx_ctx *ctx, const T *dI0, const T *dI1, int nxx, int nyy, const Tvl1Params &P,
                                int nscales, double zfactor, std::vector<Tvl1Level<T>> &lv)
 {
-    if (nscales < 1 || nscales > OFX_MAX_SCALES) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: nscales=%d", nscales);
-    if (nxx < 2 || nyy < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: image %dx%d too small", nxx, nyy);
-    if (!(zfactor > 0.0) || !(zfactor < 1.0)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: zfactor=%g", zfactor);
     if (P.warps < 1) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: warps=%d", P.warps);
 
     stats_begin(ctx, nscales, P.warps);
+    std::vector<ImgLevel<T>> img;
+    OFX_TRY(op_build_pyramid<T>(ctx, dI0, dI1, nxx, nyy, nscales, zfactor, TVL1_PRESMOOTHING_SIGMA, img));   // :255-275
     lv.resize(nscales);
-    int nx = nxx, ny = nyy;
     for (int s = 0; s < nscales; s++) {
-        if (s) ofx_zoom_size(lv[s - 1].nx, lv[s - 1].ny, &nx, &ny, zfactor);                 // :263
-        if (nx < 2 || ny < 2) return ofx_fail(ctx, OFX_ERR_SIGMA, "tvl1: scale %d is %dx%d", s, nx, ny);
-        OFX_TRY(tvl1_level_alloc<T>(ctx, lv[s], nx, ny, true));
-        ctx->stats.nx[s] = nx;
-        ctx->stats.ny[s] = ny;
-    }
-    T *tmpA, *tmpB;
-    double *scr;
-    OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpA));
-    OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpB));
-    OFX_TRY(ofx_alloc(ctx, (size_t) 2 * 1024 + 2, &scr));
-
-    OFX_TRY(op_normalize2<T>(ctx, dI0, dI1, lv[0].I0, lv[0].I1, nxx * nyy, scr));               // :255
-    OFX_TRY(op_gaussian<T>(ctx, lv[0].I0, tmpA, nxx, nyy, TVL1_PRESMOOTHING_SIGMA));            // :258-259
-    OFX_TRY(op_gaussian<T>(ctx, lv[0].I1, tmpA, nxx, nyy, TVL1_PRESMOOTHING_SIGMA));
-    for (int s = 1; s < nscales; s++) {                                                          // :262-275
-        OFX_TRY(op_zoom_out<T>(ctx, lv[s - 1].I0, lv[s].I0, tmpA, tmpB, lv[s - 1].nx, lv[s - 1].ny, zfactor));
-        OFX_TRY(op_zoom_out<T>(ctx, lv[s - 1].I1, lv[s].I1, tmpA, tmpB, lv[s - 1].nx, lv[s - 1].ny, zfactor));
+        OFX_TRY(tvl1_level_alloc<T>(ctx, lv[s], img[s].nx, img[s].ny, false));
+        lv[s].I0 = img[s].A;
+        lv[s].I1 = img[s].B;
+        OFX_TRY(ofx_alloc(ctx, (size_t) img[s].nx * img[s].ny, &lv[s].pack));
+        ctx->stats.nx[s] = img[s].nx;
+        ctx->stats.ny[s] = img[s].ny;
     }
     Tvl1Level<T> &C = lv[nscales - 1];
     OFX_TRY(op_fill2<T>(ctx, C.U[0], (size_t) C.nx * C.ny));                                     // :278-280

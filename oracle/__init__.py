@@ -159,6 +159,10 @@ class Oracle(_Lib):
     def dyy(self, f): return self._second("dyy", f)
     def dxy(self, f): return self._second("dxy", f)
 
+    def set_sor_order(self, order):
+        """0 = reference (lexicographic) sweeps, 1 = the HIP path's colour order (checker aid)."""
+        self._fn("set_sor_order", None, C.c_int)(order)
+
     def tvl1_single_scale(self, I0, I1, u1, u2, tau=0.25, lam=0.15, theta=0.3, warps=5, epsilon=0.01,
                           verbose=0):
         ny, nx = I0.shape

@@ -602,9 +602,36 @@ static inline double hs_sor_point(const double *Au, const double *Av, const doub
  * the reference's racy `omp parallel for`, deterministic with one thread), then first/last row
  * interleaved per column, first/last column interleaved per row, then the four corners.  Border
  * pixels replace missing neighbours by replicated indices exactly as :161-228 pass them. */
+/* Checker aid (NOT reference behaviour): sweep order used by the GPU kernels.  0 = the reference's
+ * lexicographic order (default); 1 = multi-colour order -- Horn-Schunck: 4 colours (i%2, j%2) in the
+ * order (0,0) (0,1) (1,0) (1,1); Brox: red-black, (i+j)%2 == 0 first -- every pixel (borders included)
+ * with clamped neighbour indices, which is what the reference's replicated border indices amount to.
+ * With order 1 the oracle reproduces the HIP path's arithmetic bit for bit, which separates "is the
+ * kernel right" from "how far does the colouring move the result" (tests/test_gpu_sor.py). */
+static int g_sor_order = 0;
+void orc_set_sor_order(int order) { g_sor_order = order; }
+
+static double hs_sweep_coloured(const double *Au, const double *Av, const double *Du, const double *Dv,
+                                const double *D, double *u, double *v, double a2, int nx, int ny)
+{
+    double error = 0;
+    for (int col = 0; col < 4; col++) {
+        const int ci = col >> 1, cj = col & 1;
+        for (int i = ci; i < ny; i += 2)
+            for (int j = cj; j < nx; j += 2) {
+                const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+                const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+                error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, i * nx + j, iu * nx + jl, iu * nx + jr,
+                                      id * nx + jl, id * nx + jr, iu * nx + j, i * nx + jl, id * nx + j, i * nx + jr);
+            }
+    }
+    return error;
+}
+
 static double hs_sweep(const double *Au, const double *Av, const double *Du, const double *Dv,
                        const double *D, double *u, double *v, double a2, int nx, int ny)
 {
+    if (g_sor_order) return hs_sweep_coloured(Au, Av, Du, Dv, D, u, v, a2, nx, ny);
     double error = 0;
     #pragma omp parallel for reduction(+:error)
     for (int i = 1; i < ny - 1; i++)
@@ -860,6 +887,16 @@ static void brox_single_scale(const double *I1, const double *I2, double *u, dou
             while (error > TOL && nsor < BROX_MAXITER) {       /* :315 */
                 error = 0;
                 nsor++;
+                if (g_sor_order) {          /* checker aid: red-black order of the HIP path */
+                    for (int col = 0; col < 2; col++)
+                        for (int i = 0; i < ny; i++)
+                            for (int j = (i + col) & 1; j < nx; j += 2)
+                                error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, i,
+                                                        i > 0 ? nx : 0, i < ny - 1 ? nx : 0, j, nx, j > 0 ? 1 : 0,
+                                                        j < nx - 1 ? 1 : 0);
+                    error = sqrt(error / size);
+                    continue;
+                }
                 #pragma omp parallel for reduction(+:error)
                 for (int i = 1; i < ny - 1; i++)
                     for (int j = 1; j < nx - 1; j++)

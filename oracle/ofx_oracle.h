@@ -63,6 +63,9 @@ double orc_tvl1_iterations(double *u1, double *u2, double *p11, double *p12, dou
                            const double *grad, int nx, int ny, double tau, double lambda,
                            double theta, int n_iter);
 
+/* checker aid, see ofx_oracle.c: 0 = reference sweep order (default), 1 = the HIP path's colour order */
+void orc_set_sor_order(int order);
+
 /* horn_schunck_pyramidal.cpp */
 void orc_hs_single_scale(const double *I1, const double *I2, double *u, double *v, int nx, int ny,
                          double alpha, int warps, double TOL, int maxiter, int verbose, int *iters);
