@@ -1,0 +1,64 @@
+"""The C-ABI boundary without a GPU: libofx.so builds for gfx950, loads, exports every entry point that
+include/ofx.h declares, and refuses to work without a device (no silent CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ofx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ofx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_reference_boundary():
+    syms = declared_symbols()
+    for must in ("ofx_tvl1_single_scale", "ofx_tvl1_multiscale", "ofx_hs_single_scale", "ofx_hs_pyramidal",
+                 "ofx_brox_spatial", "ofx_divergence", "ofx_forward_gradient", "ofx_centered_gradient", "ofx_gaussian",
+                 "ofx_bicubic_warp", "ofx_bicubic_at", "ofx_zoom_size", "ofx_zoom_out", "ofx_zoom_in",
+                 "ofx_image_normalization_2", "ofx_ctx_create", "ofx_ctx_destroy"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(ofx_mod):
+    if not os.path.exists(ofx_mod.LIB_PATH):
+        ofx_mod.build()
+    lib = C.CDLL(ofx_mod.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert missing == []
+    assert ofx_mod.lib().ofx_missing == []          # the Python mirror binds the same set
+
+
+def test_no_device_no_context(ofx_mod):
+    L = ofx_mod.lib()
+    if L.ofx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert L.ofx_ctx_create(C.byref(h), 0, ofx_mod.F64) == 5      # OFX_ERR_NODEV
+    assert not h.value
+    with pytest.raises(ofx_mod.OfxError):
+        ofx_mod.Ofx(0)                                            # the product path fails loudly
+    assert L.ofx_ctx_create(C.byref(h), 0, 7) == 1                # bad precision -> OFX_ERR_ARG
+    assert L.ofx_strerror(2) == b"GaussianSmooth: sigma too large"
+
+
+def test_zoom_size_is_host_arithmetic(ofx_mod):
+    # (int)(n * factor + 0.5), src/zoom.cpp:32-33
+    assert ofx_mod.zoom_size(1920, 1080, 0.5) == (960, 540)
+    assert ofx_mod.zoom_size(135, 68, 0.5) == (68, 34)
+    assert ofx_mod.zoom_size(240, 135, 0.5) == (120, 68)
+    assert ofx_mod.zoom_size(7, 5, 0.75) == (5, 4)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Nothing under the product package or its C sources may import / link / call oracle/."""
+    pkg = os.path.join(ROOT, "optical-flow-1_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in text and "liboracle" not in text and "libofref" not in text, f

@@ -1,0 +1,64 @@
+"""Pins the oracle against the committed golden vectors (tests/golden/*.npz, generated from the compiled
+reference by tests/golden/make_golden.py).  Runs everywhere, including the GPU box where the reference
+does not exist.  Bit-exact: the oracle runs with one OpenMP thread like the generator did."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = json.load(open(os.path.join(G, "cases.json")))
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("tag", ["7x5", "16x16", "135x68"])
+def test_operators(orc, tag):
+    g = load("operators")
+    a, b, img, u, v = (g["in_%s_%s" % (k, tag)] for k in ("a", "b", "img", "u", "v"))
+    ny, nx = a.shape
+    assert np.array_equal(orc.divergence(a, b), g["divergence_" + tag])
+    fx, fy = orc.forward_gradient(a)
+    assert np.array_equal(fx, g["fwd_x_" + tag]) and np.array_equal(fy, g["fwd_y_" + tag])
+    cx, cy = orc.centered_gradient(a)
+    assert np.array_equal(cx, g["cen_x_" + tag]) and np.array_equal(cy, g["cen_y_" + tag])
+    for name in ("dxx", "dyy", "dxy"):
+        assert np.array_equal(getattr(orc, name)(a), g[name + "_" + tag])
+    assert np.array_equal(orc.bicubic_warp(img, u, v, True), g["warp_bo_" + tag])
+    assert np.array_equal(orc.bicubic_warp(img, u, v, False), g["warp_nb_" + tag])
+    n1, n2 = orc.image_normalization_2(img, img * 0.5 + 3)
+    assert np.array_equal(n1, g["norm1_" + tag]) and np.array_equal(n2, g["norm2_" + tag])
+    if "gauss08_" + tag in g:
+        assert np.array_equal(orc.gaussian(img, 0.8), g["gauss08_" + tag])
+        assert np.array_equal(orc.gaussian(img, 0.6 * np.sqrt(3.0)), g["gauss104_" + tag])
+        assert np.array_equal(orc.zoom_out(img, 0.5), g["zoomout05_" + tag])
+        assert np.array_equal(orc.zoom_out(img, 0.7), g["zoomout07_" + tag])
+        assert np.array_equal(orc.zoom_in(a, 2 * nx - 1, 2 * ny), g["zoomin_" + tag])
+
+
+def test_bicubic_at_and_zoom_size(orc):
+    g = load("operators")
+    img = g["in_img_7x5"]
+    for bo, key in ((False, "at_nb"), (True, "at_bo")):
+        got = np.array([orc.bicubic_at(img, x, y, bo) for x, y in g["at_points"]])
+        assert np.array_equal(got, g[key])
+    for nx, ny, nxx, nyy in g["zoom_sizes"][::2]:
+        assert orc.zoom_size(int(nx), int(ny), 0.5) == (int(nxx), int(nyy))
+    for nx, ny, nxx, nyy in g["zoom_sizes"][1::2]:
+        assert orc.zoom_size(int(nx), int(ny), 0.75) == (int(nxx), int(nyy))
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_solvers(orc, synth, case):
+    c = CASES[case]
+    g = load(case)
+    I0, I1 = synth.pair(c["pair"], c["nx"], c["ny"])
+    fn = {"tvl1": orc.tvl1_multiscale, "hs": orc.hs_pyramidal, "brox": orc.brox_spatial}[c["kind"]]
+    out = fn(I0, I1, **c["params"])
+    u, v, iters = out[0], out[1], out[2]
+    assert np.array_equal(u, g["u"]) and np.array_equal(v, g["v"])
+    # the reference prints coarse-to-fine; the oracle stores [scale][solve] with scale 0 = finest
+    assert list(iters[::-1].ravel()) == list(g["iters"])
