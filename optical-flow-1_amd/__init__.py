@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libofx.so")
+LIB_PATH = os.environ.get("OFX_LIB_PATH") or os.path.join(HERE, "libofx.so")   # override: A/B builds only
 
 F64, F32 = 0, 1
 MAX_SCALES, MAX_SOLVES = 32, 64

@@ -61,6 +61,8 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->h_stage_bytes = 0;
     ctx->profile = 0;
     ctx->rows_per_wave = 0;     // 0 = pick per level
+    ctx->rows_per_wave2 = 0;
+    ctx->fuse2 = 1;             // two TV-L1 iterations per launch
     ctx->chunk = 0;             // 0 = pick per level
     ctx->fixed_work = 0;
     ctx->poll_seq = 0;
@@ -121,6 +123,12 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
         ctx->rows_per_wave = (int) value;
         return OFX_OK;
     }
+    if (!strcmp(name, "rows_per_wave2")) {
+        if (value < 0 || value > 4096) return ofx_fail(ctx, OFX_ERR_ARG, "rows_per_wave2 out of range");
+        ctx->rows_per_wave2 = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "fuse2")) { ctx->fuse2 = value != 0; return OFX_OK; }
     if (!strcmp(name, "chunk")) {
         if (value < 0 || value > OFX_TVL1_MAX_ITERATIONS) return ofx_fail(ctx, OFX_ERR_ARG, "chunk out of range");
         ctx->chunk = (int) value;

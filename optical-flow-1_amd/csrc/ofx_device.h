@@ -31,14 +31,29 @@ OFX_DEV void stn4(float4 *p, double4 v)
 }
 
 // ---- wave64 primitives --------------------------------------------------------------------------
+// Neighbour-lane moves.  gfx950 (GFX9 family) has whole-wavefront DPP shifts: one v_mov_b32_dpp per
+// dword, no LDS crossbar round trip and no address arithmetic (a __shfl compiles to ds_bpermute_b32 +
+// lane-index math).  wave_shr:1 moves data towards higher lanes (lane i reads lane i-1), wave_shl:1
+// the other way; the lane with no source keeps its own value (bound_ctrl off, old = src).
+#ifndef OFX_NO_DPP
 OFX_DEV double wave_shift_up(double v)      // value of lane-1 (lane 0 keeps its own)
 {
-    return __shfl_up(v, 1, 64);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
 OFX_DEV double wave_shift_down(double v)    // value of lane+1 (lane 63 keeps its own)
 {
-    return __shfl_down(v, 1, 64);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
+#else
+OFX_DEV double wave_shift_up(double v) { return __shfl_up(v, 1, 64); }
+OFX_DEV double wave_shift_down(double v) { return __shfl_down(v, 1, 64); }
+#endif
 // Butterfly all-reduce: every lane ends with the same bits (each level adds the same two partial
 // sums in every lane, only the operand order differs and + is commutative).
 OFX_DEV double wave_allreduce_sum(double v)

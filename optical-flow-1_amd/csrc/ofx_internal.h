@@ -53,6 +53,8 @@ struct ofx_ctx {
     // options
     int profile;
     int rows_per_wave;
+    int rows_per_wave2;
+    int fuse2;
     int chunk;
     int fixed_work;
     unsigned long long poll_seq;

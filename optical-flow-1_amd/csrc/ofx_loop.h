@@ -51,17 +51,22 @@ struct LoopSpec {
     int    crit;       // OFX_CRIT_*
     int    chunk;      // sweeps per poll
     bool   fixed;      // run exactly max_iter sweeps (stopping test disabled)
+    bool   pairs;      // the solver fuses two sweeps per launch where it can (TV-L1)
 };
 
 int ofx_loop_reserve(ofx_ctx *ctx, int max_iter);                      // err slots for max_iter sweeps
 int ofx_loop_finalize(ofx_ctx *ctx, const LoopSpec &L, int start, int launched, OfxIterState *host_slot);
 
-// Runs the loop.  launch(k, thr_eff) must enqueue every kernel of sweep k on ctx->stream; kernels
-// take (ctx->d_err, k, thr_eff, crit) and use the helpers above.  Returns the reference's n and error.
-template <class LaunchFn>
-static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, int *n_out, double *err_out, float *ms_out)
+// Runs the loop.  launch(k, count, thr) must enqueue every kernel of sweeps k .. k+count-1 on ctx->stream
+// (count is 2 only when L.pairs and at least two sweeps remain; pairs always start at an even k);
+// kernels take (ctx->d_err, k, thr) and use the helpers above.  With L.pairs the second sweep of a pair
+// runs even when the first one ended the loop; if that happens (n odd), redo(n-1) must recompute sweep
+// n-1 alone from the pair's untouched input buffers.  Returns the reference's n and error.
+template <class LaunchFn, class RedoFn>
+static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, RedoFn redo, int *n_out, double *err_out,
+                        float *ms_out)
 {
-    OFX_TRY(ofx_loop_reserve(ctx, L.max_iter));
+    OFX_TRY(ofx_loop_reserve(ctx, L.max_iter + 1));      // +1: scratch slot for the redo's error
     LoopSpec S = L;
     if (S.fixed) S.thr = -1.0;          // error >= 0 always passes `error > -1`
     OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) S.max_iter * OFX_NSHARD, ctx->stream));
@@ -73,14 +78,19 @@ static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, int *n
     int launched = 0, head = 0, tail = 0, slot_of[2] = {0, 0};
     bool stop = false;
     OfxIterState fin = {0, 0, 0.0};
-    const int chunk = S.chunk < 1 ? 1 : S.chunk;
+    int chunk = S.chunk < 1 ? 1 : S.chunk;
+    if (S.pairs) chunk += chunk & 1;
     for (;;) {
         while (launched < S.max_iter && head - tail < 2) {
+            const int first = launched;
             const int c = (S.max_iter - launched < chunk) ? S.max_iter - launched : chunk;
-            for (int q = 0; q < c; q++) OFX_TRY(launch(launched + q, S.thr));
+            while (launched < first + c) {
+                const int cnt = (S.pairs && first + c - launched >= 2) ? 2 : 1;
+                OFX_TRY(launch(launched, cnt, S.thr));
+                launched += cnt;
+            }
             const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
-            OFX_TRY(ofx_loop_finalize(ctx, S, launched, launched + c, &ctx->h_state[slot]));
-            launched += c;
+            OFX_TRY(ofx_loop_finalize(ctx, S, first, launched, &ctx->h_state[slot]));
             slot_of[head & 1] = slot;
             OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
             head++;
@@ -98,8 +108,9 @@ static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, int *n
             break;
         }
     }
-    if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
     if (!stop) return ofx_fail(ctx, OFX_ERR_HIP, "iteration loop ended without a final state");
+    if (S.pairs && (fin.n & 1) && fin.n != S.max_iter) OFX_TRY(redo(fin.n - 1));
+    if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
     *n_out = fin.n;
     *err_out = fin.error;
     if (ms_out) {

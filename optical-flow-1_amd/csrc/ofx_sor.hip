@@ -175,14 +175,15 @@ template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L
             LS.crit = OFX_CRIT_SQRT_MEAN;
             LS.chunk = sor_pick_chunk(ctx, nx, ny, 4);
             LS.fixed = ctx->fixed_work != 0;
-            auto launch = [&](int k, double thr) -> int {
+            LS.pairs = false;
+            auto launch = [&](int k, int, double thr) -> int {
                 for (int col = 0; col < 4; col++)
                     hipLaunchKernelGGL(k_hs_sor<T>, gc, b2d(), 0, ctx->stream, L.U, L.A, (const T *) L.Dif, ctx->d_err, k,
                                        nx, ny, col >> 1, col & 1, alpha2, thr);
                 OFX_LAUNCH_CHECK(ctx);
                 return OFX_OK;
             };
-            OFX_TRY(ofx_run_loop(ctx, LS, launch, &niter, &error, ctx->profile ? &ms : nullptr));
+            OFX_TRY(ofx_run_loop(ctx, LS, launch, [](int) { return OFX_OK; }, &niter, &error, ctx->profile ? &ms : nullptr));
         }
         if (P.verbose) fprintf(stderr, "Iterations %d (%g)\n", niter, error);                // :233-235
         if (scale < OFX_MAX_SCALES) {
@@ -630,14 +631,15 @@ template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T
                 LS.crit = OFX_CRIT_SQRT_MEAN;
                 LS.chunk = sor_pick_chunk(ctx, nx, ny, 2);
                 LS.fixed = ctx->fixed_work != 0;
-                auto launch = [&](int k, double thr) -> int {
+                LS.pairs = false;
+                auto launch = [&](int k, int, double thr) -> int {
                     for (int col = 0; col < 2; col++)
                         hipLaunchKernelGGL(k_brox_sor<T>, gc, b, 0, ctx->stream, L.DU, L.CO, (const T *) L.Dm,
                                            (const T *) L.Psis, ctx->d_err, k, nx, ny, col, P.alpha, thr);
                     OFX_LAUNCH_CHECK(ctx);
                     return OFX_OK;
                 };
-                OFX_TRY(ofx_run_loop(ctx, LS, launch, &nsor, &error, ctx->profile ? &ms : nullptr));
+                OFX_TRY(ofx_run_loop(ctx, LS, launch, [](int) { return OFX_OK; }, &nsor, &error, ctx->profile ? &ms : nullptr));
             }
             if (P.verbose) { printf("Iterations: %d\n", nsor); fflush(stdout); }                  // :392-394
             if (scale < OFX_MAX_SCALES) {

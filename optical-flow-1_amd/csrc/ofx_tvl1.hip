@@ -63,20 +63,77 @@ OFX_DEV RowIn<T> tvl1_load_row(const typename Pix<T>::v2 *U, const typename Pix<
     return r;
 }
 
+// Stage "primal" at one pixel: thresholding TH (src/tvl1flow.cpp:117-143), divergence of p
+// (src/operators.cpp:35-78) and u = v + theta div p (:156-157).  l11/l21 = p11/p21 of the left pixel,
+// up12/up22 = p12/p22 of the pixel above.  Returns the new (u1,u2), rounded to the storage type.
+template <typename T>
+OFX_DEV double2 tvl1_primal(double2 u, double2 a, double r, double2 p1, double2 p2, double l11, double l21, double up12,
+                            double up22, bool lef, bool rig, bool top, bool bot, double l_t, double theta)
+{
+    const double div1 = div_backward(p1.x, l11, p1.y, up12, lef, rig, top, bot);
+    const double div2 = div_backward(p2.x, l21, p2.y, up22, lef, rig, top, bot);
+    const double ix = a.x, iy = a.y;
+    const double grad = ix * ix + iy * iy;                  // :100-104
+    const double rho = r + (ix * u.x + iy * u.y);           // :119-120
+    const double ltg = l_t * grad;
+    const double fi = -rho / grad;
+    double d1, d2;
+    if (rho < -ltg)                     { d1 = l_t * ix;  d2 = l_t * iy; }
+    else if (rho > ltg)                 { d1 = -l_t * ix; d2 = -l_t * iy; }
+    else if (grad < TVL1_GRAD_IS_ZERO)  { d1 = 0.0;       d2 = 0.0; }
+    else                                { d1 = fi * ix;   d2 = fi * iy; }
+    const double v1 = u.x + d1, v2 = u.y + d2;
+    return make_double2(rnd_to<T>(v1 + theta * div1), rnd_to<T>(v2 + theta * div2));
+}
+
+// Stage "dual" at one pixel: forward gradient of the NEW u (src/operators.cpp:86-125) and the dual
+// update (src/tvl1flow.cpp:169-181).  un = new u here, r1/r2 = new u1/u2 of the right pixel, dn = new u
+// of the pixel below.
+OFX_DEV void tvl1_dual(double2 p1, double2 p2, double2 un, double r1, double r2, double2 dn, bool rig, bool lastrow,
+                       double taut, double2 &q1, double2 &q2)
+{
+    const double u1x = rig ? 0.0 : r1 - un.x;
+    const double u2x = rig ? 0.0 : r2 - un.y;
+    const double u1y = lastrow ? 0.0 : dn.x - un.x;
+    const double u2y = lastrow ? 0.0 : dn.y - un.y;
+    const double g1 = hypot_ref(u1x, u1y);
+    const double g2 = hypot_ref(u2x, u2y);
+    const double ng1 = 1.0 + taut * g1;
+    const double ng2 = 1.0 + taut * g2;
+    q1.x = (p1.x + taut * u1x) / ng1;
+    q1.y = (p1.y + taut * u1y) / ng1;
+    q2.x = (p2.x + taut * u2x) / ng2;
+    q2.y = (p2.y + taut * u2y) / ng2;
+}
+
+// Stopping test shared by both iteration kernels.  Launch k runs only if NEITHER of the two previous
+// iterations ended the loop: with two iterations fused per launch the second one always executes, so a
+// loop that ends on the first iteration of a pair leaves a live error in the second slot -- looking
+// two slots back keeps every later launch a no-op (and the pair's input buffers intact for the redo).
+OFX_DEV bool tvl1_continues(double prev1, double prev2, int k, int size, double eps2)
+{
+    if (k >= 1 && !(loop_error_from_sum(wave_allreduce_sum(prev1), size, OFX_CRIT_MEAN) > eps2)) return false;
+    if (k >= 2 && !(loop_error_from_sum(wave_allreduce_sum(prev2), size, OFX_CRIT_MEAN) > eps2)) return false;
+    return true;
+}
+
+// ---- one iteration per launch ------------------------------------------------------------------------
+// `slot` is where the error of this iteration is accumulated; `check` = index of this iteration in the
+// loop (0 = no stopping test, used for the unconditional redo of a single iteration).
 template <typename T>
 __global__ __launch_bounds__(256) void k_tvl1_iter(
     const typename Pix<T>::v2 *__restrict__ Uin, typename Pix<T>::v2 *__restrict__ Uout,
     const typename Pix<T>::v2 *__restrict__ P1in, typename Pix<T>::v2 *__restrict__ P1out,
     const typename Pix<T>::v2 *__restrict__ P2in, typename Pix<T>::v2 *__restrict__ P2out,
-    const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ R, double *__restrict__ err, int k, int nx,
-    int ny, int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2)
+    const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ R, double *__restrict__ err, int check, int slot,
+    int nx, int ny, int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2)
 {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
 
-    // The previous iteration's error shards are fetched first and tested last, so the ~2 us memory
+    // The previous iterations' error shards are fetched first and tested last, so the ~2 us memory
     // round trip overlaps with the first row's loads instead of preceding them.
-    const double err_shard = loop_fetch_prev(err, k);
+    const double prev1 = loop_fetch_prev(err, check), prev2 = loop_fetch_prev(err, check - 1);
 
     const int strip = gw % strips_pad, band = gw / strips_pad;
     const int y0 = band * rows;
@@ -100,8 +157,8 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
         cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) y0 * nx + cc);
     }
 
-    // stopping test of src/tvl1flow.cpp:113 on the previous iteration's error
-    if (!loop_continues(err_shard, k, nx * ny, eps2, OFX_CRIT_MEAN)) return;
+    // stopping test of src/tvl1flow.cpp:113
+    if (!tvl1_continues(prev1, prev2, check, nx * ny, eps2)) return;
     if (idle) return;
 
     double acc = 0.0;
@@ -115,61 +172,26 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
 
         double2 un = make_double2(0.0, 0.0);
         if (y < ny) {
-            // (ii) divergence of p, src/operators.cpp:35-78
             const double l11 = wave_shift_up(cur.p1.x);
             const double l21 = wave_shift_up(cur.p2.x);
-            const bool top = (y == 0), bot = (y == ny - 1);
-            const double div1 = div_backward(cur.p1.x, l11, cur.p1.y, up12, lef, rig, top, bot);
-            const double div2 = div_backward(cur.p2.x, l21, cur.p2.y, up22, lef, rig, top, bot);
-
-            // (i) thresholding operator TH, src/tvl1flow.cpp:117-143
-            const double ix = cur.a.x, iy = cur.a.y;
-            const double grad = ix * ix + iy * iy;                      // :100-104
-            const double rho = cur.r + (ix * cur.u.x + iy * cur.u.y);   // :119-120
-            const double ltg = l_t * grad;
-            const double fi = -rho / grad;
-            double d1, d2;
-            if (rho < -ltg)                     { d1 = l_t * ix;  d2 = l_t * iy; }
-            else if (rho > ltg)                 { d1 = -l_t * ix; d2 = -l_t * iy; }
-            else if (grad < TVL1_GRAD_IS_ZERO)  { d1 = 0.0;       d2 = 0.0; }
-            else                                { d1 = fi * ix;   d2 = fi * iy; }
-            const double v1 = cur.u.x + d1, v2 = cur.u.y + d2;
-
-            // (iii) primal update + error, :150-162
-            un.x = rnd_to<T>(v1 + theta * div1);
-            un.y = rnd_to<T>(v2 + theta * div2);
+            un = tvl1_primal<T>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0, y == ny - 1,
+                                l_t, theta);
             if (owner && y < yend) {
                 stn2(Uout + (size_t) y * nx + c, un);
-                acc += (un.x - cur.u.x) * (un.x - cur.u.x) + (un.y - cur.u.y) * (un.y - cur.u.y);
+                acc += (un.x - cur.u.x) * (un.x - cur.u.x) + (un.y - cur.u.y) * (un.y - cur.u.y);   // :159-160
             }
         }
-
         if (y > y0) {
-            // (iv) forward gradient of the NEW u at row y-1 (src/operators.cpp:86-125) and
-            // (v) dual update (src/tvl1flow.cpp:169-181)
             const double r1 = wave_shift_down(un_prev.x);
             const double r2 = wave_shift_down(un_prev.y);
-            const bool lastrow = (y - 1 == ny - 1);
-            const double u1x = rig ? 0.0 : r1 - un_prev.x;
-            const double u2x = rig ? 0.0 : r2 - un_prev.y;
-            const double u1y = lastrow ? 0.0 : un.x - un_prev.x;
-            const double u2y = lastrow ? 0.0 : un.y - un_prev.y;
-            const double g1 = hypot_ref(u1x, u1y);
-            const double g2 = hypot_ref(u2x, u2y);
-            const double ng1 = 1.0 + taut * g1;
-            const double ng2 = 1.0 + taut * g2;
             double2 q1, q2;
-            q1.x = (p1_prev.x + taut * u1x) / ng1;
-            q1.y = (p1_prev.y + taut * u1y) / ng1;
-            q2.x = (p2_prev.x + taut * u2x) / ng2;
-            q2.y = (p2_prev.y + taut * u2y) / ng2;
+            tvl1_dual(p1_prev, p2_prev, un_prev, r1, r2, un, rig, y - 1 == ny - 1, taut, q1, q2);
             if (owner) {
                 const size_t pp = (size_t) (y - 1) * nx + c;
                 stn2(P1out + pp, q1);
                 stn2(P2out + pp, q2);
             }
         }
-
         un_prev = un;
         p1_prev = cur.p1;
         p2_prev = cur.p2;
@@ -177,8 +199,127 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
         up22 = cur.p2.y;
         cur = nxt;
     }
+    loop_accumulate(err, slot, acc, gw);
+}
 
-    loop_accumulate(err, k, acc, gw);
+// ---- two iterations per launch -----------------------------------------------------------------------
+// Iterations k (A) and k+1 (B) fused: the wave marches down its strip once and runs a four-stage
+// software pipeline per loaded row y:   S1  u_A(y)   S2  p_A(y-1)   S3  u_B(y-2)   S4  p_B(y-3)
+// Intermediate u_A / p_A never touch memory: they live in registers for the one or two marching steps
+// until the next stage consumes them.  Each fused iteration widens the dependency cone by one pixel, so
+// a wave now owns 60 output columns (lanes 2..61, two halo lanes each side) and loads rows
+// y0-1 .. yend+1 (+ p12/p22 of row y0-2).  Halo pixels are recomputed by the neighbouring wave with the
+// same arithmetic, so results do not depend on the decomposition and stay bit-identical to the
+// one-iteration kernel.  HBM traffic per iteration drops from 15 to ~(9 (rows+3)/rows 64/60 + 6)/2
+// elements per pixel (8.3 at rows = 16).
+#define STRIP2_OUT 60
+#ifndef OFX_ITER2_BOUNDS
+#define OFX_ITER2_BOUNDS __launch_bounds__(256)
+#endif
+template <typename T>
+__global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
+    const typename Pix<T>::v2 *__restrict__ Uin, typename Pix<T>::v2 *__restrict__ Uout,
+    const typename Pix<T>::v2 *__restrict__ P1in, typename Pix<T>::v2 *__restrict__ P1out,
+    const typename Pix<T>::v2 *__restrict__ P2in, typename Pix<T>::v2 *__restrict__ P2out,
+    const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ R, double *__restrict__ err, int k, int nx, int ny,
+    int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2)
+{
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const double prev1 = loop_fetch_prev(err, k), prev2 = loop_fetch_prev(err, k - 1);
+
+    const int strip = gw % strips_pad, band = gw / strips_pad;
+    const int y0 = band * rows;
+    const bool idle = (strip >= strips_x) || (y0 >= ny);
+    const int yend = (y0 + rows < ny) ? y0 + rows : ny;     // rows [y0, yend) are written by this wave
+    const int ys = y0 > 0 ? y0 - 1 : 0;                      // first row loaded
+    const int yl = (yend + 1 < ny - 1) ? yend + 1 : ny - 1;  // last row loaded
+
+    const int c = strip * STRIP2_OUT - 2 + lane;            // lanes 0,1 / 62,63 are halo columns
+    const int cc = c < 0 ? 0 : (c > nx - 1 ? nx - 1 : c);
+    const bool lef = (c == 0), rig = (c == nx - 1);
+    const bool owner = (lane >= 2) && (lane <= STRIP2_OUT + 1) && (c < nx);
+
+    double up12 = 0.0, up22 = 0.0;                           // p12 / p22 (iteration k-1) of row y-1
+    RowIn<T> cur;
+    if (!idle) {
+        if (ys > 0) {
+            const size_t pu = (size_t) (ys - 1) * nx + cc;
+            up12 = ldw2(P1in + pu).y;
+            up22 = ldw2(P2in + pu).y;
+        }
+        cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) ys * nx + cc);
+    }
+    if (!tvl1_continues(prev1, prev2, k, nx * ny, eps2)) return;
+    if (idle) return;
+
+    const double2 z2 = make_double2(0.0, 0.0);
+    double accA = 0.0, accB = 0.0;
+    double2 uA0 = z2, uA1 = z2, uA2 = z2;                    // u_A of rows y, y-1, y-2
+    double2 a1 = z2, a2 = z2;                                // (I1wx, I1wy) of rows y-1, y-2
+    double r1c = 0.0, r2c = 0.0;                             // rho_c of rows y-1, y-2
+    double2 p0a = z2, p0b = z2;                              // p (iteration k-1) of row y-1
+    double2 pA1a = z2, pA1b = z2, pA2a = z2, pA2b = z2;      // p_A of rows y-2, y-3
+    double2 uB0 = z2, uB1 = z2;                              // u_B of rows y-2, y-3
+
+    for (int y = ys; y <= yend + 2; y++) {
+        RowIn<T> nxt = cur;
+        if (y + 1 <= yl) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) (y + 1) * nx + cc);
+
+        // S1: u_A(y)
+        const bool have1 = (y <= yl);
+        if (have1) {
+            const double l11 = wave_shift_up(cur.p1.x);
+            const double l21 = wave_shift_up(cur.p2.x);
+            uA0 = tvl1_primal<T>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0, y == ny - 1,
+                                 l_t, theta);
+            if (owner && y >= y0 && y < yend)
+                accA += (uA0.x - cur.u.x) * (uA0.x - cur.u.x) + (uA0.y - cur.u.y) * (uA0.y - cur.u.y);
+        }
+        // S2: p_A(y-1)
+        double2 pAna = z2, pAnb = z2;
+        if (y - 1 >= ys && y - 1 <= yend && y - 1 <= ny - 1) {
+            const double n1 = wave_shift_down(uA1.x);
+            const double n2 = wave_shift_down(uA1.y);
+            tvl1_dual(p0a, p0b, uA1, n1, n2, uA0, rig, y - 1 == ny - 1, taut, pAna, pAnb);
+            pAna.x = rnd_to<T>(pAna.x); pAna.y = rnd_to<T>(pAna.y);
+            pAnb.x = rnd_to<T>(pAnb.x); pAnb.y = rnd_to<T>(pAnb.y);
+        }
+        // S3: u_B(y-2)
+        if (y - 2 >= y0 && y - 2 <= yend && y - 2 <= ny - 1) {
+            const double l11 = wave_shift_up(pA1a.x);
+            const double l21 = wave_shift_up(pA1b.x);
+            uB0 = tvl1_primal<T>(uA2, a2, r2c, pA1a, pA1b, l11, l21, pA2a.y, pA2b.y, lef, rig, y - 2 == 0, y - 2 == ny - 1,
+                                 l_t, theta);
+            if (owner && y - 2 < yend) {
+                stn2(Uout + (size_t) (y - 2) * nx + c, uB0);
+                accB += (uB0.x - uA2.x) * (uB0.x - uA2.x) + (uB0.y - uA2.y) * (uB0.y - uA2.y);
+            }
+        }
+        // S4: p_B(y-3)
+        if (y - 3 >= y0 && y - 3 < yend) {
+            const double n1 = wave_shift_down(uB1.x);
+            const double n2 = wave_shift_down(uB1.y);
+            double2 q1, q2;
+            tvl1_dual(pA2a, pA2b, uB1, n1, n2, uB0, rig, y - 3 == ny - 1, taut, q1, q2);
+            if (owner) {
+                const size_t pp = (size_t) (y - 3) * nx + c;
+                stn2(P1out + pp, q1);
+                stn2(P2out + pp, q2);
+            }
+        }
+        // advance the pipeline by one row
+        uA2 = uA1; uA1 = uA0;
+        a2 = a1; a1 = cur.a;
+        r2c = r1c; r1c = cur.r;
+        p0a = cur.p1; p0b = cur.p2;
+        up12 = cur.p1.y; up22 = cur.p2.y;
+        pA2a = pA1a; pA2b = pA1b; pA1a = pAna; pA1b = pAnb;
+        uB1 = uB0;
+        cur = nxt;
+    }
+    loop_accumulate(err, k, accA, gw);
+    loop_accumulate(err, k + 1, accB, gw);
 }
 
 // Warp + linearisation (src/tvl1flow.cpp:94-109): the three bicubic warps of I1, I1x, I1y share one
@@ -269,6 +410,18 @@ static int tvl1_pick_rows(const ofx_ctx *ctx, int nx, int ny)
     return 1;
 }
 
+// strip height of the fused two-iteration kernel: it loads rows + 3 rows per strip, so taller strips
+// pay; the marching chain is rows + 3 steps, so tiny levels still want short ones.
+static int tvl1_pick_rows2(const ofx_ctx *ctx, int nx, int ny)
+{
+    if (ctx->rows_per_wave2 > 0) return ctx->rows_per_wave2;
+    const int strips = ofx_cdiv(nx, STRIP2_OUT);
+    if ((long) strips * ofx_cdiv(ny, 16) >= 4096) return 16;
+    if ((long) strips * ofx_cdiv(ny, 8) >= 2048) return 8;
+    if ((long) strips * ofx_cdiv(ny, 4) >= 1024) return 4;
+    return 2;
+}
+
 static int tvl1_pick_chunk(const ofx_ctx *ctx, int nx, int ny)
 {
     if (ctx->chunk > 0) return ctx->chunk;
@@ -287,10 +440,15 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
 {
     const int nx = L.nx, ny = L.ny;
     const double l_t = P.lambda * P.theta, taut = P.tau / P.theta, theta = P.theta;
+    const bool pairs = ctx->fuse2 != 0;
+    // geometry of the one-iteration kernel (also used for a trailing single iteration and the redo)
     const int rows = tvl1_pick_rows(ctx, nx, ny);
     const int strips_x = ofx_cdiv(nx, STRIP_OUT), strips_pad = ofx_cdiv(strips_x, 4) * 4;
-    const int bands = ofx_cdiv(ny, rows);
-    const dim3 grid((unsigned) (strips_pad / 4) * bands), block(256);
+    const dim3 grid((unsigned) (strips_pad / 4) * ofx_cdiv(ny, rows)), block(256);
+    // geometry of the fused two-iteration kernel
+    const int rows2 = tvl1_pick_rows2(ctx, nx, ny);
+    const int strips2_x = ofx_cdiv(nx, STRIP2_OUT), strips2_pad = ofx_cdiv(strips2_x, 4) * 4;
+    const dim3 grid2((unsigned) (strips2_pad / 4) * ofx_cdiv(ny, rows2));
     LoopSpec S;
     S.max_iter = P.max_iter;
     S.size = nx * ny;
@@ -298,17 +456,31 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
     S.crit = OFX_CRIT_MEAN;
     S.chunk = tvl1_pick_chunk(ctx, nx, ny);
     S.fixed = P.fixed;
+    S.pairs = pairs;
     const int base = L.cur;
-    auto launch = [&](int k, double thr) -> int {
-        const int in = (base + k) & 1, out = in ^ 1;
+    // launch unit u (a pair, or a single iteration) reads half (base + u) & 1 and writes the other one
+    auto single = [&](int unit, int check, int slot, double thr) -> int {
+        const int in = (base + unit) & 1, out = in ^ 1;
         hipLaunchKernelGGL(k_tvl1_iter<T>, grid, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out], L.P2[in],
-                           L.P2[out], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows, strips_x, strips_pad, l_t, theta,
-                           taut, thr);
+                           L.P2[out], L.A, (const T *) L.R, ctx->d_err, check, slot, nx, ny, rows, strips_x, strips_pad,
+                           l_t, theta, taut, thr);
         OFX_LAUNCH_CHECK(ctx);
         return OFX_OK;
     };
-    OFX_TRY(ofx_run_loop(ctx, S, launch, n_out, err_out, ms_out));
-    L.cur = (base + *n_out) & 1;
+    auto launch = [&](int k, int cnt, double thr) -> int {
+        if (cnt == 1) return single(pairs ? k / 2 : k, k, k, thr);
+        const int in = (base + k / 2) & 1, out = in ^ 1;
+        hipLaunchKernelGGL(k_tvl1_iter2<T>, grid2, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out],
+                           L.P2[in], L.P2[out], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
+                           strips2_pad, l_t, theta, taut, thr);
+        OFX_LAUNCH_CHECK(ctx);
+        return OFX_OK;
+    };
+    // the loop ended on the first iteration of a pair: recompute that iteration alone (no stopping
+    // test, error into the scratch slot) from the pair's input half, overwriting the pair's output
+    auto redo = [&](int k) -> int { return single(k / 2, 0, S.max_iter, -1.0); };
+    OFX_TRY(ofx_run_loop(ctx, S, launch, redo, n_out, err_out, ms_out));
+    L.cur = (base + (pairs ? (*n_out + 1) / 2 : *n_out)) & 1;
     return OFX_OK;
 }
 
