@@ -65,6 +65,8 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->fuse2 = 1;             // two TV-L1 iterations per launch
     ctx->chunk = 0;             // 0 = pick per level
     ctx->fixed_work = 0;
+    ctx->sor_exact = 1;
+    ctx->sor_batch = 0;
     ctx->poll_seq = 0;
     ctx->errmsg[0] = 0;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
@@ -126,6 +128,12 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "rows_per_wave2")) {
         if (value < 0 || value > 4096) return ofx_fail(ctx, OFX_ERR_ARG, "rows_per_wave2 out of range");
         ctx->rows_per_wave2 = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "sor_exact")) { ctx->sor_exact = value != 0; return OFX_OK; }
+    if (!strcmp(name, "sor_batch")) {
+        if (value < 0 || value > 4096) return ofx_fail(ctx, OFX_ERR_ARG, "sor_batch out of range");
+        ctx->sor_batch = (int) value;
         return OFX_OK;
     }
     if (!strcmp(name, "fuse2")) { ctx->fuse2 = value != 0; return OFX_OK; }

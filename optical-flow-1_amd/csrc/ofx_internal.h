@@ -57,6 +57,8 @@ struct ofx_ctx {
     int fuse2;
     int chunk;
     int fixed_work;
+    int sor_exact;      // 1: reference sweep order (hyperplane-pipelined), 0: colour order (fast)
+    int sor_batch;      // sweeps in flight per batch in exact mode (0 = 64)
     unsigned long long poll_seq;
 
     ofx_stats stats;

@@ -83,7 +83,43 @@ __global__ void k_hs_warp(const typename Pix<T>::v4 *__restrict__ pack, const T 
     stn(Dif + p, dif);
 }
 
-// One colour of one SOR sweep, src/horn_schunck_pyramidal.cpp:31-71 at every pixel of the colour.
+// SOR update of one pixel, src/horn_schunck_pyramidal.cpp:31-71.  Neighbour indices are the clamped
+// coordinates -- exactly what the reference's replicated border indices are (:161-228) -- in the order
+// up-left, up-right, bottom-left, bottom-right / up, left, bottom, right, with ONE quirk kept for
+// bit-exactness: the bottom-right corner lists its diagonal taps bottom pair first (:222-228).
+// Returns the squared update (:70).
+template <typename T>
+OFX_DEV double hs_point(typename Pix<T>::v2 *__restrict__ U, const typename Pix<T>::v2 *__restrict__ A,
+                        const T *__restrict__ Dif, int i, int j, int nx, int ny, double alpha2)
+{
+    const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+    const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+    const size_t p = (size_t) i * nx + j;
+    double2 p1 = ldw2(U + (size_t) iu * nx + jl), p2 = ldw2(U + (size_t) iu * nx + jr);
+    double2 p3 = ldw2(U + (size_t) id * nx + jl), p4 = ldw2(U + (size_t) id * nx + jr);
+    if (i == ny - 1 && j == nx - 1) {
+        const double2 a1 = p1, a2 = p2;
+        p1 = p3; p2 = p4; p3 = a1; p4 = a2;
+    }
+    const double2 p5 = ldw2(U + (size_t) iu * nx + j), p6 = ldw2(U + (size_t) i * nx + jl);
+    const double2 p7 = ldw2(U + (size_t) id * nx + j), p8 = ldw2(U + (size_t) i * nx + jr);
+    const double2 c = ldw2(U + p);
+    const double2 a = ldw2(A + p);
+    const double dif = ldw(Dif + p);
+    const double w = HS_SOR_W;
+    const double Au = dif * a.x, Av = dif * a.y;                              // :133-134
+    const double Du = a.x * a.x + alpha2, Dv = a.y * a.y + alpha2;            // :135-136
+    const double D = a.x * a.y;                                               // :137
+    const double ula = 1. / 12. * (p1.x + p2.x + p3.x + p4.x) + 1. / 6. * (p5.x + p6.x + p7.x + p8.x);
+    const double vla = 1. / 12. * (p1.y + p2.y + p3.y + p4.y) + 1. / 6. * (p5.y + p6.y + p7.y + p8.y);
+    const double uk = c.x, vk = c.y;
+    const double un = rnd_to<T>((1.0 - w) * uk + w * (Au - D * vk + alpha2 * ula) / Du);   // :66
+    const double vn = rnd_to<T>((1.0 - w) * vk + w * (Av - D * un + alpha2 * vla) / Dv);   // :67
+    stn2(U + p, make_double2(un, vn));
+    return (un - uk) * (un - uk) + (vn - vk) * (vn - vk);                     // :70
+}
+
+// One colour of one SOR sweep (fast, order-changing mode).
 template <typename T>
 __global__ __launch_bounds__(256) void k_hs_sor(typename Pix<T>::v2 *__restrict__ U,
                                                 const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif,
@@ -97,37 +133,121 @@ __global__ __launch_bounds__(256) void k_hs_sor(typename Pix<T>::v2 *__restrict_
     const int gw = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.y;
     if (!loop_continues(prev, k, nx * ny, tol, OFX_CRIT_SQRT_MEAN)) return;
     double e = 0.0;
-    if (in) {
-        const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
-        const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
-        const size_t p = (size_t) i * nx + j;
-        const double2 p1 = ldw2(U + (size_t) iu * nx + jl), p2 = ldw2(U + (size_t) iu * nx + jr);
-        const double2 p3 = ldw2(U + (size_t) id * nx + jl), p4 = ldw2(U + (size_t) id * nx + jr);
-        const double2 p5 = ldw2(U + (size_t) iu * nx + j), p6 = ldw2(U + (size_t) i * nx + jl);
-        const double2 p7 = ldw2(U + (size_t) id * nx + j), p8 = ldw2(U + (size_t) i * nx + jr);
-        const double2 c = ldw2(U + p);
-        const double2 a = ldw2(A + p);
-        const double dif = ldw(Dif + p);
-        const double w = HS_SOR_W;
-        const double Au = dif * a.x, Av = dif * a.y;                              // :133-134
-        const double Du = a.x * a.x + alpha2, Dv = a.y * a.y + alpha2;            // :135-136
-        const double D = a.x * a.y;                                               // :137
-        const double ula = 1. / 12. * (p1.x + p2.x + p3.x + p4.x) + 1. / 6. * (p5.x + p6.x + p7.x + p8.x);
-        const double vla = 1. / 12. * (p1.y + p2.y + p3.y + p4.y) + 1. / 6. * (p5.y + p6.y + p7.y + p8.y);
-        const double uk = c.x, vk = c.y;
-        const double un = rnd_to<T>((1.0 - w) * uk + w * (Au - D * vk + alpha2 * ula) / Du);   // :66
-        const double vn = rnd_to<T>((1.0 - w) * vk + w * (Av - D * un + alpha2 * vla) / Dv);   // :67
-        stn2(U + p, make_double2(un, vn));
-        e = (un - uk) * (un - uk) + (vn - vk) * (vn - vk);                        // :70
-    }
+    if (in) e = hs_point<T>(U, A, Dif, i, j, nx, ny, alpha2);
     loop_accumulate(err, k, e, gw);
+}
+
+// ---- exact mode: the reference's sequential sweep order, pipelined over hyperplanes --------------------
+// Pixel X of sweep s runs at time t = pos(X) + C s.  pos() is the pixel's rank in a time-skewed version of
+// the reference's visiting order (interior rows lexicographic -> first/last row -> first/last column ->
+// corners, horn_schunck_pyramidal.cpp:148-228) and C the spacing between consecutive sweeps, chosen so
+// that for every two NEIGHBOURING pixels X before Y in that order   t(X,s) < t(Y,s) < t(X,s+1).
+// Then (a) all pixels of one time step are mutually independent, (b) the in-place array holds, at the
+// moment X of sweep s runs, exactly the versions the sequential sweep would read (Y of sweep s if Y comes
+// earlier, of sweep s-1 if later).  One launch = one time step, all sweeps of the batch that are inside
+// the image at that time (blockIdx.y = sweep).  HS (8 neighbours): pos = 2i + j in the interior, C = 6.
+// The same schedule is executed on the CPU by oracle order 2 and is bit-identical to the reference's
+// sequential sweeps (tests/test_oracle_golden.py::test_hyperplane_schedule_is_exact).
+#define HS_PLANE_C 6
+OFX_DEV bool hs_plane_item(int r, int q, int nx, int ny, int corner, int &i, int &j)
+{
+    if (r >= 1 && r <= ny - 2) { i = r; j = q - 2 * r; return j >= 1 && j <= nx - 2; }          // interior
+    if (r == 0) { i = 0; j = q - 4; return j >= 1 && j <= nx - 2; }                               // first row
+    if (r == ny - 1) { i = ny - 1; j = q - 2 * (ny - 1); return j >= 1 && j <= nx - 2; }         // last row
+    if (r == ny) { const int d = q - 4; i = d >> 1; j = 0; return !(d & 1) && i >= 1 && i <= ny - 2; }             // first column
+    if (r == ny + 1) { const int d = q - nx - 1; i = d >> 1; j = nx - 1; return !(d & 1) && i >= 1 && i <= ny - 2; }  // last column
+    if (r == ny + 2) {                                                                            // corners
+        if (corner == 0) { i = 0; j = 0; return q == 7; }
+        if (corner == 1) { i = 0; j = nx - 1; return q == nx + 4; }
+        if (corner == 2) { i = ny - 1; j = 0; return q == 2 * ny + 1; }
+        i = ny - 1; j = nx - 1; return q == 2 * ny + nx - 2;
+    }
+    return false;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_hs_plane(typename Pix<T>::v2 *__restrict__ U,
+                                                 const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif,
+                                                 double *__restrict__ err, int t, int s_lo, int nx, int ny, double alpha2)
+{
+    const int s = s_lo + blockIdx.y;
+    const int q = t - HS_PLANE_C * s;
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    double e = 0.0;
+    int i, j;
+    if (r == ny + 2) {
+        for (int corner = 0; corner < 4; corner++)
+            if (hs_plane_item(r, q, nx, ny, corner, i, j)) e += hs_point<T>(U, A, Dif, i, j, nx, ny, alpha2);
+    } else if (hs_plane_item(r, q, nx, ny, 0, i, j)) {
+        e = hs_point<T>(U, A, Dif, i, j, nx, ny, alpha2);
+    }
+    loop_accumulate(err, s, e, blockIdx.x);
+}
+
+// Exact SOR loop:  while (error > TOL && n < maxiter) sweep.   Sweeps run in batches of up to `batch`
+// pipelined sweeps (launch_plane(t, s_lo, s_cnt) = one time step).  The per-sweep errors of a batch are
+// only known when it has drained, so a batch that ran past the stopping sweep is rolled back to its
+// checkpoint (a copy of the unknowns taken before the batch) and re-run with exactly the sweeps that
+// count.  qmax = largest pos() of the image, C = sweep spacing.
+template <class PlaneFn, class SaveFn, class RestoreFn>
+static int sor_exact_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int qmax, int C, PlaneFn launch_plane,
+                          SaveFn save, RestoreFn restore, int *n_out, double *err_out)
+{
+    int niter = 0;
+    double error = 1000;
+    const int batch = ctx->sor_batch > 0 ? ctx->sor_batch : 64;
+    OFX_TRY(ofx_loop_reserve(ctx, batch + 1));
+    LoopSpec LS;
+    LS.size = size;
+    LS.thr = TOL;
+    LS.crit = OFX_CRIT_SQRT_MEAN;
+    LS.chunk = 0;
+    LS.fixed = false;
+    LS.pairs = false;
+    auto run_batch = [&](int ns, OfxIterState *out) -> int {
+        OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) ns * OFX_NSHARD, ctx->stream));
+        OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
+        const int tmax = qmax + C * (ns - 1);
+        for (int t = 0; t <= tmax; t++) {
+            int s_lo = (t - qmax + C - 1) / C;                 // smallest s with t - C s <= qmax
+            if (t - qmax < 0) s_lo = 0;
+            int s_hi = t / C;
+            if (s_hi > ns - 1) s_hi = ns - 1;
+            if (s_hi < s_lo) continue;
+            OFX_TRY(launch_plane(t, s_lo, s_hi - s_lo + 1));
+        }
+        LS.max_iter = ns;
+        const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
+        OFX_TRY(ofx_loop_finalize(ctx, LS, 0, ns, &ctx->h_state[slot]));
+        OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
+        OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
+        *out = ctx->h_state[slot];
+        return OFX_OK;
+    };
+    while (error > TOL && niter < maxiter) {
+        const int b = (maxiter - niter < batch) ? maxiter - niter : batch;
+        OFX_TRY(save());
+        OfxIterState st;
+        OFX_TRY(run_batch(b, &st));
+        if (st.n < b) {                                        // stopped inside the batch: redo exactly st.n sweeps
+            const int used = st.n;
+            OFX_TRY(restore());
+            OFX_TRY(run_batch(used, &st));
+            st.n = used;
+        }
+        niter += st.n;
+        error = st.error;
+    }
+    *n_out = niter;
+    *err_out = error;
+    return OFX_OK;
 }
 
 template <typename T> struct HsLevel {
     int nx, ny;
     T *I1, *I2;
     typename Pix<T>::v4 *pack;
-    typename Pix<T>::v2 *U, *A;
+    typename Pix<T>::v2 *U, *A, *Uck;
     T *Dif;
 };
 
@@ -138,6 +258,7 @@ template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int
     L.ny = ny;
     OFX_TRY(ofx_alloc(ctx, n, &L.pack));
     OFX_TRY(ofx_alloc(ctx, n, &L.U));
+    OFX_TRY(ofx_alloc(ctx, n, &L.Uck));
     OFX_TRY(ofx_alloc(ctx, n, &L.A));
     OFX_TRY(ofx_alloc(ctx, n, &L.Dif));
     return OFX_OK;
@@ -167,7 +288,26 @@ template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L
         int niter = 0;
         double error = 1000;                                                                  // :140
         float ms = 0.f;
-        if (P.maxiter > 0 && error > P.TOL) {
+        if (ctx->sor_exact && nx >= 3 && ny >= 3) {
+            const size_t ub = (size_t) nx * ny * sizeof(typename Pix<T>::v2);
+            const dim3 gp(ofx_cdiv(ny + 3, 64), 1), bp(64);
+            auto plane = [&](int t, int s_lo, int s_cnt) -> int {
+                hipLaunchKernelGGL(k_hs_plane<T>, dim3(gp.x, s_cnt), bp, 0, ctx->stream, L.U, L.A, (const T *) L.Dif,
+                                   ctx->d_err, t, s_lo, nx, ny, alpha2);
+                OFX_LAUNCH_CHECK(ctx);
+                return OFX_OK;
+            };
+            auto save = [&]() -> int {
+                OFX_HIP(ctx, hipMemcpyAsync(L.Uck, L.U, ub, hipMemcpyDeviceToDevice, ctx->stream));
+                return OFX_OK;
+            };
+            auto restore = [&]() -> int {
+                OFX_HIP(ctx, hipMemcpyAsync(L.U, L.Uck, ub, hipMemcpyDeviceToDevice, ctx->stream));
+                return OFX_OK;
+            };
+            OFX_TRY(sor_exact_loop(ctx, nx * ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, plane, save, restore,
+                                   &niter, &error));
+        } else if (P.maxiter > 0 && error > P.TOL) {
             LoopSpec LS;
             LS.max_iter = P.maxiter;
             LS.size = nx * ny;
@@ -521,7 +661,30 @@ __global__ void k_brox_coeff(const T *__restrict__ I1, const typename Pix<T>::v2
     stn(Dm + i, Duv);
 }
 
-// one colour of one SOR sweep, :129-172 at every pixel with (i + j) % 2 == colour
+// SOR update of one pixel, src/brox_optic_flow_spatial.cpp:129-172; returns the squared update (:166)
+template <typename T>
+OFX_DEV double brox_point(typename Pix<T>::v2 *__restrict__ DU, const typename Pix<T>::v4 *__restrict__ CO,
+                          const T *__restrict__ Dm, const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha)
+{
+    const size_t p = (size_t) i * nx + j;
+    const Psi4 s = brox_psi4(Psis, i, j, nx, ny);
+    // a missing neighbour is addressed as the pixel itself (offset 0) with psi = 0, :332-388
+    const double2 c = ldw2(DU + p);
+    const double2 dn = (i < ny - 1) ? ldw2(DU + p + nx) : c, up = (i > 0) ? ldw2(DU + p - nx) : c;
+    const double2 rt = (j < nx - 1) ? ldw2(DU + p + 1) : c, lf = (j > 0) ? ldw2(DU + p - 1) : c;
+    const double4 co = ldw4(CO + p);
+    const double D = ldw(Dm + p);
+    const double w = BROX_SOR_W;
+    const double div_du = s.p1 * dn.x + s.p2 * up.x + s.p3 * rt.x + s.p4 * lf.x;      // :153-154
+    const double div_dv = s.p1 * dn.y + s.p2 * up.y + s.p3 * rt.y + s.p4 * lf.y;      // :155-156
+    const double duk = c.x, dvk = c.y;
+    const double dun = rnd_to<T>((1. - w) * duk + w * (co.x - D * dvk + alpha * div_du) / co.z);   // :162
+    const double dvn = rnd_to<T>((1. - w) * dvk + w * (co.y - D * dun + alpha * div_dv) / co.w);   // :163
+    stn2(DU + p, make_double2(dun, dvn));
+    return (dun - duk) * (dun - duk) + (dvn - dvk) * (dvn - dvk);                     // :166
+}
+
+// one colour of one SOR sweep (fast, order-changing mode): every pixel with (i + j) % 2 == colour
 template <typename T>
 __global__ __launch_bounds__(256) void k_brox_sor(typename Pix<T>::v2 *__restrict__ DU,
                                                   const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
@@ -535,25 +698,47 @@ __global__ __launch_bounds__(256) void k_brox_sor(typename Pix<T>::v2 *__restric
     const int gw = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.y;
     if (!loop_continues(prev, k, nx * ny, tol, OFX_CRIT_SQRT_MEAN)) return;
     double e = 0.0;
-    if (in) {
-        const size_t p = (size_t) i * nx + j;
-        const Psi4 s = brox_psi4(Psis, i, j, nx, ny);
-        // a missing neighbour is addressed as the pixel itself (offset 0) with psi = 0, :332-388
-        const double2 c = ldw2(DU + p);
-        const double2 dn = (i < ny - 1) ? ldw2(DU + p + nx) : c, up = (i > 0) ? ldw2(DU + p - nx) : c;
-        const double2 rt = (j < nx - 1) ? ldw2(DU + p + 1) : c, lf = (j > 0) ? ldw2(DU + p - 1) : c;
-        const double4 co = ldw4(CO + p);
-        const double D = ldw(Dm + p);
-        const double w = BROX_SOR_W;
-        const double div_du = s.p1 * dn.x + s.p2 * up.x + s.p3 * rt.x + s.p4 * lf.x;      // :153-154
-        const double div_dv = s.p1 * dn.y + s.p2 * up.y + s.p3 * rt.y + s.p4 * lf.y;      // :155-156
-        const double duk = c.x, dvk = c.y;
-        const double dun = rnd_to<T>((1. - w) * duk + w * (co.x - D * dvk + alpha * div_du) / co.z);   // :162
-        const double dvn = rnd_to<T>((1. - w) * dvk + w * (co.y - D * dun + alpha * div_dv) / co.w);   // :163
-        stn2(DU + p, make_double2(dun, dvn));
-        e = (dun - duk) * (dun - duk) + (dvn - dvk) * (dvn - dvk);                        // :166
-    }
+    if (in) e = brox_point<T>(DU, CO, Dm, Psis, i, j, nx, ny, alpha);
     loop_accumulate(err, k, e, gw);
+}
+
+// exact mode (see k_hs_plane): 5-point stencil -> pos = i + j in the interior, C = 2
+// (visiting order brox_optic_flow_spatial.cpp:320-387)
+#define BROX_PLANE_C 2
+OFX_DEV bool brox_plane_item(int r, int q, int nx, int ny, int corner, int &i, int &j)
+{
+    if (r >= 1 && r <= ny - 2) { i = r; j = q - r; return j >= 1 && j <= nx - 2; }
+    if (r == 0) { i = 0; j = q - 2; return j >= 1 && j <= nx - 2; }
+    if (r == ny - 1) { i = ny - 1; j = q - (ny - 1); return j >= 1 && j <= nx - 2; }
+    if (r == ny) { i = q - 2; j = 0; return i >= 1 && i <= ny - 2; }
+    if (r == ny + 1) { i = q - (nx - 1); j = nx - 1; return i >= 1 && i <= ny - 2; }
+    if (r == ny + 2) {
+        if (corner == 0) { i = 0; j = 0; return q == 4; }
+        if (corner == 1) { i = 0; j = nx - 1; return q == nx + 1; }
+        if (corner == 2) { i = ny - 1; j = 0; return q == ny + 1; }
+        i = ny - 1; j = nx - 1; return q == ny + nx - 2;
+    }
+    return false;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_brox_plane(typename Pix<T>::v2 *__restrict__ DU,
+                                                   const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
+                                                   const T *__restrict__ Psis, double *__restrict__ err, int t, int s_lo,
+                                                   int nx, int ny, double alpha)
+{
+    const int s = s_lo + blockIdx.y;
+    const int q = t - BROX_PLANE_C * s;
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    double e = 0.0;
+    int i, j;
+    if (r == ny + 2) {
+        for (int corner = 0; corner < 4; corner++)
+            if (brox_plane_item(r, q, nx, ny, corner, i, j)) e += brox_point<T>(DU, CO, Dm, Psis, i, j, nx, ny, alpha);
+    } else if (brox_plane_item(r, q, nx, ny, 0, i, j)) {
+        e = brox_point<T>(DU, CO, Dm, Psis, i, j, nx, ny, alpha);
+    }
+    loop_accumulate(err, s, e, blockIdx.x);
 }
 
 // u += du, v += dv, :398-401
@@ -571,7 +756,7 @@ template <typename T> struct BroxLevel {
     using v4 = typename Pix<T>::v4;
     int nx, ny;
     T *I1, *I2, *Psis, *Dd, *Dm;
-    v2 *G1, *PB, *WB, *U, *DV, *DU;
+    v2 *G1, *PB, *WB, *U, *DV, *DU, *DUck;
     v4 *PA, *WA, *CO;
 };
 
@@ -589,6 +774,7 @@ template <typename T> static int brox_level_alloc(ofx_ctx *ctx, BroxLevel<T> &L,
     OFX_TRY(ofx_alloc(ctx, n, &L.U));
     OFX_TRY(ofx_alloc(ctx, n, &L.DV));
     OFX_TRY(ofx_alloc(ctx, n, &L.DU));
+    OFX_TRY(ofx_alloc(ctx, n, &L.DUck));
     OFX_TRY(ofx_alloc(ctx, n, &L.PA));
     OFX_TRY(ofx_alloc(ctx, n, &L.WA));
     OFX_TRY(ofx_alloc(ctx, n, &L.CO));
@@ -623,7 +809,26 @@ template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T
             int nsor = 0;
             double error = 1000;                                                                  // :312
             float ms = 0.f;
-            if (error > P.TOL) {
+            if (ctx->sor_exact && nx >= 3 && ny >= 3) {
+                const size_t ub = (size_t) n * sizeof(typename Pix<T>::v2);
+                const unsigned gpx = ofx_cdiv(ny + 3, 64);
+                auto plane = [&](int t, int s_lo, int s_cnt) -> int {
+                    hipLaunchKernelGGL(k_brox_plane<T>, dim3(gpx, s_cnt), dim3(64), 0, ctx->stream, L.DU, L.CO,
+                                       (const T *) L.Dm, (const T *) L.Psis, ctx->d_err, t, s_lo, nx, ny, P.alpha);
+                    OFX_LAUNCH_CHECK(ctx);
+                    return OFX_OK;
+                };
+                auto save = [&]() -> int {
+                    OFX_HIP(ctx, hipMemcpyAsync(L.DUck, L.DU, ub, hipMemcpyDeviceToDevice, ctx->stream));
+                    return OFX_OK;
+                };
+                auto restore = [&]() -> int {
+                    OFX_HIP(ctx, hipMemcpyAsync(L.DU, L.DUck, ub, hipMemcpyDeviceToDevice, ctx->stream));
+                    return OFX_OK;
+                };
+                OFX_TRY(sor_exact_loop(ctx, n, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, plane, save,
+                                       restore, &nsor, &error));
+            } else if (error > P.TOL) {
                 LoopSpec LS;
                 LS.max_iter = OFX_BROX_MAX_ITERATIONS;
                 LS.size = n;

@@ -602,6 +602,23 @@ static inline double hs_sor_point(const double *Au, const double *Av, const doub
  * the reference's racy `omp parallel for`, deterministic with one thread), then first/last row
  * interleaved per column, first/last column interleaved per row, then the four corners.  Border
  * pixels replace missing neighbours by replicated indices exactly as :161-228 pass them. */
+/* The reference's replicated border indices are exactly the clamped neighbour coordinates, in the
+ * order up-left, up-right, bottom-left, bottom-right / up, left, bottom, right -- with ONE exception:
+ * the bottom-right corner passes its four diagonal taps as (k-1, k, k-nx-1, k-nx)
+ * (horn_schunck_pyramidal.cpp:222-228), i.e. the bottom pair first.  Same set, different summation
+ * order, so it is kept to stay bit-identical. */
+static inline double hs_point_clamped(const double *Au, const double *Av, const double *Du, const double *Dv,
+                                      const double *D, double *u, double *v, double a2, int i, int j, int nx, int ny)
+{
+    const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+    const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+    if (i == ny - 1 && j == nx - 1)
+        return hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, i * nx + j, id * nx + jl, id * nx + jr, iu * nx + jl,
+                            iu * nx + jr, iu * nx + j, i * nx + jl, id * nx + j, i * nx + jr);
+    return hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, i * nx + j, iu * nx + jl, iu * nx + jr, id * nx + jl,
+                        id * nx + jr, iu * nx + j, i * nx + jl, id * nx + j, i * nx + jr);
+}
+
 /* Checker aid (NOT reference behaviour): sweep order used by the GPU kernels.  0 = the reference's
  * lexicographic order (default); 1 = multi-colour order -- Horn-Schunck: 4 colours (i%2, j%2) in the
  * order (0,0) (0,1) (1,0) (1,1); Brox: red-black, (i+j)%2 == 0 first -- every pixel (borders included)
@@ -618,20 +635,92 @@ static double hs_sweep_coloured(const double *Au, const double *Av, const double
     for (int col = 0; col < 4; col++) {
         const int ci = col >> 1, cj = col & 1;
         for (int i = ci; i < ny; i += 2)
-            for (int j = cj; j < nx; j += 2) {
-                const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
-                const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
-                error += hs_sor_point(Au, Av, Du, Dv, D, u, v, a2, i * nx + j, iu * nx + jl, iu * nx + jr,
-                                      id * nx + jl, id * nx + jr, iu * nx + j, i * nx + jl, id * nx + j, i * nx + jr);
-            }
+            for (int j = cj; j < nx; j += 2)
+                error += hs_point_clamped(Au, Av, Du, Dv, D, u, v, a2, i, j, nx, ny);
     }
     return error;
 }
 
+/* Checker aid, order 2: the HIP path's EXACT schedule.  Pixel X of sweep s runs at time
+ * T = pos(X) + C*s; everything with the same T runs "at once" (here: in arbitrary order).  pos/C are
+ * chosen so that for every pair of neighbouring pixels X before Y in the reference's sweep order
+ * T(X,s) < T(Y,s) < T(X,s+1): each pixel then reads exactly the versions the sequential sweep reads,
+ * although up to `nsweeps` sweeps are in flight.  Derivation: DESIGN.md 5.3. */
+static int hs_pos(int i, int j, int nx, int ny)
+{
+    const int top = (i == 0), bot = (i == ny - 1), lef = (j == 0), rig = (j == nx - 1);
+    if (!top && !bot && !lef && !rig) return 2 * i + j;      /* interior, lexicographic */
+    if (top && !lef && !rig) return j + 4;                    /* first row, after the interior */
+    if (bot && !lef && !rig) return 2 * (ny - 1) + j;         /* last row */
+    if (lef && !top && !bot) return 2 * i + 4;                /* first column, after the rows */
+    if (rig && !top && !bot) return 2 * i + nx + 1;           /* last column */
+    if (top && lef) return 7;                                 /* corners last */
+    if (top && rig) return nx + 4;
+    if (bot && lef) return 2 * ny + 1;
+    return 2 * ny + nx - 2;
+}
+#define HS_PLANE_C 6
+
+static int brox_pos(int i, int j, int nx, int ny)
+{
+    const int top = (i == 0), bot = (i == ny - 1), lef = (j == 0), rig = (j == nx - 1);
+    if (!top && !bot && !lef && !rig) return i + j;
+    if (top && !lef && !rig) return j + 2;
+    if (bot && !lef && !rig) return ny - 1 + j;
+    if (lef && !top && !bot) return i + 2;
+    if (rig && !top && !bot) return i + nx - 1;
+    if (top && lef) return 4;
+    if (top && rig) return nx + 1;
+    if (bot && lef) return ny + 1;
+    return ny + nx - 2;
+}
+#define BROX_PLANE_C 2
+
+/* pixels bucketed by pos: start[p] .. start[p+1] index into `order` */
+typedef struct { int npos; int *start; int *order; } plane_index;
+
+static void plane_index_build(plane_index *P, int nx, int ny, int (*pos)(int, int, int, int))
+{
+    int maxp = 0;
+    for (int i = 0; i < ny; i++) for (int j = 0; j < nx; j++) { int q = pos(i, j, nx, ny); if (q > maxp) maxp = q; }
+    P->npos = maxp + 1;
+    P->start = (int *) calloc((size_t) P->npos + 1, sizeof(int));
+    P->order = (int *) malloc(sizeof(int) * (size_t) nx * ny);
+    for (int i = 0; i < ny; i++) for (int j = 0; j < nx; j++) P->start[pos(i, j, nx, ny) + 1]++;
+    for (int q = 0; q < P->npos; q++) P->start[q + 1] += P->start[q];
+    int *fill = (int *) malloc(sizeof(int) * (size_t) P->npos);
+    memcpy(fill, P->start, sizeof(int) * (size_t) P->npos);
+    for (int i = 0; i < ny; i++) for (int j = 0; j < nx; j++) P->order[fill[pos(i, j, nx, ny)]++] = i * nx + j;
+    free(fill);
+}
+
+static void plane_index_free(plane_index *P) { free(P->start); free(P->order); }
+
+/* runs sweeps [0, nsweeps) pipelined; errs[s] = sum of squared updates of sweep s */
+static void hs_sweeps_planes(const plane_index *P, const double *Au, const double *Av, const double *Du,
+                             const double *Dv, const double *D, double *u, double *v, double a2, int nx, int ny,
+                             int nsweeps, double *errs)
+{
+    for (int s = 0; s < nsweeps; s++) errs[s] = 0;
+    const int tmax = P->npos - 1 + HS_PLANE_C * (nsweeps - 1);
+    for (int t = 0; t <= tmax; t++)
+        for (int s = 0; s < nsweeps; s++) {
+            const int q = t - HS_PLANE_C * s;
+            if (q < 0 || q >= P->npos) continue;
+            for (int e = P->start[q]; e < P->start[q + 1]; e++) {
+                const int k = P->order[e];
+                errs[s] += hs_point_clamped(Au, Av, Du, Dv, D, u, v, a2, k / nx, k % nx, nx, ny);
+            }
+        }
+}
+
+static int g_plane_batch = 64;      /* sweeps in flight per batch, like the HIP path */
+void orc_set_plane_batch(int b) { if (b > 0) g_plane_batch = b; }
+
 static double hs_sweep(const double *Au, const double *Av, const double *Du, const double *Dv,
                        const double *D, double *u, double *v, double a2, int nx, int ny)
 {
-    if (g_sor_order) return hs_sweep_coloured(Au, Av, Du, Dv, D, u, v, a2, nx, ny);
+    if (g_sor_order == 1) return hs_sweep_coloured(Au, Av, Du, Dv, D, u, v, a2, nx, ny);
     double error = 0;
     #pragma omp parallel for reduction(+:error)
     for (int i = 1; i < ny - 1; i++)
@@ -697,6 +786,30 @@ void orc_hs_single_scale(const double *I1, const double *I2, double *u, double *
         }
         int niter = 0;
         double error = 1000;
+        if (g_sor_order == 2 && nx >= 3 && ny >= 3) {
+            /* batches of pipelined sweeps; a batch that runs past the stopping sweep is rolled back to
+             * its checkpoint and re-run with exactly the sweeps that count */
+            plane_index PI;
+            plane_index_build(&PI, nx, ny, hs_pos);
+            double *cu = dalloc(n), *cv = dalloc(n), *errs = dalloc((size_t) g_plane_batch);
+            while (error > TOL && niter < maxiter) {
+                const int b = (maxiter - niter < g_plane_batch) ? maxiter - niter : g_plane_batch;
+                memcpy(cu, u, n * sizeof(double));
+                memcpy(cv, v, n * sizeof(double));
+                hs_sweeps_planes(&PI, Au, Av, Du, Dv, D, u, v, alpha2, nx, ny, b, errs);
+                int used = b;
+                for (int q = 0; q < b; q++) { error = sqrt(errs[q] / size); if (!(error > TOL)) { used = q + 1; break; } }
+                if (used < b) {
+                    memcpy(u, cu, n * sizeof(double));
+                    memcpy(v, cv, n * sizeof(double));
+                    hs_sweeps_planes(&PI, Au, Av, Du, Dv, D, u, v, alpha2, nx, ny, used, errs);
+                    error = sqrt(errs[used - 1] / size);
+                }
+                niter += used;
+            }
+            free(cu); free(cv); free(errs);
+            plane_index_free(&PI);
+        } else
         while (error > TOL && niter < maxiter) {                       /* :143 */
             niter++;
             error = hs_sweep(Au, Av, Du, Dv, D, u, v, alpha2, nx, ny);
@@ -884,10 +997,45 @@ static void brox_single_scale(const double *I1, const double *I2, double *u, dou
 
             double error = 1000;
             int nsor = 0;
+            if (g_sor_order == 2 && nx >= 3 && ny >= 3) {
+                plane_index PI;
+                plane_index_build(&PI, nx, ny, brox_pos);
+                double *cu = dalloc(n), *cv = dalloc(n), *errs = dalloc((size_t) g_plane_batch);
+                while (error > TOL && nsor < BROX_MAXITER) {
+                    const int b = (BROX_MAXITER - nsor < g_plane_batch) ? BROX_MAXITER - nsor : g_plane_batch;
+                    memcpy(cu, du, n * sizeof(double));
+                    memcpy(cv, dv, n * sizeof(double));
+                    int used = b;
+                    for (int pass = 0; pass < 2; pass++) {
+                        const int ns = pass ? used : b;
+                        for (int q = 0; q < ns; q++) errs[q] = 0;
+                        const int tmax = PI.npos - 1 + BROX_PLANE_C * (ns - 1);
+                        for (int t = 0; t <= tmax; t++)
+                            for (int q = 0; q < ns; q++) {
+                                const int pq = t - BROX_PLANE_C * q;
+                                if (pq < 0 || pq >= PI.npos) continue;
+                                for (int e = PI.start[pq]; e < PI.start[pq + 1]; e++) {
+                                    const int k = PI.order[e], i = k / nx, j = k % nx;
+                                    errs[q] += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, i,
+                                                              i > 0 ? nx : 0, i < ny - 1 ? nx : 0, j, nx, j > 0 ? 1 : 0,
+                                                              j < nx - 1 ? 1 : 0);
+                                }
+                            }
+                        if (pass) { error = sqrt(errs[used - 1] / size); break; }
+                        for (int q = 0; q < b; q++) { error = sqrt(errs[q] / size); if (!(error > TOL)) { used = q + 1; break; } }
+                        if (used == b) break;
+                        memcpy(du, cu, n * sizeof(double));
+                        memcpy(dv, cv, n * sizeof(double));
+                    }
+                    nsor += used;
+                }
+                free(cu); free(cv); free(errs);
+                plane_index_free(&PI);
+            } else
             while (error > TOL && nsor < BROX_MAXITER) {       /* :315 */
                 error = 0;
                 nsor++;
-                if (g_sor_order) {          /* checker aid: red-black order of the HIP path */
+                if (g_sor_order == 1) {     /* checker aid: red-black order of the HIP path */
                     for (int col = 0; col < 2; col++)
                         for (int i = 0; i < ny; i++)
                             for (int j = (i + col) & 1; j < nx; j += 2)

@@ -63,8 +63,10 @@ double orc_tvl1_iterations(double *u1, double *u2, double *p11, double *p12, dou
                            const double *grad, int nx, int ny, double tau, double lambda,
                            double theta, int n_iter);
 
-/* checker aid, see ofx_oracle.c: 0 = reference sweep order (default), 1 = the HIP path's colour order */
+/* checker aids, see ofx_oracle.c: 0 = reference sweep order (default), 1 = the HIP path's colour order,
+ * 2 = the HIP path's exact hyperplane-pipelined schedule (bit-identical to 0 by construction) */
 void orc_set_sor_order(int order);
+void orc_set_plane_batch(int sweeps_in_flight);
 
 /* horn_schunck_pyramidal.cpp */
 void orc_hs_single_scale(const double *I1, const double *I2, double *u, double *v, int nx, int ny,

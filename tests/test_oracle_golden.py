@@ -62,3 +62,24 @@ def test_solvers(orc, synth, case):
     assert np.array_equal(u, g["u"]) and np.array_equal(v, g["v"])
     # the reference prints coarse-to-fine; the oracle stores [scale][solve] with scale 0 = finest
     assert list(iters[::-1].ravel()) == list(g["iters"])
+
+
+@pytest.mark.parametrize("batch", [1, 7, 64])
+def test_hyperplane_schedule_is_exact(orc, synth, batch):
+    """oracle order 2 = the HIP path's exact SOR schedule (pixel X of sweep s at time pos(X) + C s, many
+    sweeps in flight, rollback + redo of an overshooting batch) run on the CPU: bit-identical to the
+    reference's sequential sweeps for any batch size."""
+    import ctypes as C
+    fn = orc._fn("set_plane_batch", None, C.c_int)
+    for kind, kw in (("hs", dict(alpha=20.0, nscales=3, warps=4)), ("brox", dict(nscales=3, outer=4))):
+        I0, I1 = synth.pair("P1", 96, 64)
+        run = orc.hs_pyramidal if kind == "hs" else orc.brox_spatial
+        u0, v0, it0 = run(I0, I1, **kw)
+        fn(batch)
+        orc.set_sor_order(2)
+        try:
+            u2, v2, it2 = run(I0, I1, **kw)
+        finally:
+            orc.set_sor_order(0)
+            fn(64)
+        assert np.array_equal(it0, it2) and np.array_equal(u0, u2) and np.array_equal(v0, v2)
