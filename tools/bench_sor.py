@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""BASELINE configs 3 and 4 (parity-test cases): Horn-Schunck 1920x1080 and Brox 1280x720 on the GPU in exact
+and colour-order mode, next to the compiled reference on the host cores.  Prints one JSON line per config."""
+import importlib, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ofx = importlib.import_module("optical-flow-1_amd")
+synth = importlib.import_module("optical-flow-1_amd.synth")
+import oracle
+
+ctx = ofx.Ofx(0, ofx.F64)
+cpu = oracle.Ref() if oracle.have_ref() else oracle.Oracle()
+cores = min(oracle.host_cores(), 32)
+small = "--small" in sys.argv
+
+
+def aepe(a, b):
+    return float(np.mean(np.hypot(a[0] - b[0], a[1] - b[1])))
+
+
+def run(name, gpu_fn, cpu_fn, I1, I2, kw):
+    out = {"config": name, "size": "%dx%d" % (I1.shape[1], I1.shape[0])}
+    res = {}
+    for mode in ("exact", "colour"):
+        ctx.set_option("sor_exact", 1 if mode == "exact" else 0)
+        gpu_fn(I1, I2, **kw)                                   # warm (arena, clocks)
+        t0 = time.perf_counter()
+        res[mode] = gpu_fn(I1, I2, **kw)
+        dt = time.perf_counter() - t0
+        st = ctx.stats()
+        out[mode] = {"seconds": round(dt, 4), "sweeps": int(st.iterations().sum()),
+                     "mpix_sweeps_per_s": round(st.work_pix_iters / dt / 1e6, 1)}
+    ctx.set_option("sor_exact", 1)
+    cpu.set_num_threads(1)
+    t0 = time.perf_counter()
+    ref = cpu_fn(I1, I2, **kw)
+    t1 = time.perf_counter() - t0
+    cpu.set_num_threads(cores)
+    t0 = time.perf_counter()
+    cpu_fn(I1, I2, **kw)
+    tn = time.perf_counter() - t0
+    out["cpu_reference"] = {"kind": cpu.kind, "seconds_1_thread": round(t1, 3), "seconds_%d_threads" % cores: round(tn, 3)}
+    out["exact"]["aepe_vs_reference_1thread"] = aepe(res["exact"], ref)
+    out["exact"]["max_abs_diff"] = float(max(np.abs(res["exact"][0] - ref[0]).max(), np.abs(res["exact"][1] - ref[1]).max()))
+    out["colour"]["aepe_vs_reference_1thread"] = aepe(res["colour"], ref)
+    print(json.dumps(out), flush=True)
+
+
+nx, ny = (640, 360) if small else (1920, 1080)
+I1, I2 = synth.pair("P0", nx, ny)
+run("cfg3 horn_schunck_pyramidal alpha=20 nscales=5 warps=10", ctx.hs_pyramidal, cpu.hs_pyramidal, I1, I2,
+    dict(alpha=20.0, nscales=5, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150))
+nx, ny = (320, 180) if small else (1280, 720)
+I1, I2 = synth.pair("P0", nx, ny)
+run("cfg4 brox_spatial defaults (6 scales)", ctx.brox_spatial, cpu.brox_spatial, I1, I2,
+    dict(alpha=50.0, gamma=10.0, nscales=4 if small else 6, nu=0.5, TOL=1e-4, inner=1, outer=15))
