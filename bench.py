@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--streams", type=int, default=4,
                     help="image pairs in flight per GPU, each on its own context / HIP stream (SURVEY 8e: >= 2)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     return ap.parse_args()
@@ -79,38 +80,45 @@ def cpu_baseline(synth, nx, ny, pair):
     cores = min(oracle.host_cores(), 32)
     cpu.set_num_threads(cores)
     log("cpu_baseline: %s on %d threads (affinity %d)" % (cpu.kind, cores, len(os.sched_getaffinity(0))))
-    I0, I1 = synth.pair(pair, nx, ny, 0)
+    # a bounded sample (~10 s of CPU work): NPAIR batch variants of the bench pair through the multiscale call
+    NPAIR = 4
+    pairs = [synth.pair(pair, nx, ny, k) for k in range(NPAIR)]
     t0 = time.perf_counter()
-    cpu.tvl1_multiscale(I0, I1, **PAR)
+    for I0, I1 in pairs:
+        cpu.tvl1_multiscale(I0, I1, **PAR)
     t_ms = time.perf_counter() - t0
-    log("cpu_baseline: multiscale %.2f s" % t_ms)
+    log("cpu_baseline: %d multiscale calls %.2f s" % (NPAIR, t_ms))
     out = {"unit": "Mpix*warp-iters/s", "cores": cores, "kind": cpu.kind,
-           "sample": "1 pair %s %dx%d, same parameters, one Dual_TVL1_optic_flow_multiscale call (%.2f s)"
-                     % (pair, nx, ny, t_ms), "seconds": round(t_ms, 3), "build": "-O3 -fopenmp, generic x86-64"}
-    # work of that call: iteration counts from the port (bit-identical loop, OMP_NUM_THREADS=1 parity-tested)
+           "sample": "%d pairs %s %dx%d (batch variants 0..%d), same parameters, Dual_TVL1_optic_flow_multiscale (%.2f s)"
+                     % (NPAIR, pair, nx, ny, NPAIR - 1, t_ms), "seconds": round(t_ms, 3),
+           "build": "-O3 -fopenmp, generic x86-64"}
+    # work of those calls: iteration counts from the port (bit-identical loop, OMP_NUM_THREADS=1 parity-tested)
     work = None
     if port is not None:
         port.set_num_threads(cores)
-        _, _, iters, _ = port.tvl1_multiscale(I0, I1, **PAR)
         sizes = [(nx, ny)]
         for _ in range(1, PAR["nscales"]):
             sizes.append(cpu.zoom_size(sizes[-1][0], sizes[-1][1], PAR["zfactor"]))
-        work = float(sum(int(iters[s].sum()) * sizes[s][0] * sizes[s][1] for s in range(PAR["nscales"])))
+        work = 0.0
+        for I0, I1 in pairs:
+            _, _, iters, _ = port.tvl1_multiscale(I0, I1, **PAR)
+            work += float(sum(int(iters[s].sum()) * sizes[s][0] * sizes[s][1] for s in range(PAR["nscales"])))
         out["value"] = round(work / t_ms / 1e6, 3)
+    I0, I1 = pairs[0]
     # fixed-work inner loop: Dual_TVL1_optic_flow, 1 warp, eps=0 -> 300 iterations at full resolution
     z = np.zeros((ny, nx))
     t0 = time.perf_counter()
     if cpu.kind == "reference":
-        cpu.tvl1_single_scale(I0, I1, z, z, tau=PAR["tau"], lam=PAR["lam"], theta=PAR["theta"], warps=1, epsilon=0.0)
-        n_it = 300
+        cpu.tvl1_single_scale(I0, I1, z, z, tau=PAR["tau"], lam=PAR["lam"], theta=PAR["theta"], warps=2, epsilon=0.0)
+        n_it = 600
     else:
-        _, _, it, _ = cpu.tvl1_single_scale(I0, I1, z, z, tau=PAR["tau"], lam=PAR["lam"], theta=PAR["theta"], warps=1,
+        _, _, it, _ = cpu.tvl1_single_scale(I0, I1, z, z, tau=PAR["tau"], lam=PAR["lam"], theta=PAR["theta"], warps=2,
                                             epsilon=0.0)
-        n_it = it[0]
+        n_it = sum(it)
     t_fx = time.perf_counter() - t0
     log("cpu_baseline: fixed-work inner loop %.2f s" % t_fx)
     out["fixed_work"] = {"value": round(n_it * nx * ny / t_fx / 1e6, 3), "unit": "Mpix*iters/s",
-                         "sample": "Dual_TVL1_optic_flow %dx%d, 1 warp, eps=0 (%d iterations, %.2f s)" % (nx, ny, n_it, t_fx)}
+                         "sample": "Dual_TVL1_optic_flow %dx%d, 2 warps, eps=0 (%d iterations, %.2f s)" % (nx, ny, n_it, t_fx)}
     return out, work
 
 
@@ -129,11 +137,15 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    local = local % torch.cuda.device_count()      # rehearsal of N ranks on a 1-GPU box (gloo); identity on a real node
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     ofx_mod = importlib.import_module("optical-flow-1_amd")
     synth = importlib.import_module("optical-flow-1_amd.synth")

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""gpurun_out/final/ -> profiles/ (tracked): bench line, rocprofv3 kernel stats, PMC traffic JSON.
+usage: tools/summarize_profiles.py <tag>      e.g. r01_final"""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "final")
+DST = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+
+shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, tag + "_bench.json"))
+bench = json.load(open(os.path.join(SRC, "bench.json")))
+
+# ---- kernel stats of the bench command ----
+stats = list(csv.DictReader(open(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0])))
+trace = list(csv.DictReader(open(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv"))[0])))
+out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu --streams 1   (MI355X, f64, 1920x1080 P1)",
+       "# the run contains the reference-semantics steps (eps=0.01) AND the fixed-work passes (300 iterations / warp)",
+       "# kernel | calls | total ms | average us | % of GPU time", ""]
+for r in stats:
+    out.append("%-96s %8s %11.3f %10.3f %8.3f" % (r["Name"][:96], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                  float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in trace:
+    if "k_tvl1_iter" in r["Kernel_Name"]:
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        name = "iter2" if "iter2" in r["Kernel_Name"] else "iter1"
+        key = (name, int(r["Grid_Size_X"]))
+        agg[key][0] += 1
+        agg[key][1] += d
+out += ["", "# TV-L1 iteration kernels by grid size (= pyramid level); iter2 = two fused iterations per launch.",
+        "# Small averages at a level are dominated by no-op launches behind the stopping iteration.",
+        "# kernel grid_threads launches avg_us total_ms"]
+full = None
+for k, v in sorted(agg.items()):
+    out.append("%-6s %9d %7d %9.2f %10.2f" % (k[0], k[1], v[0], v[1] / v[0], v[1] / 1e3))
+# the full-resolution fused launches that did real work (fixed-work pass): compare with bench's HIP-event number
+durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trace
+        if "k_tvl1_iter2" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == max(k[1] for k in agg if k[0] == "iter2")]
+work = [d for d in durs if d > 0.5 * (sorted(durs)[len(durs) // 2])]
+rocprof_avg = sum(work) / len(work)
+out += ["", "# full-resolution k_tvl1_iter2 launches doing real work: %d, rocprofv3 average %.2f us per launch" % (len(work), rocprof_avg),
+        "# bench.py (HIP events on the library stream, includes launch gaps): %.2f us per launch" % bench["roofline"]["avg_launch_us"]]
+open(os.path.join(DST, tag + "_kernel_stats.txt"), "w").write("\n".join(out) + "\n")
+
+# ---- PMC traffic ----
+pm = {"note": "rocprofv3 --pmc passes on tools/pmc_iter.py (40 fixed iterations = 20 launches of k_tvl1_iter2<double>). "
+              "FETCH_SIZE is doubled (gfx950 counts a wide coalesced read at half its bytes, MI355X_MICROARCH.md HBM); "
+              "WRITE_SIZE as reported. Units: bytes per launch (2 iterations)."}
+for sz in ("1920x1080", "3840x2160"):
+    vals = {}
+    for kind in ("fetch", "write", "sq"):
+        f = glob.glob(os.path.join(SRC, "pmc_%s_%s" % (kind, sz), "*", "*_counter_collection.csv"))
+        if not f:
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            if "k_tvl1_iter2" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            vals[k] = sum(v) / len(v)
+        kt = glob.glob(os.path.join(SRC, "pmc_%s_%s" % (kind, sz), "*", "*_kernel_trace.csv"))
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt[0])) if "k_tvl1_iter2" in r["Kernel_Name"]]
+        vals["launch_us_" + kind] = sum(d) / len(d)
+    nx, ny = map(int, sz.split("x"))
+    rd, wr = 2 * vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
+    pm["bytes_per_launch_f64_" + sz] = rd + wr
+    pm["detail_" + sz] = {"read_bytes": rd, "write_bytes": wr, "algorithmic_bytes_per_launch": 2 * 120.0 * nx * ny,
+                          "traffic_over_algorithmic": (rd + wr) / (2 * 120.0 * nx * ny),
+                          "l2_hit_rate": vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]),
+                          "valu_active_fraction": 4 * vals["SQ_ACTIVE_INST_VALU"] / 1024 / (vals["launch_us_sq"] * 1e-6 * vals["GRBM_GUI_ACTIVE"] / 8 / (vals["launch_us_fetch"] * 1e-6)),
+                          "clock_ghz": vals["GRBM_GUI_ACTIVE"] / 8 / (vals["launch_us_fetch"] * 1e-6) / 1e9,
+                          "launch_us": vals["launch_us_fetch"], "valu_insts_per_launch": vals["SQ_INSTS_VALU"],
+                          "waves": vals["SQ_WAVES"]}
+json.dump(pm, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(pm, indent=1))
+print("\n".join(out[-8:]))
