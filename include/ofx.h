@@ -78,8 +78,15 @@ void *ofx_ctx_stream(const ofx_ctx *ctx);                      /* the context's 
 int   ofx_ctx_precision(const ofx_ctx *ctx);
 int   ofx_ctx_synchronize(ofx_ctx *ctx);
 int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
-/* options: "profile" (0/1: bracket inner-iteration launches with HIP events -> stats.iter_ms),
- *          "rows_per_wave", "chunk" (tuning of the TV-L1 iteration kernel / launch batching). */
+/* options (value 0 = default / automatic unless noted):
+ *   "profile"        0/1  bracket the inner-iteration launches with HIP events -> stats.iter_ms
+ *   "fixed_work"     0/1  TV-L1: every warp runs exactly OFX_TVL1_MAX_ITERATIONS iterations (stopping
+ *                         test disabled; the reference with epsilon = 0)
+ *   "sor_exact"      1/0  HS / Brox: 1 (default) = the reference's sweep order, bit-identical results;
+ *                         0 = colour-ordered sweeps (much faster, result drifts by ~1e-5..1e-3 px)
+ *   "sor_batch"      sweeps in flight per batch in exact mode (default 64)
+ *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
+ *   "rows_per_wave", "rows_per_wave2", "chunk"   tuning of the TV-L1 kernels / launch batching */
 int   ofx_get_stats(const ofx_ctx *ctx, ofx_stats *out);
 
 /* ---- operators (replace src/operators.h:29-134) ---------------------------------------------*/

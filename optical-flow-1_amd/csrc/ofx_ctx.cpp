@@ -1,4 +1,4 @@
-// ofx_ctx.cpp -- context, device arena, pinned staging, error reporting (host side of libofx.so).
+// ofx_ctx.cpp -- context, device arena, options, error reporting (host side of libofx.so).
 #include "ofx_internal.h"
 
 #include <cstdarg>
@@ -57,8 +57,6 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->cur_slab = 0;
     ctx->cur_used = 0;
     ctx->call_bytes = 0;
-    ctx->h_stage = nullptr;
-    ctx->h_stage_bytes = 0;
     ctx->profile = 0;
     ctx->rows_per_wave = 0;     // 0 = pick per level
     ctx->rows_per_wave2 = 0;
@@ -94,7 +92,6 @@ extern "C" void ofx_ctx_destroy(ofx_ctx *ctx)
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->slabs) (void) hipFree(s.base);
-    if (ctx->h_stage) (void) hipHostFree(ctx->h_stage);
     (void) hipFree(ctx->d_err);
     (void) hipFree(ctx->d_state);
     (void) hipHostFree(ctx->h_state);
@@ -199,18 +196,5 @@ int ofx_arena_alloc(ofx_ctx *ctx, size_t bytes, void **out)
     ctx->cur_used = bytes;
     ctx->call_bytes += bytes;
     *out = p;
-    return OFX_OK;
-}
-
-int ofx_stage_reserve(ofx_ctx *ctx, size_t bytes)
-{
-    if (bytes <= ctx->h_stage_bytes) return OFX_OK;
-    if (ctx->h_stage) { (void) hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
-    hipError_t e = hipHostMalloc(&ctx->h_stage, bytes, hipHostMallocDefault);
-    if (e != hipSuccess) {
-        (void) hipGetLastError();
-        return ofx_fail(ctx, OFX_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    }
-    ctx->h_stage_bytes = bytes;
     return OFX_OK;
 }

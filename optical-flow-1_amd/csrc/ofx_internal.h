@@ -46,10 +46,6 @@ struct ofx_ctx {
     hipEvent_t    ev_poll[OFX_NPOLL];
     hipEvent_t    ev_t0, ev_t1;
 
-    // pinned staging for host<->device transfers of the host-pointer API
-    void  *h_stage;
-    size_t h_stage_bytes;
-
     // options
     int profile;
     int rows_per_wave;
@@ -86,7 +82,6 @@ int ofx_fail(ofx_ctx *ctx, int status, const char *fmt, ...);
 // ---- arena -----------------------------------------------------------------------------------
 void ofx_arena_reset(ofx_ctx *ctx);
 int  ofx_arena_alloc(ofx_ctx *ctx, size_t bytes, void **out);
-int  ofx_stage_reserve(ofx_ctx *ctx, size_t bytes);
 
 template <typename T>
 static inline int ofx_alloc(ofx_ctx *ctx, size_t count, T **out)

@@ -73,5 +73,3 @@ int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nx, int ny, int
             return ofx_fail((ctx), OFX_ERR_HIP, "kernel launch failed: %s (%s:%d)",              \
                             hipGetErrorString(e__), __FILE__, __LINE__);                         \
     } while (0)
-
-static inline hipError_t ofx_launch_status() { return hipGetLastError(); }

@@ -1,0 +1,72 @@
+"""Error behaviour of the C ABI on a real device: bad arguments are reported as status codes (the
+reference would crash or throw), and a failed call leaves the context usable."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_argument_validation(gpu64, ofx_mod, synth):
+    L = ofx_mod.lib()
+    I0, I1 = synth.pair("P0", 64, 48)
+    u, v = np.zeros((48, 64)), np.zeros((48, 64))
+    dp = lambda a: a.ctypes.data_as(C.c_void_p)
+    raw = C.CDLL(ofx_mod.LIB_PATH)
+    f = raw.ofx_tvl1_multiscale
+    f.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int,
+                                    C.c_double, C.c_int]
+    args = (48 * 0 + 64, 48, 0.25, 0.15, 0.3, 3, 0.5, 5, 0.01, 0)
+    assert f(gpu64.h, None, dp(I1), dp(u), dp(v), *args) == 1                       # NULL image
+    assert f(None, dp(I0), dp(I1), dp(u), dp(v), *args) == 1                        # NULL context
+    assert f(gpu64.h, dp(I0), dp(I1), dp(u), dp(v), 1, 48, 0.25, 0.15, 0.3, 1, 0.5, 5, 0.01, 0) == 1    # nx < 2
+    assert f(gpu64.h, dp(I0), dp(I1), dp(u), dp(v), 64, 48, 0.25, 0.15, 0.3, 0, 0.5, 5, 0.01, 0) == 1   # nscales 0
+    assert f(gpu64.h, dp(I0), dp(I1), dp(u), dp(v), 64, 48, 0.25, 0.15, 0.3, 3, 1.5, 5, 0.01, 0) == 1   # zfactor
+    assert f(gpu64.h, dp(I0), dp(I1), dp(u), dp(v), 64, 48, 0.25, 0.15, 0.3, 3, 0.5, 0, 0.01, 0) == 1   # warps 0
+    assert f(gpu64.h, dp(I0), dp(I1), dp(u), dp(v), 64, 48, 0.25, 0.15, 0.3, 8, 0.5, 5, 0.01, 0) == 2   # pyramid too deep
+    assert b"sigma" in L.ofx_last_error(gpu64.h).lower() or b"scale" in L.ofx_last_error(gpu64.h).lower()
+    with pytest.raises(ofx_mod.OfxError) as e:
+        gpu64.set_option("no_such_option", 1)
+    assert e.value.status == 1
+    with pytest.raises(ofx_mod.OfxError):
+        gpu64.gaussian(np.zeros((8, 8)), -1.0)
+    with pytest.raises(ofx_mod.OfxError):
+        gpu64.hs_single_scale(I0, I1, u, v, maxiter=10 ** 6)
+    # the context still works after all those failures
+    uu, vv = gpu64.tvl1_multiscale(I0, I1, nscales=3)
+    assert np.isfinite(uu).all() and gpu64.stats().nscales == 3
+
+
+def test_context_reuse_across_sizes_and_solvers(gpu64, orc, synth):
+    """the arena is reset per call and coalesced once: interleaving sizes / solvers must not disturb results"""
+    ref = {}
+    for nx, ny in ((64, 48), (160, 120), (96, 64)):
+        I0, I1 = synth.pair("P1", nx, ny)
+        ref[(nx, ny)] = orc.tvl1_multiscale(I0, I1, nscales=3)[:2]
+    for rep in range(2):
+        for (nx, ny), (uo, vo) in ref.items():
+            I0, I1 = synth.pair("P1", nx, ny)
+            u, v = gpu64.tvl1_multiscale(I0, I1, nscales=3)
+            assert np.abs(u - uo).max() < 1e-9 and np.abs(v - vo).max() < 1e-9
+            gpu64.hs_pyramidal(I0, I1, alpha=20.0, nscales=2, warps=2)
+            gpu64.divergence(I0, I1)
+
+
+def test_two_contexts_from_two_threads(ofx_mod, orc, synth):
+    """calls on different contexts are independent (this is how bench.py keeps 4 pairs in flight)"""
+    import threading
+    I0, I1 = synth.pair("P1", 200, 150)
+    uo, vo, _, _ = orc.tvl1_multiscale(I0, I1, nscales=4)
+    out = [None, None]
+
+    def work(w):
+        c = ofx_mod.Ofx(0, ofx_mod.F64)
+        for _ in range(3):
+            out[w] = c.tvl1_multiscale(I0, I1, nscales=4)
+        c.close()
+    th = [threading.Thread(target=work, args=(w,)) for w in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for u, v in out:
+        assert np.abs(u - uo).max() < 1e-9 and np.abs(v - vo).max() < 1e-9

@@ -127,3 +127,59 @@ def test_sigma_too_large_is_reported(gpu64, ofx_mod, synth):
     with pytest.raises(ofx_mod.OfxError) as e:
         gpu64.tvl1_multiscale(I0, I1, nscales=6, **PAR)      # 64x48 -> ... -> 2x2: gaussian radius > size
     assert e.value.status == 2
+
+
+# ---- BASELINE.json full sizes ---------------------------------------------------------------------------
+def test_full_size_1080p_matches_oracle(gpu64, oracle_mod, synth):
+    """config 2 at full size.  TV-L1 on the CPU is race-free, so the oracle may use every host core."""
+    o = oracle_mod.Oracle()
+    o.set_num_threads(min(oracle_mod.host_cores(), 32))
+    I0, I1 = synth.pair("P1", 1920, 1080)
+    uo, vo, it_o, _ = o.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+    ug, vg = gpu64.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+    assert np.array_equal(gpu64.stats().iterations(), it_o)
+    assert aepe(ug, vg, uo, vo) < 1e-4
+    assert np.abs(ug - uo).max() < 1e-9 and np.abs(vg - vo).max() < 1e-9
+
+
+def test_4k_size_independent_properties(gpu64, synth):
+    """config 5 size (3840x2160), where the oracle is too slow for the suite: (i) the fused two-iteration
+    kernel and the one-iteration kernel give bit-identical flows and iteration counts, for any strip
+    height; (ii) the result is bit-reproducible run to run; (iii) zero motion stays zero."""
+    I0, I1 = synth.pair("P1", 3840, 2160)
+    kw = dict(nscales=5, warps=2, **PAR)
+    u_a, v_a = gpu64.tvl1_multiscale(I0, I1, **kw)
+    it_a = gpu64.stats().iterations()
+    gpu64.set_option("fuse2", 0)
+    try:
+        u_b, v_b = gpu64.tvl1_multiscale(I0, I1, **kw)
+        it_b = gpu64.stats().iterations()
+    finally:
+        gpu64.set_option("fuse2", 1)
+    assert np.array_equal(it_a, it_b) and np.array_equal(u_a, u_b) and np.array_equal(v_a, v_b)
+    gpu64.set_option("rows_per_wave2", 5)
+    try:
+        u_c, v_c = gpu64.tvl1_multiscale(I0, I1, **kw)
+    finally:
+        gpu64.set_option("rows_per_wave2", 0)
+    assert np.array_equal(u_a, u_c) and np.array_equal(v_a, v_c)
+    u_d, v_d = gpu64.tvl1_multiscale(I0, I1, **kw)
+    assert np.array_equal(u_a, u_d) and np.array_equal(v_a, v_d)
+    u_z, v_z = gpu64.tvl1_multiscale(I0, I0, **kw)
+    assert np.abs(u_z).max() == 0.0 and np.abs(v_z).max() == 0.0
+    assert np.isfinite(u_a).all() and abs(float(u_a.mean())) < 10
+
+
+@pytest.mark.parametrize("nx,ny", [(61, 33), (121, 35), (180, 47), (64, 3), (3, 64)])
+def test_fused_kernel_equals_single_kernel(gpu64, orc, synth, nx, ny):
+    """strip / halo edge cases of the fused kernel: widths around multiples of 60, very flat / thin images"""
+    u1, u2, p, I1wx, I1wy, rho_c, grad = linearised_state(orc, synth, max(nx, 8), max(ny, 8))
+    u1, u2, I1wx, I1wy, rho_c, grad = (np.ascontiguousarray(a[:ny, :nx]) for a in (u1, u2, I1wx, I1wy, rho_c, grad))
+    p = [np.ascontiguousarray(a[:ny, :nx]) for a in p]
+    for n_iter in (2, 5, 6):
+        go = [x.copy() for x in (u1, u2, *p)]
+        gg = [x.copy() for x in (u1, u2, *p)]
+        orc.tvl1_iterations(*go, I1wx, I1wy, rho_c, grad, PAR["tau"], PAR["lam"], PAR["theta"], n_iter)
+        gpu64.tvl1_iterations(*gg, I1wx, I1wy, rho_c, PAR["tau"], PAR["lam"], PAR["theta"], n_iter)
+        for a, b in zip(gg, go):
+            assert np.array_equal(a, b)
