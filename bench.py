@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--rows2", type=int, default=0)
     return ap.parse_args()
 
 
@@ -155,10 +156,13 @@ def main():
     ctxs = [ofx_mod.Ofx(local, prec) for _ in range(nstreams)]
     ctx = ctxs[0]
     for c_ in ctxs:
+        c_.set_option("concurrency", nstreams)
         if a.rows:
             c_.set_option("rows_per_wave", a.rows)
         if a.chunk:
             c_.set_option("chunk", a.chunk)
+        if a.rows2:
+            c_.set_option("rows_per_wave2", a.rows2)
 
     nx, ny = a.nx, a.ny
     I0, I1 = synth.pair(a.pair, nx, ny, rank)
@@ -243,6 +247,7 @@ def main():
         fence()
         tq = time.perf_counter() - tq0
         # (b) one pair alone with HIP events around the iteration launches: per-kernel times for the roofline
+        ctx.set_option("concurrency", 1)
         ctx.set_option("profile", 1)
         step(0)                                              # warm
         ctx.synchronize()
@@ -262,6 +267,7 @@ def main():
         for c_ in ctxs:
             c_.set_option("fixed_work", 0)
         ctx.set_option("profile", 0)
+        ctx.set_option("concurrency", nstreams)
         log("fixed-work pass: %d steps in %.3f s" % (a.fixed_steps, tf))
         fixed = {"value": round(fw_par / tq / 1e6, 1), "unit": "Mpix*warp-iters/s",
                  "ms_per_step": round(tq / (a.fixed_steps * nstreams) * 1e3, 3), "steps": a.fixed_steps * nstreams,

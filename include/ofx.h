@@ -86,6 +86,8 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         0 = colour-ordered sweeps (much faster, result drifts by ~1e-5..1e-3 px)
  *   "sor_batch"      sweeps in flight per batch in exact mode (default 64)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
+ *   "concurrency"    number of contexts that will be solving on the same device at the same time
+ *                         (default 1); a scheduling hint for the strip height of the TV-L1 kernels
  *   "rows_per_wave", "rows_per_wave2", "chunk"   tuning of the TV-L1 kernels / launch batching */
 int   ofx_get_stats(const ofx_ctx *ctx, ofx_stats *out);
 

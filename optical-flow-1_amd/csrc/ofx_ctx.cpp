@@ -61,6 +61,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->rows_per_wave = 0;     // 0 = pick per level
     ctx->rows_per_wave2 = 0;
     ctx->fuse2 = 1;             // two TV-L1 iterations per launch
+    ctx->concurrency = 1;
     ctx->chunk = 0;             // 0 = pick per level
     ctx->fixed_work = 0;
     ctx->sor_exact = 1;
@@ -125,6 +126,11 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "rows_per_wave2")) {
         if (value < 0 || value > 4096) return ofx_fail(ctx, OFX_ERR_ARG, "rows_per_wave2 out of range");
         ctx->rows_per_wave2 = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "concurrency")) {
+        if (value < 1 || value > 64) return ofx_fail(ctx, OFX_ERR_ARG, "concurrency out of range");
+        ctx->concurrency = (int) value;
         return OFX_OK;
     }
     if (!strcmp(name, "sor_exact")) { ctx->sor_exact = value != 0; return OFX_OK; }

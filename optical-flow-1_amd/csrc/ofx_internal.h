@@ -51,6 +51,7 @@ struct ofx_ctx {
     int rows_per_wave;
     int rows_per_wave2;
     int fuse2;
+    int concurrency;    // contexts expected to share the device (tuning hint, default 1)
     int chunk;
     int fixed_work;
     int sor_exact;      // 1: reference sweep order (hyperplane-pipelined), 0: colour order (fast)

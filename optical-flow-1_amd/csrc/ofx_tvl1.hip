@@ -410,16 +410,44 @@ static int tvl1_pick_rows(const ofx_ctx *ctx, int nx, int ny)
     return 1;
 }
 
-// strip height of the fused two-iteration kernel: it loads rows + 3 rows per strip, so taller strips
-// pay; the marching chain is rows + 3 steps, so tiny levels still want short ones.
+// Strip height of the fused two-iteration kernel.  A wave of a strip of r rows executes r + 3 marching
+// steps (+ ~2 steps of start-up).  At 142 VGPRs the chip holds 3 waves per SIMD = 3072 waves at once, so a
+// launch of W waves takes k = ceil(W / 3072) rounds of about (r + 5) step times.  The best strip height is
+// therefore the SMALLEST r whose wave count still fits k rounds exactly (1080p: r = 12 -> 32 x 90 = 2880
+// waves, one round; r = 8 -> 4320 waves = 1.4 rounds is 9 % slower), minimised over k.  Measured on the
+// bench workload at every pyramid level: profiles/r01_g_rows2_on_bench_workload.txt.
 static int tvl1_pick_rows2(const ofx_ctx *ctx, int nx, int ny)
 {
     if (ctx->rows_per_wave2 > 0) return ctx->rows_per_wave2;
-    const int strips = ofx_cdiv(nx, STRIP2_OUT);
-    if ((long) strips * ofx_cdiv(ny, 16) >= 4096) return 16;
-    if ((long) strips * ofx_cdiv(ny, 8) >= 2048) return 8;
-    if ((long) strips * ofx_cdiv(ny, 4) >= 1024) return 4;
-    return 2;
+    const long strips_pad = ofx_cdiv(ofx_cdiv(nx, STRIP2_OUT), 4) * 4;
+    const int rmax = 24;
+    int best = rmax;
+    long best_cost = -1;
+    if (ctx->concurrency > 1) {
+        // Several contexts share the device (option "concurrency"): other pairs' waves fill this launch's
+        // partial rounds, so what counts is the total work  ~ ceil(W / 1024 SIMDs) * (r + 5)  -- taller
+        // strips, less halo recomputation (measured with 4 pairs in flight: +8 % job throughput over the
+        // single-pair choice).
+        static const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 20, 24};
+        for (int r : cand) {
+            const long waves = strips_pad * ofx_cdiv(ny, r);
+            const long cost = ((waves + 1023) / 1024) * (r + 5);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
+        }
+        return best;
+    }
+    const long slots = 3072;
+    for (int k = 1; k <= 4; k++) {
+        for (int r = 1; r <= rmax; r++) {
+            if (strips_pad * ofx_cdiv(ny, r) > k * slots) continue;
+            const long cost = (long) k * (r + 5);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
+            break;
+        }
+    }
+    // very short strips triple the halo work; keep 3 rows as long as that still leaves >= 512 waves
+    if (best < 3 && strips_pad * ofx_cdiv(ny, 3) >= 512) best = 3;
+    return best;
 }
 
 static int tvl1_pick_chunk(const ofx_ctx *ctx, int nx, int ny)
