@@ -177,29 +177,15 @@ def main():
         return c_.stats().work_pix_iters
 
     def run_steps(n):
-        """n steps (pairs), `nstreams` of them in flight: worker w takes steps w, w+S, ... on its own
-        context.  The C calls release the GIL, so the host threads really overlap: while one pair waits
-        for a convergence poll or crawls through a launch-bound coarse level, another one fills the GPU."""
+        """n steps (pairs) through the library's batch entry point: pair i runs on context i % nstreams, so
+        `nstreams` pairs are in flight (one host thread + one HIP stream each, inside libofx): while one
+        pair waits for a convergence poll or crawls through a launch-bound coarse level, another one fills
+        the GPU."""
         if nstreams == 1:
             return sum(step(i) for i in range(n))
-        import threading
-        done = [0.0] * nstreams
-        errs = []
-
-        def worker(w):
-            try:
-                for i in range(w, n, nstreams):
-                    done[w] += step(i, ctxs[w])
-            except Exception as e:          # surface failures of worker threads
-                errs.append(e)
-        th = [threading.Thread(target=worker, args=(w,)) for w in range(nstreams)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
-        return sum(done)
+        work = ofx_mod.tvl1_batch_dev(ctxs, [dI0.data_ptr()] * n, [dI1.data_ptr()] * n,
+                                      [flo[i % flo.shape[0]].data_ptr() for i in range(n)], nx, ny, **PAR)
+        return sum(work)
 
     def fence():
         for c_ in ctxs:

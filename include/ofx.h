@@ -138,6 +138,18 @@ int ofx_tvl1_multiscale_dev(ofx_ctx *ctx, const void *dI0, const void *dI1, void
                             int nx, int ny, double tau, double lambda, double theta, int nscales,
                             double zfactor, int warps, double epsilon, int verbose);
 
+/* Batch of independent pairs on ONE device (the unit of parallel work is the image pair).
+ * Pair k is solved on context ctxs[k % n_ctx]; one host thread per context drives its pairs, so n_ctx
+ * pairs are in flight at a time (each context = its own HIP stream and workspace; all contexts must
+ * live on the same device and have the same precision).  Arrays dI0/dI1/d_flo hold n_pairs device
+ * pointers with the layout of ofx_tvl1_multiscale_dev.  work_pix_iters (optional, n_pairs doubles)
+ * receives sum n_iter*nx_s*ny_s per pair.  Returns after every pair has been fully solved (all
+ * streams synchronised); the first failing pair's status is returned. */
+int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI0, const void *const *dI1,
+                       void *const *d_flo, int n_pairs, int nx, int ny, double tau, double lambda,
+                       double theta, int nscales, double zfactor, int warps, double epsilon,
+                       double *work_pix_iters);
+
 /* Fixed-work inner loop only (src/tvl1flow.cpp:113-182 run exactly n_iter times on linearised
  * data, all arrays host double planes; u/p updated in place).  Returns the last error in *error.
  * Used by the kernel-level parity tests and the roofline measurement. */

@@ -99,6 +99,8 @@ def lib():
         "ofx_tvl1_single_scale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _d, _i, _d, _i]),
         "ofx_tvl1_multiscale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _d, _i, _d, _i, _d, _i]),
         "ofx_tvl1_multiscale_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _d, _d, _i, _d, _i, _d, _i]),
+        "ofx_tvl1_batch_dev": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _d, _d, _d,
+                                    _i, _d, _i, _d, C.POINTER(_d)]),
         "ofx_tvl1_iterations": (_i, [_vp] + [_dp] * 9 + [_i, _i, _d, _d, _d, _i, C.POINTER(_d)]),
         "ofx_hs_single_scale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _i]),
         "ofx_hs_pyramidal": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _d, _i, _i]),
@@ -124,6 +126,20 @@ def zoom_size(nx, ny, factor):
 
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def tvl1_batch_dev(ctxs, dI0, dI1, d_flo, nx, ny, tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5,
+                   epsilon=0.01):
+    """ofx_tvl1_batch_dev: lists of device pointers (ints), one entry per pair; pair k runs on ctxs[k % len(ctxs)]
+    with len(ctxs) pairs in flight.  Returns the per-pair work (pixel-iterations)."""
+    n = len(dI0)
+    arr = lambda xs: (_vp * len(xs))(*xs)
+    work = (_d * max(n, 1))()
+    s = lib().ofx_tvl1_batch_dev(arr([c.h.value for c in ctxs]), len(ctxs), arr(dI0), arr(dI1), arr(d_flo), n, nx, ny, tau,
+                                 lam, theta, nscales, zfactor, warps, epsilon, work)
+    if s:
+        raise OfxError(s, "; ".join((c.L.ofx_last_error(c.h) or b"").decode() for c in ctxs))
+    return [work[i] for i in range(n)]
 
 
 class Ofx:

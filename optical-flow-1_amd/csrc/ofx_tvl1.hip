@@ -34,8 +34,10 @@
 #include "ofx_device.h"
 #include "ofx_loop.h"
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <thread>
 
 #define TVL1_GRAD_IS_ZERO 1E-10          // src/tvl1flow.cpp:24
 #define TVL1_PRESMOOTHING_SIGMA 0.8      // src/tvl1flow.cpp:23
@@ -771,4 +773,31 @@ extern "C" int ofx_tvl1_iterations(ofx_ctx *ctx, double *u1, double *u2, double 
                 : tvl1_iterations_host<float>(ctx, u1, u2, p11, p12, p21, p22, I1wx, I1wy, rho_c, nx, ny, P, error);
     ctx->stats.total_ms = ofx_now_ms() - t0;
     return s;
+}
+
+// ---- batch of pairs: one worker thread per context ----------------------------------------------------
+extern "C" int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI0, const void *const *dI1,
+                                  void *const *d_flo, int n_pairs, int nx, int ny, double tau, double lambda,
+                                  double theta, int nscales, double zfactor, int warps, double epsilon,
+                                  double *work_pix_iters)
+{
+    if (!ctxs || n_ctx < 1 || n_pairs < 0 || !dI0 || !dI1 || !d_flo) return OFX_ERR_ARG;
+    for (int w = 0; w < n_ctx; w++)
+        if (!ctxs[w] || ctxs[w]->device != ctxs[0]->device || ctxs[w]->precision != ctxs[0]->precision) return OFX_ERR_ARG;
+    std::atomic<int> status(OFX_OK);
+    auto worker = [&](int w) {
+        for (int k = w; k < n_pairs; k += n_ctx) {
+            if (status.load() != OFX_OK) return;
+            const int s = ofx_tvl1_multiscale_dev(ctxs[w], dI0[k], dI1[k], d_flo[k], nx, ny, tau, lambda, theta, nscales,
+                                                  zfactor, warps, epsilon, 0);
+            if (s != OFX_OK) { int expected = OFX_OK; status.compare_exchange_strong(expected, s); return; }
+            if (work_pix_iters) work_pix_iters[k] = ctxs[w]->stats.work_pix_iters;
+        }
+        (void) hipStreamSynchronize(ctxs[w]->stream);
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < n_ctx && w < n_pairs; w++) th.emplace_back(worker, w);
+    worker(0);
+    for (auto &t : th) t.join();
+    return status.load();
 }

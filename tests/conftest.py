@@ -18,6 +18,15 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def ofx_mod():
+    # PyTorch ships its own HIP runtime; if libofx.so (system ROCm) touches the GPU first, torch later
+    # reports "No HIP GPUs are available".  Tests that hand torch device pointers to the library
+    # therefore let torch initialise the device first (bench.py does the same by construction).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     return importlib.import_module("optical-flow-1_amd")
 
 

@@ -70,3 +70,25 @@ def test_two_contexts_from_two_threads(ofx_mod, orc, synth):
     [t.join() for t in th]
     for u, v in out:
         assert np.abs(u - uo).max() < 1e-9 and np.abs(v - vo).max() < 1e-9
+
+
+def test_batch_entry_point(ofx_mod, orc, synth):
+    """ofx_tvl1_batch_dev: 5 different pairs over 2 contexts == each pair solved alone"""
+    import torch
+    nx, ny, n = 128, 96, 5
+    ctxs = [ofx_mod.Ofx(0, ofx_mod.F64) for _ in range(2)]
+    pairs = [synth.pair("P1", nx, ny, k) for k in range(n)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in pairs]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in pairs]
+    flo = torch.zeros((n, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    work = ofx_mod.tvl1_batch_dev(ctxs, [t.data_ptr() for t in d0], [t.data_ptr() for t in d1],
+                                  [flo[k].data_ptr() for k in range(n)], nx, ny, nscales=3)
+    got = flo.cpu().numpy()
+    for k in range(n):
+        uo, vo, it, _ = orc.tvl1_multiscale(pairs[k][0], pairs[k][1], nscales=3)
+        assert np.array_equal(got[k], np.stack([uo, vo], axis=-1).astype(np.float32))
+        sizes = [(nx, ny), (64, 48), (32, 24)]
+        assert work[k] == sum(int(it[s].sum()) * sizes[s][0] * sizes[s][1] for s in range(3))
+    for c in ctxs:
+        c.close()
