@@ -73,15 +73,19 @@ static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, RedoFn
     OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
     if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
 
-    // head / tail count the polls issued / consumed; at most two are outstanding (the one the host
-    // waits for and one chunk of lookahead that keeps the GPU busy meanwhile).
+    // head / tail count the polls issued / consumed.  A context that has the device to itself keeps two
+    // outstanding (the one the host waits for and one chunk of lookahead, so the GPU never idles while the
+    // host reads a poll) at the price of one chunk of no-op launches behind the stopping iteration.  When
+    // other contexts share the device (option "concurrency" > 1) their work fills such gaps, so nothing is
+    // launched speculatively: one outstanding poll.
+    const int max_out = ctx->concurrency > 1 ? 1 : 2;
     int launched = 0, head = 0, tail = 0, slot_of[2] = {0, 0};
     bool stop = false;
     OfxIterState fin = {0, 0, 0.0};
     int chunk = S.chunk < 1 ? 1 : S.chunk;
     if (S.pairs) chunk += chunk & 1;
     for (;;) {
-        while (launched < S.max_iter && head - tail < 2) {
+        while (launched < S.max_iter && head - tail < max_out) {
             const int first = launched;
             const int c = (S.max_iter - launched < chunk) ? S.max_iter - launched : chunk;
             while (launched < first + c) {
