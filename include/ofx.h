@@ -41,8 +41,11 @@ extern "C" {
 #define OFX_ERR_NODEV   5   /* no gfx950 device / device index out of range                      */
 
 /* storage precision of the device-resident arrays; arithmetic is ALWAYS double in registers.   */
-#define OFX_F64 0           /* strict mode: double storage, bit-compatible per-pixel arithmetic  */
-#define OFX_F32 1           /* fast mode: float storage (half the HBM traffic)                   */
+#define OFX_F64 0           /* strict mode: double storage, per-pixel arithmetic bit-identical to
+                               the reference (glibc-exact hypot, IEEE divisions, no FMA contraction) */
+#define OFX_F32 1           /* fast mode: float storage (half the HBM traffic) and, in the TV-L1
+                               dual update, hypot = sqrt(x*x+y*y) and one reciprocal per denominator;
+                               AEPE vs the double reference ~1e-5, not bit-compatible             */
 
 /* solver limits mirrored from the reference's #defines */
 #define OFX_TVL1_MAX_ITERATIONS 300   /* src/tvl1flow.cpp:22  */
