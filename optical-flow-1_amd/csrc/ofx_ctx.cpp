@@ -176,6 +176,8 @@ void ofx_arena_reset(ofx_ctx *ctx)
 
 int ofx_arena_alloc(ofx_ctx *ctx, size_t bytes, void **out)
 {
+    static const long skew = getenv("OFX_ARENA_SKEW") ? atol(getenv("OFX_ARENA_SKEW")) : 0;   // A/B knob only
+    bytes += (size_t) skew;
     bytes = (bytes + kSlabAlign - 1) / kSlabAlign * kSlabAlign;
     if (bytes == 0) bytes = kSlabAlign;
     while (ctx->cur_slab < ctx->slabs.size()) {

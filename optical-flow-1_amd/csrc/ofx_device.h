@@ -12,7 +12,17 @@
 // ---- widening loads / narrowing stores --------------------------------------------------------
 OFX_DEV double  ldw(const double *p) { return *p; }
 OFX_DEV double  ldw(const float *p)  { return (double) *p; }
+typedef double ofx_d2v __attribute__((ext_vector_type(2)));
+typedef float ofx_f2v __attribute__((ext_vector_type(2)));
+#ifdef OFX_NT_LOAD
+OFX_DEV double2 ldw2(const double2 *p)
+{
+    const ofx_d2v v = __builtin_nontemporal_load(reinterpret_cast<const ofx_d2v *>(p));
+    return make_double2(v.x, v.y);
+}
+#else
 OFX_DEV double2 ldw2(const double2 *p) { return *p; }
+#endif
 OFX_DEV double2 ldw2(const float2 *p)  { float2 v = *p; return make_double2((double) v.x, (double) v.y); }
 OFX_DEV double4 ldw4(const double4 *p) { return *p; }
 OFX_DEV double4 ldw4(const float4 *p)
@@ -22,7 +32,15 @@ OFX_DEV double4 ldw4(const float4 *p)
 }
 OFX_DEV void stn(double *p, double v) { *p = v; }
 OFX_DEV void stn(float *p, double v)  { *p = (float) v; }
+#ifdef OFX_NT_STORE
+OFX_DEV void stn2(double2 *p, double2 v)
+{
+    ofx_d2v w; w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<ofx_d2v *>(p));
+}
+#else
 OFX_DEV void stn2(double2 *p, double2 v) { *p = v; }
+#endif
 OFX_DEV void stn2(float2 *p, double2 v)  { *p = make_float2((float) v.x, (float) v.y); }
 OFX_DEV void stn4(double4 *p, double4 v) { *p = v; }
 OFX_DEV void stn4(float4 *p, double4 v)

@@ -52,16 +52,29 @@ template <typename T> struct RowIn {
     double r;
 };
 
+// All streams of a level are addressed as  uniform base pointer + 32-bit per-lane BYTE offset, which is
+// the addressing mode of global_load/store (SGPR base + zero-extended VGPR offset): one v_add per row
+// step instead of 64-bit index arithmetic per access.  Requires nx*ny*16 < 2^32 (checked by the host).
+template <typename V> OFX_DEV const V *at(const V *base, unsigned byte_off)
+{
+    return reinterpret_cast<const V *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <typename V> OFX_DEV V *at(V *base, unsigned byte_off)
+{
+    return reinterpret_cast<V *>(reinterpret_cast<char *>(base) + byte_off);
+}
+
+// off2 = byte offset of the pixel in the pair arrays (2 T per pixel); rho_c (1 T per pixel) is at off2 / 2
 template <typename T>
 OFX_DEV RowIn<T> tvl1_load_row(const typename Pix<T>::v2 *U, const typename Pix<T>::v2 *P1,
-                               const typename Pix<T>::v2 *P2, const typename Pix<T>::v2 *A, const T *R, size_t p)
+                               const typename Pix<T>::v2 *P2, const typename Pix<T>::v2 *A, const T *R, unsigned off2)
 {
     RowIn<T> r;
-    r.u = ldw2(U + p);
-    r.p1 = ldw2(P1 + p);
-    r.p2 = ldw2(P2 + p);
-    r.a = ldw2(A + p);
-    r.r = ldw(R + p);
+    r.u = ldw2(at(U, off2));
+    r.p1 = ldw2(at(P1, off2));
+    r.p2 = ldw2(at(P2, off2));
+    r.a = ldw2(at(A, off2));
+    r.r = ldw(at(R, off2 >> 1));
     return r;
 }
 
@@ -164,16 +177,21 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
     const bool lef = (c == 0), rig = (c == nx - 1);
     const bool owner = (lane >= 1) && (lane <= STRIP_OUT) && (c < nx);
 
+    const unsigned E2 = 2 * sizeof(T);                      // bytes per pixel of the pair arrays
+    const unsigned row2 = (unsigned) nx * E2;
+    unsigned off = ((unsigned) y0 * nx + cc) * E2;          // byte offset of (y, cc)
+    const unsigned offs = ((unsigned) y0 * nx + (c < 0 ? 0 : c)) * E2;   // ... of (y, c) for the stores
+    unsigned so = offs;
+
     // p12 / p22 of the row above the strip (dropped by the top-row rule when y0 == 0)
     double up12 = 0.0, up22 = 0.0;
     RowIn<T> cur;
     if (!idle) {
         if (y0 > 0) {
-            const size_t pu = (size_t) (y0 - 1) * nx + cc;
-            up12 = ldw2(P1in + pu).y;
-            up22 = ldw2(P2in + pu).y;
+            up12 = ldw2(at(P1in, off - row2)).y;
+            up22 = ldw2(at(P2in, off - row2)).y;
         }
-        cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) y0 * nx + cc);
+        cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off);
     }
 
     // stopping test of src/tvl1flow.cpp:113
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
     for (int y = y0; y <= yend; y++) {
         // prefetch the next row while this one is being processed
         RowIn<T> nxt = cur;
-        if (y + 1 <= yend && y + 1 < ny) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) (y + 1) * nx + cc);
+        if (y + 1 <= yend && y + 1 < ny) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + row2);
 
         double2 un = make_double2(0.0, 0.0);
         if (y < ny) {
@@ -196,7 +214,7 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
             un = tvl1_primal<T>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0, y == ny - 1,
                                 l_t, theta);
             if (owner && y < yend) {
-                stn2(Uout + (size_t) y * nx + c, un);
+                stn2(at(Uout, so), un);
                 acc += (un.x - cur.u.x) * (un.x - cur.u.x) + (un.y - cur.u.y) * (un.y - cur.u.y);   // :159-160
             }
         }
@@ -206,9 +224,8 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
             double2 q1, q2;
             tvl1_dual<T>(p1_prev, p2_prev, un_prev, r1, r2, un, rig, y - 1 == ny - 1, taut, q1, q2);
             if (owner) {
-                const size_t pp = (size_t) (y - 1) * nx + c;
-                stn2(P1out + pp, q1);
-                stn2(P2out + pp, q2);
+                stn2(at(P1out, so - row2), q1);
+                stn2(at(P2out, so - row2), q2);
             }
         }
         un_prev = un;
@@ -217,6 +234,8 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
         up12 = cur.p1.y;
         up22 = cur.p2.y;
         cur = nxt;
+        off += row2;
+        so += row2;
     }
     loop_accumulate(err, slot, acc, gw);
 }
@@ -232,7 +251,14 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
 // one-iteration kernel.  HBM traffic per iteration drops from 15 to ~(9 (rows+3)/rows 64/60 + 6)/2
 // elements per pixel (8.3 at rows = 16).
 #define STRIP2_OUT 60
-#ifndef OFX_ITER2_BOUNDS
+// waves per SIMD the fused kernel is compiled for (3: 130 VGPRs as the compiler likes it; 4: capped at
+// 128 VGPRs with a 3-dword spill).  The strip-height model below needs the same number.
+#ifndef OFX_ITER2_WAVES
+#define OFX_ITER2_WAVES 3
+#endif
+#if OFX_ITER2_WAVES >= 4
+#define OFX_ITER2_BOUNDS __launch_bounds__(256, 4)
+#else
 #define OFX_ITER2_BOUNDS __launch_bounds__(256)
 #endif
 template <typename T>
@@ -259,15 +285,19 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
     const bool lef = (c == 0), rig = (c == nx - 1);
     const bool owner = (lane >= 2) && (lane <= STRIP2_OUT + 1) && (c < nx);
 
+    const unsigned E2 = 2 * sizeof(T);                      // bytes per pixel of the pair arrays
+    const unsigned row2 = (unsigned) nx * E2;
+    unsigned off = ((unsigned) ys * nx + cc) * E2;          // byte offset of (y, cc): loads
+    unsigned so = ((unsigned) ys * nx + (c < 0 ? 0 : c)) * E2;   // ... of (y, c): stores (owner lanes only)
+
     double up12 = 0.0, up22 = 0.0;                           // p12 / p22 (iteration k-1) of row y-1
     RowIn<T> cur;
     if (!idle) {
         if (ys > 0) {
-            const size_t pu = (size_t) (ys - 1) * nx + cc;
-            up12 = ldw2(P1in + pu).y;
-            up22 = ldw2(P2in + pu).y;
+            up12 = ldw2(at(P1in, off - row2)).y;
+            up22 = ldw2(at(P2in, off - row2)).y;
         }
-        cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) ys * nx + cc);
+        cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off);
     }
     if (!tvl1_continues(prev1, prev2, k, nx * ny, eps2)) return;
     if (idle) return;
@@ -283,7 +313,7 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
 
     for (int y = ys; y <= yend + 2; y++) {
         RowIn<T> nxt = cur;
-        if (y + 1 <= yl) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, (size_t) (y + 1) * nx + cc);
+        if (y + 1 <= yl) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + row2);
 
         // S1: u_A(y)
         const bool have1 = (y <= yl);
@@ -311,7 +341,7 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
             uB0 = tvl1_primal<T>(uA2, a2, r2c, pA1a, pA1b, l11, l21, pA2a.y, pA2b.y, lef, rig, y - 2 == 0, y - 2 == ny - 1,
                                  l_t, theta);
             if (owner && y - 2 < yend) {
-                stn2(Uout + (size_t) (y - 2) * nx + c, uB0);
+                stn2(at(Uout, so - 2 * row2), uB0);
                 accB += (uB0.x - uA2.x) * (uB0.x - uA2.x) + (uB0.y - uA2.y) * (uB0.y - uA2.y);
             }
         }
@@ -322,9 +352,8 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
             double2 q1, q2;
             tvl1_dual<T>(pA2a, pA2b, uB1, n1, n2, uB0, rig, y - 3 == ny - 1, taut, q1, q2);
             if (owner) {
-                const size_t pp = (size_t) (y - 3) * nx + c;
-                stn2(P1out + pp, q1);
-                stn2(P2out + pp, q2);
+                stn2(at(P1out, so - 3 * row2), q1);
+                stn2(at(P2out, so - 3 * row2), q2);
             }
         }
         // advance the pipeline by one row
@@ -336,6 +365,8 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
         pA2a = pA1a; pA2b = pA1b; pA1a = pAna; pA1b = pAnb;
         uB1 = uB0;
         cur = nxt;
+        off += row2;
+        so += row2;
     }
     loop_accumulate(err, k, accA, gw);
     loop_accumulate(err, k + 1, accB, gw);
@@ -455,7 +486,7 @@ static int tvl1_pick_rows2(const ofx_ctx *ctx, int nx, int ny)
         }
         return best;
     }
-    const long slots = 3072;
+    const long slots = 1024L * OFX_ITER2_WAVES;
     for (int k = 1; k <= 4; k++) {
         for (int r = 1; r <= rmax; r++) {
             if (strips_pad * ofx_cdiv(ny, r) > k * slots) continue;
@@ -486,6 +517,7 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
                                float *ms_out)
 {
     const int nx = L.nx, ny = L.ny;
+    if ((long long) nx * ny >= (1LL << 28)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: image larger than 2^28 pixels");
     const double l_t = P.lambda * P.theta, taut = P.tau / P.theta, theta = P.theta;
     const bool pairs = ctx->fuse2 != 0;
     // geometry of the one-iteration kernel (also used for a trailing single iteration and the redo)
