@@ -12,17 +12,7 @@
 // ---- widening loads / narrowing stores --------------------------------------------------------
 OFX_DEV double  ldw(const double *p) { return *p; }
 OFX_DEV double  ldw(const float *p)  { return (double) *p; }
-typedef double ofx_d2v __attribute__((ext_vector_type(2)));
-typedef float ofx_f2v __attribute__((ext_vector_type(2)));
-#ifdef OFX_NT_LOAD
-OFX_DEV double2 ldw2(const double2 *p)
-{
-    const ofx_d2v v = __builtin_nontemporal_load(reinterpret_cast<const ofx_d2v *>(p));
-    return make_double2(v.x, v.y);
-}
-#else
 OFX_DEV double2 ldw2(const double2 *p) { return *p; }
-#endif
 OFX_DEV double2 ldw2(const float2 *p)  { float2 v = *p; return make_double2((double) v.x, (double) v.y); }
 OFX_DEV double4 ldw4(const double4 *p) { return *p; }
 OFX_DEV double4 ldw4(const float4 *p)
@@ -32,16 +22,30 @@ OFX_DEV double4 ldw4(const float4 *p)
 }
 OFX_DEV void stn(double *p, double v) { *p = v; }
 OFX_DEV void stn(float *p, double v)  { *p = (float) v; }
-#ifdef OFX_NT_STORE
-OFX_DEV void stn2(double2 *p, double2 v)
+OFX_DEV void stn2(double2 *p, double2 v) { *p = v; }
+OFX_DEV void stn2(float2 *p, double2 v)  { *p = make_float2((float) v.x, (float) v.y); }
+// Non-temporal stores for results that no kernel will find in cache again (working set of the level
+// larger than the 256 MiB Infinity Cache): measured +3.7 % on the 4K iteration kernel, -3 % at 1080p
+// where the ping-pong output of one launch is still resident when the next launch reads it.
+typedef double ofx_d2v __attribute__((ext_vector_type(2)));
+typedef float ofx_f2v __attribute__((ext_vector_type(2)));
+OFX_DEV void stn2_nt(double2 *p, double2 v)
 {
-    ofx_d2v w; w.x = v.x; w.y = v.y;
+    ofx_d2v w;
+    w.x = v.x; w.y = v.y;
     __builtin_nontemporal_store(w, reinterpret_cast<ofx_d2v *>(p));
 }
-#else
-OFX_DEV void stn2(double2 *p, double2 v) { *p = v; }
-#endif
-OFX_DEV void stn2(float2 *p, double2 v)  { *p = make_float2((float) v.x, (float) v.y); }
+OFX_DEV void stn2_nt(float2 *p, double2 v)
+{
+    ofx_f2v w;
+    w.x = (float) v.x; w.y = (float) v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<ofx_f2v *>(p));
+}
+template <bool NT, typename V> OFX_DEV void stn2_sel(V *p, double2 v)
+{
+    if (NT) stn2_nt(p, v);
+    else stn2(p, v);
+}
 OFX_DEV void stn4(double4 *p, double4 v) { *p = v; }
 OFX_DEV void stn4(float4 *p, double4 v)
 {

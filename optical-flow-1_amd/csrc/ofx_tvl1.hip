@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
 #else
 #define OFX_ITER2_BOUNDS __launch_bounds__(256)
 #endif
-template <typename T>
+template <typename T, bool NT>
 __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
     const typename Pix<T>::v2 *__restrict__ Uin, typename Pix<T>::v2 *__restrict__ Uout,
     const typename Pix<T>::v2 *__restrict__ P1in, typename Pix<T>::v2 *__restrict__ P1out,
@@ -341,7 +341,7 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
             uB0 = tvl1_primal<T>(uA2, a2, r2c, pA1a, pA1b, l11, l21, pA2a.y, pA2b.y, lef, rig, y - 2 == 0, y - 2 == ny - 1,
                                  l_t, theta);
             if (owner && y - 2 < yend) {
-                stn2(at(Uout, so - 2 * row2), uB0);
+                stn2_sel<NT>(at(Uout, so - 2 * row2), uB0);
                 accB += (uB0.x - uA2.x) * (uB0.x - uA2.x) + (uB0.y - uA2.y) * (uB0.y - uA2.y);
             }
         }
@@ -352,8 +352,8 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
             double2 q1, q2;
             tvl1_dual<T>(pA2a, pA2b, uB1, n1, n2, uB0, rig, y - 3 == ny - 1, taut, q1, q2);
             if (owner) {
-                stn2(at(P1out, so - 3 * row2), q1);
-                stn2(at(P2out, so - 3 * row2), q2);
+                stn2_sel<NT>(at(P1out, so - 3 * row2), q1);
+                stn2_sel<NT>(at(P2out, so - 3 * row2), q2);
             }
         }
         // advance the pipeline by one row
@@ -537,6 +537,8 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
     S.fixed = P.fixed;
     S.pairs = pairs;
     const int base = L.cur;
+    // one launch touches 15 storage elements per pixel; beyond the Infinity Cache its output is streamed out
+    const bool nt_stores = (double) nx * ny * 15.0 * sizeof(T) > 300e6;
     // launch unit u (a pair, or a single iteration) reads half (base + u) & 1 and writes the other one
     auto single = [&](int unit, int check, int slot, double thr) -> int {
         const int in = (base + unit) & 1, out = in ^ 1;
@@ -549,9 +551,14 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
     auto launch = [&](int k, int cnt, double thr) -> int {
         if (cnt == 1) return single(pairs ? k / 2 : k, k, k, thr);
         const int in = (base + k / 2) & 1, out = in ^ 1;
-        hipLaunchKernelGGL(k_tvl1_iter2<T>, grid2, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out],
-                           L.P2[in], L.P2[out], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
-                           strips2_pad, l_t, theta, taut, thr);
+        if (nt_stores)
+            hipLaunchKernelGGL((k_tvl1_iter2<T, true>), grid2, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out],
+                               L.P2[in], L.P2[out], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
+                               strips2_pad, l_t, theta, taut, thr);
+        else
+            hipLaunchKernelGGL((k_tvl1_iter2<T, false>), grid2, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out],
+                               L.P2[in], L.P2[out], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
+                               strips2_pad, l_t, theta, taut, thr);
         OFX_LAUNCH_CHECK(ctx);
         return OFX_OK;
     };
