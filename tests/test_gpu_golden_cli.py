@@ -124,3 +124,32 @@ def test_other_front_ends_run(synth, tmp_path):
     g = load("brox_p1_96x64")
     f = read_flo(tmp_path / "x.flo")
     assert np.array_equal(f, np.stack([g["u"], g["v"]], axis=-1).astype(np.float32))
+
+
+def test_batch_front_end_writes_the_same_flo_as_tvl1flow(orc, synth, tmp_path):
+    """optical-flow-1_amd/batch_run.py on one GPU: 3 pairs from PGM files -> 3 .flo files, byte-identical to
+    the single-pair results (and, rehearsing the 2-rank path over gloo on the same GPU, identical again)."""
+    import sys
+    nx, ny = 128, 96
+    lines = []
+    want = []
+    for k in range(3):
+        I0, I1 = synth.pair("P1", nx, ny, k)
+        write_pgm(tmp_path / ("a%d.pgm" % k), I0)
+        write_pgm(tmp_path / ("b%d.pgm" % k), I1)
+        lines.append("%s %s out%d.flo" % (tmp_path / ("a%d.pgm" % k), tmp_path / ("b%d.pgm" % k), k))
+        uo, vo, _, _ = orc.tvl1_multiscale(I0, I1, nscales=4)      # auto: 1 + log2(160/16) = 4.32 -> 4
+        want.append(np.stack([uo, vo], axis=-1).astype(np.float32))
+    (tmp_path / "pairs.txt").write_text("\n".join(lines) + "\n")
+    script = os.path.join(ROOT, "optical-flow-1_amd", "batch_run.py")
+    r = subprocess.run([sys.executable, script, "--list", str(tmp_path / "pairs.txt"), "--out-dir", str(tmp_path / "o1")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k in range(3):
+        assert np.array_equal(read_flo(tmp_path / "o1" / ("out%d.flo" % k)), want[k])
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", script, "--list", str(tmp_path / "pairs.txt"),
+                        "--out-dir", str(tmp_path / "o2"), "--backend", "gloo"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k in range(3):
+        assert np.array_equal(read_flo(tmp_path / "o2" / ("out%d.flo" % k)), want[k])
