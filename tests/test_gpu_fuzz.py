@@ -1,0 +1,79 @@
+"""Randomised sizes and parameters (seeded): the C-ABI TV-L1 path against the oracle, and the operators on
+ragged sizes.  Everything stays small enough for the oracle to finish in a fraction of a second."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def cases(seed, n):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        nx, ny = int(rng.integers(24, 200)), int(rng.integers(24, 160))
+        zf = float(rng.choice([0.5, 0.5, 0.6, 0.75, 0.8]))
+        # deepest pyramid whose coarsest level still takes the zoom gaussian (radius (int)(5 sigma)+1 < size)
+        sigma = 0.6 * np.sqrt(1.0 / (zf * zf) - 1.0)
+        rad = int(5 * sigma) + 1
+        ns, w, h = 1, nx, ny
+        while ns < 4 and min(w, h) > max(rad, 5) + 1 and min(int(w * zf + 0.5), int(h * zf + 0.5)) > 6:
+            w, h = int(w * zf + 0.5), int(h * zf + 0.5)
+            ns += 1
+        out.append(dict(nx=nx, ny=ny, pair=str(rng.choice(["P0", "P1"])), k=int(rng.integers(0, 5)),
+                        kw=dict(tau=float(rng.choice([0.25, 0.2, 0.1])), lam=float(rng.choice([0.15, 0.05, 0.4])),
+                                theta=float(rng.choice([0.3, 0.1, 0.5])), nscales=int(rng.integers(1, ns + 1)), zfactor=zf,
+                                warps=int(rng.integers(1, 5)), epsilon=float(rng.choice([0.01, 0.05, 0.002, 0.0])))))
+    return out
+
+
+@pytest.mark.parametrize("c", cases(2026, 24), ids=lambda c: "%dx%d-%s-ns%d-w%d-z%g-e%g" % (
+    c["nx"], c["ny"], c["pair"], c["kw"]["nscales"], c["kw"]["warps"], c["kw"]["zfactor"], c["kw"]["epsilon"]))
+def test_tvl1_random_configurations(gpu64, orc, synth, c):
+    I0, I1 = synth.pair(c["pair"], c["nx"], c["ny"], c["k"])
+    uo, vo, it_o, err_o = orc.tvl1_multiscale(I0, I1, **c["kw"])
+    ug, vg = gpu64.tvl1_multiscale(I0, I1, **c["kw"])
+    st = gpu64.stats()
+    assert np.array_equal(st.iterations(), it_o)
+    assert np.abs(ug - uo).max() < 1e-9 and np.abs(vg - vo).max() < 1e-9
+    assert np.allclose(st.errors(), err_o, rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_operators_ragged_sizes(gpu64, orc, seed):
+    rng = np.random.default_rng(100 + seed)
+    nx, ny = int(rng.integers(2, 140)), int(rng.integers(2, 90))
+    a, b = rng.standard_normal((ny, nx)), rng.standard_normal((ny, nx))
+    assert np.array_equal(gpu64.divergence(a, b), orc.divergence(a, b))
+    for g, o in zip(gpu64.forward_gradient(a), orc.forward_gradient(a)):
+        assert np.array_equal(g, o)
+    for g, o in zip(gpu64.centered_gradient(a), orc.centered_gradient(a)):
+        assert np.array_equal(g, o)
+    for name in ("dxx", "dyy", "dxy"):
+        assert np.array_equal(getattr(gpu64, name)(a), getattr(orc, name)(a))
+    u, v = rng.standard_normal((ny, nx)) * 5, rng.standard_normal((ny, nx)) * 5
+    assert np.array_equal(gpu64.bicubic_warp(a, u, v, True), orc.bicubic_warp(a, u, v, True))
+    assert np.array_equal(gpu64.bicubic_warp(a, u, v, False), orc.bicubic_warp(a, u, v, False))
+    if min(nx, ny) > 7:
+        assert np.array_equal(gpu64.gaussian(a, 0.8), orc.gaussian(a, 0.8))
+        assert np.array_equal(gpu64.zoom_out(a, 0.5), orc.zoom_out(a, 0.5))
+        assert np.array_equal(gpu64.zoom_in(a, nx + 3, ny + 5), orc.zoom_in(a, nx + 3, ny + 5))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_sor_random_configurations(gpu64, orc, synth, seed):
+    rng = np.random.default_rng(300 + seed)
+    nx, ny = int(rng.integers(20, 90)), int(rng.integers(16, 70))
+    I1, I2 = synth.pair("P1", nx, ny, seed)
+    z = np.zeros((ny, nx))
+    kw = dict(alpha=float(rng.choice([7.0, 20.0, 40.0])), warps=int(rng.integers(1, 4)), TOL=float(rng.choice([1e-4, 1e-3])),
+              maxiter=int(rng.choice([5, 150])))
+    uo, vo, it_o = orc.hs_single_scale(I1, I2, z, z, **kw)
+    ug, vg = gpu64.hs_single_scale(I1, I2, z, z, **kw)
+    assert list(gpu64.stats().iterations()[0]) == it_o
+    assert np.abs(ug - uo).max() < 1e-11 and np.abs(vg - vo).max() < 1e-11
+    kw = dict(alpha=float(rng.choice([50.0, 18.0])), gamma=float(rng.choice([10.0, 0.0, 7.0])), nscales=1, nu=0.5,
+              TOL=1e-4, inner=int(rng.integers(1, 3)), outer=int(rng.integers(1, 4)))
+    uo, vo, it_o = orc.brox_spatial(I1, I2, **kw)
+    ug, vg = gpu64.brox_spatial(I1, I2, **kw)
+    assert np.array_equal(gpu64.stats().iterations(), it_o)
+    assert np.abs(ug - uo).max() < 1e-10 and np.abs(vg - vo).max() < 1e-10
