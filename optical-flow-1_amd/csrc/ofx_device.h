@@ -46,6 +46,32 @@ template <bool NT, typename V> OFX_DEV void stn2_sel(V *p, double2 v)
     if (NT) stn2_nt(p, v);
     else stn2(p, v);
 }
+// Predicated stores without control flow.  A store inside `if (owner) ...` sits in its own basic block, and
+// the compiler's s_waitcnt placement then has to assume at the top of a marching loop that NO store was
+// issued after the prefetch loads -- it waits with vmcnt(0), i.e. for the stores of the previous step as
+// well, and the whole write latency (~1.4 us per marching step) lands on the critical path of a wave.
+// Buffer stores drop lanes whose offset is outside the descriptor's range, so the predicate becomes part
+// of the address (OFX_OOB for lanes that must not write), the instruction is issued unconditionally and
+// the loads are awaited with an exact vmcnt(#stores).
+#define OFX_OOB 0xFFFFFFF0u
+typedef unsigned ofx_u4v __attribute__((ext_vector_type(4)));
+typedef unsigned ofx_u2v __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t ofx_rsrc;
+// raw buffer over [p, p + bytes): stride 0, 32-bit data format (descriptor word 3 of the gfx9 family)
+OFX_DEV ofx_rsrc make_rsrc(void *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, bytes, 0x00020000); }
+template <bool NT> OFX_DEV void bst2(ofx_rsrc r, unsigned byte_off, double2 v, const double2 *)
+{
+    ofx_u4v w;
+    __builtin_memcpy(&w, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, byte_off, 0, NT ? 2 : 0);
+}
+template <bool NT> OFX_DEV void bst2(ofx_rsrc r, unsigned byte_off, double2 v, const float2 *)
+{
+    const float2 f = make_float2((float) v.x, (float) v.y);
+    ofx_u2v w;
+    __builtin_memcpy(&w, &f, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, byte_off, 0, NT ? 2 : 0);
+}
 OFX_DEV void stn4(double4 *p, double4 v) { *p = v; }
 OFX_DEV void stn4(float4 *p, double4 v)
 {

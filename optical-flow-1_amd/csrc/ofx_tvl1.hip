@@ -198,6 +198,8 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
     if (!tvl1_continues(prev1, prev2, check, nx * ny, eps2)) return;
     if (idle) return;
 
+    const unsigned level_bytes = (unsigned) nx * (unsigned) ny * E2;
+    const ofx_rsrc rU = make_rsrc(Uout, level_bytes), rP1 = make_rsrc(P1out, level_bytes), rP2 = make_rsrc(P2out, level_bytes);
     double acc = 0.0;
     double2 un_prev = make_double2(0.0, 0.0);                // u_new of row y-1
     double2 p1_prev = make_double2(0.0, 0.0), p2_prev = make_double2(0.0, 0.0);
@@ -208,26 +210,28 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
         if (y + 1 <= yend && y + 1 < ny) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + row2);
 
         double2 un = make_double2(0.0, 0.0);
+        unsigned st_u = OFX_OOB, st_p = OFX_OOB;
         if (y < ny) {
             const double l11 = wave_shift_up(cur.p1.x);
             const double l21 = wave_shift_up(cur.p2.x);
             un = tvl1_primal<T>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0, y == ny - 1,
                                 l_t, theta);
             if (owner && y < yend) {
-                stn2(at(Uout, so), un);
+                st_u = so;
                 acc += (un.x - cur.u.x) * (un.x - cur.u.x) + (un.y - cur.u.y) * (un.y - cur.u.y);   // :159-160
             }
         }
+        double2 q1 = make_double2(0.0, 0.0), q2 = q1;
         if (y > y0) {
             const double r1 = wave_shift_down(un_prev.x);
             const double r2 = wave_shift_down(un_prev.y);
-            double2 q1, q2;
             tvl1_dual<T>(p1_prev, p2_prev, un_prev, r1, r2, un, rig, y - 1 == ny - 1, taut, q1, q2);
-            if (owner) {
-                stn2(at(P1out, so - row2), q1);
-                stn2(at(P2out, so - row2), q2);
-            }
+            if (owner) st_p = so - row2;
         }
+        // always issued; lanes / steps with nothing to write are out of the buffer's range (ofx_device.h)
+        bst2<false>(rU, st_u, un, Uout);
+        bst2<false>(rP1, st_p, q1, P1out);
+        bst2<false>(rP2, st_p, q2, P2out);
         un_prev = un;
         p1_prev = cur.p1;
         p2_prev = cur.p2;
@@ -303,6 +307,8 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
     if (idle) return;
 
     const double2 z2 = make_double2(0.0, 0.0);
+    const unsigned level_bytes = (unsigned) nx * (unsigned) ny * E2;
+    const ofx_rsrc rU = make_rsrc(Uout, level_bytes), rP1 = make_rsrc(P1out, level_bytes), rP2 = make_rsrc(P2out, level_bytes);
     double accA = 0.0, accB = 0.0;
     double2 uA0 = z2, uA1 = z2, uA2 = z2;                    // u_A of rows y, y-1, y-2
     double2 a1 = z2, a2 = z2;                                // (I1wx, I1wy) of rows y-1, y-2
@@ -335,27 +341,29 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
             pAnb.x = rnd_to<T>(pAnb.x); pAnb.y = rnd_to<T>(pAnb.y);
         }
         // S3: u_B(y-2)
+        unsigned st3 = OFX_OOB, st4 = OFX_OOB;
         if (y - 2 >= y0 && y - 2 <= yend && y - 2 <= ny - 1) {
             const double l11 = wave_shift_up(pA1a.x);
             const double l21 = wave_shift_up(pA1b.x);
             uB0 = tvl1_primal<T>(uA2, a2, r2c, pA1a, pA1b, l11, l21, pA2a.y, pA2b.y, lef, rig, y - 2 == 0, y - 2 == ny - 1,
                                  l_t, theta);
             if (owner && y - 2 < yend) {
-                stn2_sel<NT>(at(Uout, so - 2 * row2), uB0);
+                st3 = so - 2 * row2;
                 accB += (uB0.x - uA2.x) * (uB0.x - uA2.x) + (uB0.y - uA2.y) * (uB0.y - uA2.y);
             }
         }
         // S4: p_B(y-3)
+        double2 q1 = z2, q2 = z2;
         if (y - 3 >= y0 && y - 3 < yend) {
             const double n1 = wave_shift_down(uB1.x);
             const double n2 = wave_shift_down(uB1.y);
-            double2 q1, q2;
             tvl1_dual<T>(pA2a, pA2b, uB1, n1, n2, uB0, rig, y - 3 == ny - 1, taut, q1, q2);
-            if (owner) {
-                stn2_sel<NT>(at(P1out, so - 3 * row2), q1);
-                stn2_sel<NT>(at(P2out, so - 3 * row2), q2);
-            }
+            if (owner) st4 = so - 3 * row2;
         }
+        // the three stores of this step: always issued, lanes / steps with nothing to write are out of range
+        bst2<NT>(rU, st3, uB0, Uout);
+        bst2<NT>(rP1, st4, q1, P1out);
+        bst2<NT>(rP2, st4, q2, P2out);
         // advance the pipeline by one row
         uA2 = uA1; uA1 = uA0;
         a2 = a1; a1 = cur.a;

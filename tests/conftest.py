@@ -44,10 +44,19 @@ def oracle_mod():
 
 
 @pytest.fixture(scope="session")
-def orc(oracle_mod):
-    o = oracle_mod.Oracle()
-    o.set_num_threads(1)
-    return o
+def _orc_session(oracle_mod):
+    return oracle_mod.Oracle()
+
+
+@pytest.fixture
+def orc(_orc_session):
+    """The CPU checker in its only deterministic configuration.  Thread count and SOR order are
+    process-global state of liboracle.so (omp_set_num_threads), and the reference's SOR sweeps are a racy
+    `omp parallel for`: a test that raised the thread count must not leak it into the next SOR comparison,
+    so both are reset before every test."""
+    _orc_session.set_num_threads(1)
+    _orc_session.set_sor_order(0)
+    return _orc_session
 
 
 @pytest.fixture(scope="session")

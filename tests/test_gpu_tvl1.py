@@ -135,7 +135,10 @@ def test_full_size_1080p_matches_oracle(gpu64, oracle_mod, synth):
     o = oracle_mod.Oracle()
     o.set_num_threads(min(oracle_mod.host_cores(), 32))
     I0, I1 = synth.pair("P1", 1920, 1080)
-    uo, vo, it_o, _ = o.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+    try:
+        uo, vo, it_o, _ = o.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+    finally:
+        o.set_num_threads(1)        # process-global (OpenMP): the SOR checks need the single-thread oracle
     ug, vg = gpu64.tvl1_multiscale(I0, I1, nscales=5, **PAR)
     assert np.array_equal(gpu64.stats().iterations(), it_o)
     assert aepe(ug, vg, uo, vo) < 1e-4
