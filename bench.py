@@ -51,7 +51,11 @@ def parse():
     ap.add_argument("--pair", default="P1")
     ap.add_argument("--fixed-steps", type=int, default=2, help="fixed-work passes for the roofline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--lockstep", type=int, default=4,
+                    help="pairs per lockstep group (they share every kernel launch of one context)")
+    ap.add_argument("--concurrency", type=int, default=0, help="override the library's concurrency hint (0 = streams)")
+    ap.add_argument("--variants", type=int, default=8, help="distinct synthetic pairs cycled through by the steps")
+    ap.add_argument("--streams", type=int, default=2,
                     help="image pairs in flight per GPU, each on its own context / HIP stream (SURVEY 8e: >= 2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--rows", type=int, default=0)
@@ -152,11 +156,14 @@ def main():
     synth = importlib.import_module("optical-flow-1_amd.synth")
     prec = ofx_mod.F64 if a.precision == "f64" else ofx_mod.F32
     tdt = torch.float64 if a.precision == "f64" else torch.float32
-    nstreams = max(1, min(a.streams, max(a.steps, 1)))
+    lockstep = max(1, min(a.lockstep, 16, max(a.steps, 1)))
+    nstreams = max(1, min(a.streams, -(-max(a.steps, 1) // lockstep)))
+    in_flight = nstreams * lockstep
     ctxs = [ofx_mod.Ofx(local, prec) for _ in range(nstreams)]
     ctx = ctxs[0]
     for c_ in ctxs:
-        c_.set_option("concurrency", nstreams)
+        c_.set_option("concurrency", a.concurrency or nstreams)
+        c_.set_option("lockstep", lockstep)
         if a.rows:
             c_.set_option("rows_per_wave", a.rows)
         if a.chunk:
@@ -165,25 +172,31 @@ def main():
             c_.set_option("rows_per_wave2", a.rows2)
 
     nx, ny = a.nx, a.ny
-    I0, I1 = synth.pair(a.pair, nx, ny, rank)
-    dI0 = torch.from_numpy(I0).to(dev, tdt).contiguous()
-    dI1 = torch.from_numpy(I1).to(dev, tdt).contiguous()
-    flo = torch.empty((max(a.steps, 1), ny, nx, 2), dtype=torch.float32, device=dev)
+    # a short synthetic sequence: `variants` distinct pairs (SURVEY 8d batch variants), resident in HBM; step i of
+    # rank r solves variant (r * steps + i) % variants, so the pairs of a lockstep group converge differently
+    nvar = max(1, a.variants)
+    host_pairs = [synth.pair(a.pair, nx, ny, k) for k in range(nvar)]
+    dI0s = [torch.from_numpy(p[0]).to(dev, tdt).contiguous() for p in host_pairs]
+    dI1s = [torch.from_numpy(p[1]).to(dev, tdt).contiguous() for p in host_pairs]
+    var_of = lambda i: (rank * max(a.steps, 1) + i) % nvar
+    flo = torch.empty((max(a.steps, in_flight, 1), ny, nx, 2), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     def step(i, c_=None):
         c_ = c_ or ctx
-        c_.tvl1_multiscale_dev(dI0.data_ptr(), dI1.data_ptr(), flo[i].data_ptr(), nx, ny, **PAR)
+        v = var_of(i)
+        c_.tvl1_multiscale_dev(dI0s[v].data_ptr(), dI1s[v].data_ptr(), flo[i % flo.shape[0]].data_ptr(), nx, ny, **PAR)
         return c_.stats().work_pix_iters
 
     def run_steps(n):
-        """n steps (pairs) through the library's batch entry point: pair i runs on context i % nstreams, so
-        `nstreams` pairs are in flight (one host thread + one HIP stream each, inside libofx): while one
-        pair waits for a convergence poll or crawls through a launch-bound coarse level, another one fills
+        """n steps (pairs) through the library's batch entry point: the pairs are cut into lockstep groups of
+        `lockstep` pairs that share every kernel launch; group q runs on context q % nstreams (one host thread +
+        one HIP stream each, inside libofx), so while one group waits for a convergence poll another one fills
         the GPU."""
-        if nstreams == 1:
+        if in_flight == 1:
             return sum(step(i) for i in range(n))
-        work = ofx_mod.tvl1_batch_dev(ctxs, [dI0.data_ptr()] * n, [dI1.data_ptr()] * n,
+        work = ofx_mod.tvl1_batch_dev(ctxs, [dI0s[var_of(i)].data_ptr() for i in range(n)],
+                                      [dI1s[var_of(i)].data_ptr() for i in range(n)],
                                       [flo[i % flo.shape[0]].data_ptr() for i in range(n)], nx, ny, **PAR)
         return sum(work)
 
@@ -197,7 +210,7 @@ def main():
 
     log("rank %d/%d: inputs resident, warmup" % (rank, world))
     for i in range(a.warmup):
-        run_steps(nstreams)
+        run_steps(in_flight)
     log("warmup done")
     gathered = None
     if world > 1 and rank == 0:
@@ -226,10 +239,10 @@ def main():
         # (a) throughput of the fixed-work job with the same number of pairs in flight as the headline
         for c_ in ctxs:
             c_.set_option("fixed_work", 1)
-        run_steps(nstreams)                                  # warm
+        run_steps(in_flight)                                 # warm
         fence()
         tq0 = time.perf_counter()
-        fw_par = run_steps(a.fixed_steps * nstreams)
+        fw_par = run_steps(a.fixed_steps * in_flight)
         fence()
         tq = time.perf_counter() - tq0
         # (b) one pair alone with HIP events around the iteration launches: per-kernel times for the roofline
@@ -253,11 +266,11 @@ def main():
         for c_ in ctxs:
             c_.set_option("fixed_work", 0)
         ctx.set_option("profile", 0)
-        ctx.set_option("concurrency", nstreams)
+        ctx.set_option("concurrency", a.concurrency or nstreams)
         log("fixed-work pass: %d steps in %.3f s" % (a.fixed_steps, tf))
         fixed = {"value": round(fw_par / tq / 1e6, 1), "unit": "Mpix*warp-iters/s",
-                 "ms_per_step": round(tq / (a.fixed_steps * nstreams) * 1e3, 3), "steps": a.fixed_steps * nstreams,
-                 "pairs_in_flight": nstreams, "iterations_per_warp": 300,
+                 "ms_per_step": round(tq / (a.fixed_steps * in_flight) * 1e3, 3), "steps": a.fixed_steps * in_flight,
+                 "pairs_in_flight": in_flight, "iterations_per_warp": 300,
                  "single_pair": {"value": round(fw / tf / 1e6, 1), "ms_per_step": round(tf / a.fixed_steps * 1e3, 3)},
                  "levels": [{"size": "%dx%d" % (st.nx[s_], st.ny[s_]), "iter_us": round(lv_ms[s_] * 1e3 / max(lv_n[s_], 1), 2),
                              "ms_per_step": round(lv_ms[s_] / a.fixed_steps, 2)} for s_ in range(PAR["nscales"])]}
@@ -297,8 +310,10 @@ def main():
         "dtype": a.precision, "data": "synthetic",
         "config": {"workload": "tvl1flow %dx%d pair (synthetic %s), nscales=5 warps=5 tau=0.25 lambda=0.15 theta=0.3 "
                                "zfactor=0.5 epsilon=0.01; one pair per step per GPU" % (nx, ny, a.pair),
-                   "pairs_per_gpu": a.steps, "pairs_in_flight_per_gpu": nstreams,
-                   "parallelism": "%d GPU(s) x %d pairs in flight (one HIP stream each), RCCL gather of .flo at end" % (world, nstreams),
+                   "pairs_per_gpu": a.steps, "pairs_in_flight_per_gpu": in_flight, "lockstep_group": lockstep,
+                   "streams_per_gpu": nstreams, "distinct_pairs": nvar,
+                   "parallelism": "%d GPU(s) x %d HIP stream(s) x lockstep groups of %d pairs, RCCL gather of .flo at end"
+                                  % (world, nstreams, lockstep),
                    "pix_iters_per_step": work / max(a.steps, 1) / world},
         "pairs_per_s": round(a.steps * world / elapsed, 3),
     }

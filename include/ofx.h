@@ -89,6 +89,7 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         0 = colour-ordered sweeps (much faster, result drifts by ~1e-5..1e-3 px)
  *   "sor_batch"      sweeps in flight per batch in exact mode (default 64)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
+ *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default 4, at most 16)
  *   "concurrency"    number of contexts that will be solving on the same device at the same time
  *                         (default 1); a scheduling hint for the strip height of the TV-L1 kernels
  *   "rows_per_wave", "rows_per_wave2", "chunk"   tuning of the TV-L1 kernels / launch batching */
@@ -141,13 +142,24 @@ int ofx_tvl1_multiscale_dev(ofx_ctx *ctx, const void *dI0, const void *dI1, void
                             int nx, int ny, double tau, double lambda, double theta, int nscales,
                             double zfactor, int warps, double epsilon, int verbose);
 
+/* Lockstep group: n_pairs (1..16) independent pairs of the same size solved by ONE context with shared
+ * kernel launches (every level array holds the pairs back to back, blockIdx.y = pair).  Each pair keeps
+ * its own stopping test, iteration counts and ping-pong phase, so every flow is bit-identical to what
+ * ofx_tvl1_multiscale_dev computes for that pair alone; what is shared is the launch latency of the small
+ * pyramid levels and the host's convergence polls.  dI0/dI1/d_flo: n_pairs device pointers (layout of
+ * ofx_tvl1_multiscale_dev); stats_out: optional, n_pairs records.  Asynchronous like the single-pair call. */
+int ofx_tvl1_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *dI0, const void *const *dI1,
+                       void *const *d_flo, int nx, int ny, double tau, double lambda, double theta,
+                       int nscales, double zfactor, int warps, double epsilon, ofx_stats *stats_out);
+
 /* Batch of independent pairs on ONE device (the unit of parallel work is the image pair).
- * Pair k is solved on context ctxs[k % n_ctx]; one host thread per context drives its pairs, so n_ctx
- * pairs are in flight at a time (each context = its own HIP stream and workspace; all contexts must
- * live on the same device and have the same precision).  Arrays dI0/dI1/d_flo hold n_pairs device
+ * The pairs are cut into lockstep groups of `lockstep` consecutive pairs (option of ctxs[0], default 4);
+ * group q is solved on context ctxs[q % n_ctx] with ofx_tvl1_group_dev, one host thread per context, so
+ * n_ctx groups are in flight at a time (each context = its own HIP stream and workspace; all contexts
+ * must live on the same device and have the same precision).  Arrays dI0/dI1/d_flo hold n_pairs device
  * pointers with the layout of ofx_tvl1_multiscale_dev.  work_pix_iters (optional, n_pairs doubles)
  * receives sum n_iter*nx_s*ny_s per pair.  Returns after every pair has been fully solved (all
- * streams synchronised); the first failing pair's status is returned. */
+ * streams synchronised); the first failing group's status is returned. */
 int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI0, const void *const *dI1,
                        void *const *d_flo, int n_pairs, int nx, int ny, double tau, double lambda,
                        double theta, int nscales, double zfactor, int warps, double epsilon,

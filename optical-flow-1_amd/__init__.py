@@ -99,6 +99,8 @@ def lib():
         "ofx_tvl1_single_scale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _d, _i, _d, _i]),
         "ofx_tvl1_multiscale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _d, _i, _d, _i, _d, _i]),
         "ofx_tvl1_multiscale_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _d, _d, _i, _d, _i, _d, _i]),
+        "ofx_tvl1_group_dev": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _d, _d, _d, _i, _d, _i, _d,
+                                    C.POINTER(Stats)]),
         "ofx_tvl1_batch_dev": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _d, _d, _d,
                                     _i, _d, _i, _d, C.POINTER(_d)]),
         "ofx_tvl1_iterations": (_i, [_vp] + [_dp] * 9 + [_i, _i, _d, _d, _d, _i, C.POINTER(_d)]),
@@ -130,8 +132,9 @@ def _f64(a):
 
 def tvl1_batch_dev(ctxs, dI0, dI1, d_flo, nx, ny, tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5,
                    epsilon=0.01):
-    """ofx_tvl1_batch_dev: lists of device pointers (ints), one entry per pair; pair k runs on ctxs[k % len(ctxs)]
-    with len(ctxs) pairs in flight.  Returns the per-pair work (pixel-iterations)."""
+    """ofx_tvl1_batch_dev: lists of device pointers (ints), one entry per pair; the pairs are cut into lockstep
+    groups (option "lockstep" of ctxs[0], default 4), group q runs on ctxs[q % len(ctxs)] with len(ctxs) groups in
+    flight.  Returns the per-pair work (pixel-iterations)."""
     n = len(dI0)
     arr = lambda xs: (_vp * len(xs))(*xs)
     work = (_d * max(n, 1))()
@@ -270,6 +273,17 @@ class Ofx:
         """dI0, dI1, d_flo: device pointers (ints).  Enqueues on the context's stream."""
         self._ck(self.L.ofx_tvl1_multiscale_dev(self.h, dI0, dI1, d_flo, nx, ny, tau, lam, theta, nscales, zfactor,
                                                 warps, epsilon, verbose))
+
+    def tvl1_group_dev(self, dI0, dI1, d_flo, nx, ny, tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5,
+                       epsilon=0.01):
+        """ofx_tvl1_group_dev: lists of device pointers (ints), all pairs solved in lockstep on this context.
+        Returns the per-pair Stats records."""
+        n = len(dI0)
+        arr = lambda xs: (_vp * len(xs))(*xs)
+        st = (Stats * max(n, 1))()
+        self._ck(self.L.ofx_tvl1_group_dev(self.h, n, arr(dI0), arr(dI1), arr(d_flo), nx, ny, tau, lam, theta, nscales,
+                                           zfactor, warps, epsilon, st))
+        return [st[i] for i in range(n)]
 
     def tvl1_iterations(self, u1, u2, p11, p12, p21, p22, I1wx, I1wy, rho_c, tau, lam, theta, n_iter):
         """In place on the six state arrays (float64, C-contiguous); returns the last error."""

@@ -62,6 +62,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->rows_per_wave2 = 0;
     ctx->fuse2 = 1;             // two TV-L1 iterations per launch
     ctx->concurrency = 1;
+    ctx->lockstep = 0;
     ctx->chunk = 0;             // 0 = pick per level
     ctx->fixed_work = 0;
     ctx->sor_exact = 1;
@@ -73,8 +74,8 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc((void **) &ctx->d_err, sizeof(double) * OFX_TVL1_MAX_ITERATIONS * OFX_NSHARD) == hipSuccess;
     ctx->d_err_cap = OFX_TVL1_MAX_ITERATIONS;
-    ok = ok && hipMalloc((void **) &ctx->d_state, sizeof(OfxIterState)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **) &ctx->h_state, sizeof(OfxIterState) * OFX_NPOLL, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void **) &ctx->d_state, sizeof(OfxIterState) * OFX_MAX_GROUP) == hipSuccess;
+    ok = ok && hipHostMalloc((void **) &ctx->h_state, sizeof(OfxIterState) * OFX_NPOLL * OFX_MAX_GROUP, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < OFX_NPOLL; i++)
         ok = hipEventCreateWithFlags(&ctx->ev_poll[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->ev_t0) == hipSuccess && hipEventCreate(&ctx->ev_t1) == hipSuccess;
@@ -131,6 +132,11 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "concurrency")) {
         if (value < 1 || value > 64) return ofx_fail(ctx, OFX_ERR_ARG, "concurrency out of range");
         ctx->concurrency = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "lockstep")) {
+        if (value < 0 || value > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "lockstep out of range");
+        ctx->lockstep = (int) value;
         return OFX_OK;
     }
     if (!strcmp(name, "sor_exact")) { ctx->sor_exact = value != 0; return OFX_OK; }

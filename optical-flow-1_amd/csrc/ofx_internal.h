@@ -14,6 +14,7 @@
 
 #define OFX_NSHARD 64          // error-accumulator shards per iteration slot (= wave size)
 #define OFX_NPOLL  4           // in-flight convergence polls
+#define OFX_MAX_GROUP 16       // image pairs one context can solve in lockstep (TV-L1 groups)
 
 // What the finalize kernel publishes to the host after every chunk of iterations.
 struct OfxIterState {
@@ -41,8 +42,8 @@ struct ofx_ctx {
     // convergence machinery
     double       *d_err;    // [d_err_cap][OFX_NSHARD] per-iteration squared-update sums
     int           d_err_cap;
-    OfxIterState *d_state;  // device copy
-    OfxIterState *h_state;  // pinned ring [OFX_NPOLL]
+    OfxIterState *d_state;  // device copy [OFX_MAX_GROUP]
+    OfxIterState *h_state;  // pinned ring [OFX_NPOLL][OFX_MAX_GROUP]
     hipEvent_t    ev_poll[OFX_NPOLL];
     hipEvent_t    ev_t0, ev_t1;
 
@@ -52,6 +53,7 @@ struct ofx_ctx {
     int rows_per_wave2;
     int fuse2;
     int concurrency;    // contexts expected to share the device (tuning hint, default 1)
+    int lockstep;       // pairs per lockstep group in ofx_tvl1_batch_dev (0 = default)
     int chunk;
     int fixed_work;
     int sor_exact;      // 1: reference sweep order (hyperplane-pipelined), 0: colour order (fast)

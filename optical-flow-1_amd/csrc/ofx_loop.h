@@ -55,22 +55,35 @@ struct LoopSpec {
 };
 
 int ofx_loop_reserve(ofx_ctx *ctx, int max_iter);                      // err slots for max_iter sweeps
-int ofx_loop_finalize(ofx_ctx *ctx, const LoopSpec &L, int start, int launched, OfxIterState *host_slot);
-
-// Runs the loop.  launch(k, count, thr) must enqueue every kernel of sweeps k .. k+count-1 on ctx->stream
-// (count is 2 only when L.pairs and at least two sweeps remain; pairs always start at an even k);
-// kernels take (ctx->d_err, k, thr) and use the helpers above.  With L.pairs the second sweep of a pair
-// runs even when the first one ended the loop; if that happens (n odd), redo(n-1) must recompute sweep
-// n-1 alone from the pair's untouched input buffers.  Returns the reference's n and error.
-template <class LaunchFn, class RedoFn>
-static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, RedoFn redo, int *n_out, double *err_out,
-                        float *ms_out)
+// G problems in lockstep: problem g owns err slots [g * slots_per_problem, ...) and state entry g.
+int ofx_loop_finalize_group(ofx_ctx *ctx, const LoopSpec &L, int G, int slots_per_problem, int start, int launched,
+                            OfxIterState *host_slot);
+static inline int ofx_loop_finalize(ofx_ctx *ctx, const LoopSpec &L, int start, int launched, OfxIterState *host_slot)
 {
-    OFX_TRY(ofx_loop_reserve(ctx, L.max_iter + 1));      // +1: scratch slot for the redo's error
+    return ofx_loop_finalize_group(ctx, L, 1, 0, start, launched, host_slot);
+}
+
+// Runs the loop for G independent problems of the same size in LOCKSTEP (TV-L1: G image pairs solved by
+// the same launches, blockIdx.y = problem; the SOR solvers use G = 1).  Problem g accumulates into err slots
+// g * (L.max_iter + 1) + k and stops on its own test -- its launches turn into no-ops while the others
+// continue; the host stops enqueueing when every problem is done.
+//   launch(k, count, thr) must enqueue every kernel of sweeps k .. k+count-1 of ALL problems on ctx->stream
+// (count is 2 only when L.pairs and at least two sweeps remain; pairs always start at an even k); kernels
+// take (ctx->d_err, k, thr) and use the helpers above.  With L.pairs the second sweep of a pair runs even
+// when the first one ended the loop; if that happens for problem g (n odd), redo(g, n-1) must recompute
+// sweep n-1 of that problem alone from the pair's untouched input buffers.  Returns the reference's n and
+// error per problem.
+template <class LaunchFn, class RedoFn>
+static int ofx_run_loop_group(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn launch, RedoFn redo, int *n_out,
+                              double *err_out, float *ms_out)
+{
+    if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "loop group of %d problems", G);
+    const int per = L.max_iter + 1;                      // +1: scratch slot for the redo's error
+    OFX_TRY(ofx_loop_reserve(ctx, G * per));
     LoopSpec S = L;
     if (S.fixed) S.thr = -1.0;          // error >= 0 always passes `error > -1`
-    OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) S.max_iter * OFX_NSHARD, ctx->stream));
-    OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
+    OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) G * per * OFX_NSHARD, ctx->stream));
+    OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState) * G, ctx->stream));
     if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
 
     // head / tail count the polls issued / consumed.  A context that has the device to itself keeps two
@@ -81,7 +94,7 @@ static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, RedoFn
     const int max_out = ctx->concurrency > 1 ? 1 : 2;
     int launched = 0, head = 0, tail = 0, slot_of[2] = {0, 0};
     bool stop = false;
-    OfxIterState fin = {0, 0, 0.0};
+    OfxIterState fin[OFX_MAX_GROUP];
     int chunk = S.chunk < 1 ? 1 : S.chunk;
     if (S.pairs) chunk += chunk & 1;
     for (;;) {
@@ -94,7 +107,7 @@ static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, RedoFn
                 launched += cnt;
             }
             const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
-            OFX_TRY(ofx_loop_finalize(ctx, S, first, launched, &ctx->h_state[slot]));
+            OFX_TRY(ofx_loop_finalize_group(ctx, S, G, per, first, launched, &ctx->h_state[slot * OFX_MAX_GROUP]));
             slot_of[head & 1] = slot;
             OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
             head++;
@@ -102,24 +115,38 @@ static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, RedoFn
         if (tail == head) break;
         const int slot = slot_of[tail & 1];
         OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
-        const OfxIterState st = ctx->h_state[slot];
+        bool all = true;
+        for (int g = 0; g < G; g++) {
+            fin[g] = ctx->h_state[slot * OFX_MAX_GROUP + g];
+            all = all && fin[g].done;
+        }
         tail++;
-        if (st.done) {
+        if (all) {
             // A poll still in flight covers launches that are no-ops (their stopping test already
             // fails); it is not drained -- stream order keeps it ahead of whatever is enqueued next.
             stop = true;
-            fin = st;
             break;
         }
     }
     if (!stop) return ofx_fail(ctx, OFX_ERR_HIP, "iteration loop ended without a final state");
-    if (S.pairs && (fin.n & 1) && fin.n != S.max_iter) OFX_TRY(redo(fin.n - 1));
+    for (int g = 0; g < G; g++)
+        if (S.pairs && (fin[g].n & 1) && fin[g].n != S.max_iter) OFX_TRY(redo(g, fin[g].n - 1));
     if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
-    *n_out = fin.n;
-    *err_out = fin.error;
+    for (int g = 0; g < G; g++) {
+        n_out[g] = fin[g].n;
+        err_out[g] = fin[g].error;
+    }
     if (ms_out) {
         OFX_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
         OFX_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev_t0, ctx->ev_t1));
     }
     return OFX_OK;
+}
+
+// single problem (the SOR solvers); redo(k) as above without the problem index
+template <class LaunchFn, class RedoFn>
+static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, RedoFn redo, int *n_out, double *err_out,
+                        float *ms_out)
+{
+    return ofx_run_loop_group(ctx, L, 1, launch, [&](int, int k) { return redo(k); }, n_out, err_out, ms_out);
 }

@@ -1,13 +1,17 @@
 // ofx_loop.hip -- finalize kernel and host helpers of the convergence-loop machinery (ofx_loop.h).
 #include "ofx_loop.h"
 
-// One block (16 waves).  Scans the error slots of sweeps [start, launched) and publishes how many
-// sweeps really ran (the reference's n), whether the loop is over, and the criterion value at exit.
-__global__ __launch_bounds__(1024) void k_loop_finalize(const double *__restrict__ err, int start, int launched,
-                                                        int max_iter, int size, double thr, int crit,
+// One block (16 waves) per problem of a lockstep group.  Scans the error slots of sweeps [start, launched)
+// and publishes how many sweeps really ran (the reference's n), whether the loop is over, and the criterion
+// value at exit.
+__global__ __launch_bounds__(1024) void k_loop_finalize(const double *__restrict__ err, int slots_per_problem, int start,
+                                                        int launched, int max_iter, int size, double thr, int crit,
                                                         OfxIterState *st, OfxIterState *host_st)
 {
     extern __shared__ double s_err[];
+    err += (size_t) blockIdx.x * slots_per_problem * OFX_NSHARD;
+    st += blockIdx.x;
+    host_st += blockIdx.x;
     if (st->done) {                                         // an earlier chunk already ended the loop
         if (threadIdx.x == 0) *host_st = *st;
         return;
@@ -33,11 +37,12 @@ __global__ __launch_bounds__(1024) void k_loop_finalize(const double *__restrict
     }
 }
 
-int ofx_loop_finalize(ofx_ctx *ctx, const LoopSpec &L, int start, int launched, OfxIterState *host_slot)
+int ofx_loop_finalize_group(ofx_ctx *ctx, const LoopSpec &L, int G, int slots_per_problem, int start, int launched,
+                            OfxIterState *host_slot)
 {
     const size_t shmem = sizeof(double) * (size_t) (launched - start);
-    hipLaunchKernelGGL(k_loop_finalize, dim3(1), dim3(1024), shmem, ctx->stream, (const double *) ctx->d_err, start,
-                       launched, L.max_iter, L.size, L.thr, L.crit, ctx->d_state, host_slot);
+    hipLaunchKernelGGL(k_loop_finalize, dim3(G), dim3(1024), shmem, ctx->stream, (const double *) ctx->d_err,
+                       slots_per_problem, start, launched, L.max_iter, L.size, L.thr, L.crit, ctx->d_state, host_slot);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
     return OFX_OK;

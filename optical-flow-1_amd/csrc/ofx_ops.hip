@@ -470,28 +470,30 @@ template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>
     return OFX_OK;
 }
 
-template <typename T>
-int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nxx, int nyy, int nscales, double zfactor,
-                     double sigma, std::vector<ImgLevel<T>> &lv)
+int op_pyramid_sizes(ofx_ctx *ctx, int nxx, int nyy, int nscales, double zfactor, int *nxs, int *nys)
 {
     if (nscales < 1 || nscales > OFX_MAX_SCALES) return ofx_fail(ctx, OFX_ERR_ARG, "nscales=%d", nscales);
     if (nxx < 2 || nyy < 2) return ofx_fail(ctx, OFX_ERR_ARG, "image %dx%d too small", nxx, nyy);
     if (!(zfactor > 0.0) || !(zfactor < 1.0)) return ofx_fail(ctx, OFX_ERR_ARG, "zoom factor %g", zfactor);
-    lv.resize(nscales);
     int nx = nxx, ny = nyy;
     for (int s = 0; s < nscales; s++) {
-        if (s) ofx_zoom_size(lv[s - 1].nx, lv[s - 1].ny, &nx, &ny, zfactor);
+        if (s) ofx_zoom_size(nxs[s - 1], nys[s - 1], &nx, &ny, zfactor);
         if (nx < 2 || ny < 2) return ofx_fail(ctx, OFX_ERR_SIGMA, "scale %d would be %dx%d", s, nx, ny);
-        lv[s].nx = nx;
-        lv[s].ny = ny;
-        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &lv[s].A));
-        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &lv[s].B));
+        nxs[s] = nx;
+        nys[s] = ny;
     }
-    T *tmpA, *tmpB;
-    double *scr;
-    OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpA));
-    OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpB));
-    OFX_TRY(ofx_alloc(ctx, (size_t) 2 * MM_BLOCKS + 2, &scr));
+    return OFX_OK;
+}
+
+size_t op_pyramid_scratch_doubles() { return (size_t) 2 * MM_BLOCKS + 2; }
+
+// lv[s] = sizes and DESTINATION arrays of every level (caller-allocated); tmpA / tmpB: full-size scratch
+// images, scr: op_pyramid_scratch_doubles() doubles.
+template <typename T>
+int op_build_pyramid_into(ofx_ctx *ctx, const T *dA, const T *dB, int nscales, double zfactor, double sigma,
+                          const std::vector<ImgLevel<T>> &lv, T *tmpA, T *tmpB, double *scr)
+{
+    const int nxx = lv[0].nx, nyy = lv[0].ny;
     OFX_TRY(op_normalize2<T>(ctx, dA, dB, lv[0].A, lv[0].B, nxx * nyy, scr));
     OFX_TRY(op_gaussian<T>(ctx, lv[0].A, tmpA, nxx, nyy, sigma));
     OFX_TRY(op_gaussian<T>(ctx, lv[0].B, tmpA, nxx, nyy, sigma));
@@ -500,6 +502,27 @@ int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nxx, int nyy, i
         OFX_TRY(op_zoom_out<T>(ctx, lv[s - 1].B, lv[s].B, tmpA, tmpB, lv[s - 1].nx, lv[s - 1].ny, zfactor));
     }
     return OFX_OK;
+}
+
+template <typename T>
+int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nxx, int nyy, int nscales, double zfactor,
+                     double sigma, std::vector<ImgLevel<T>> &lv)
+{
+    int nxs[OFX_MAX_SCALES], nys[OFX_MAX_SCALES];
+    OFX_TRY(op_pyramid_sizes(ctx, nxx, nyy, nscales, zfactor, nxs, nys));
+    lv.resize(nscales);
+    for (int s = 0; s < nscales; s++) {
+        lv[s].nx = nxs[s];
+        lv[s].ny = nys[s];
+        OFX_TRY(ofx_alloc(ctx, (size_t) nxs[s] * nys[s], &lv[s].A));
+        OFX_TRY(ofx_alloc(ctx, (size_t) nxs[s] * nys[s], &lv[s].B));
+    }
+    T *tmpA, *tmpB;
+    double *scr;
+    OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpA));
+    OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpB));
+    OFX_TRY(ofx_alloc(ctx, op_pyramid_scratch_doubles(), &scr));
+    return op_build_pyramid_into<T>(ctx, dA, dB, nscales, zfactor, sigma, lv, tmpA, tmpB, scr);
 }
 
 // ---- explicit instantiations -----------------------------------------------------------------------
@@ -523,7 +546,9 @@ int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nxx, int nyy, i
     template int op_bicubic_at<T>(ofx_ctx *, const T *, const double *, const double *, double *, int, int, int, int);           \
     template int op_grad_pack<T>(ofx_ctx *, const T *, Pix<T>::v4 *, int, int);                                        \
     template int op_build_pyramid<T>(ofx_ctx *, const T *, const T *, int, int, int, double, double,                   \
-                                     std::vector<ImgLevel<T>> &);
+                                     std::vector<ImgLevel<T>> &);                                                      \
+    template int op_build_pyramid_into<T>(ofx_ctx *, const T *, const T *, int, double, double,                        \
+                                          const std::vector<ImgLevel<T>> &, T *, T *, double *);
 
 OFX_INSTANTIATE(double)
 OFX_INSTANTIATE(float)

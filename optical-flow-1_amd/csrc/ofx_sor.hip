@@ -218,10 +218,10 @@ static int sor_exact_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int q
         }
         LS.max_iter = ns;
         const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
-        OFX_TRY(ofx_loop_finalize(ctx, LS, 0, ns, &ctx->h_state[slot]));
+        OFX_TRY(ofx_loop_finalize(ctx, LS, 0, ns, &ctx->h_state[slot * OFX_MAX_GROUP]));
         OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
         OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
-        *out = ctx->h_state[slot];
+        *out = ctx->h_state[slot * OFX_MAX_GROUP];
         return OFX_OK;
     };
     while (error > TOL && niter < maxiter) {

@@ -149,19 +149,51 @@ OFX_DEV bool tvl1_continues(double prev1, double prev2, int k, int size, double 
     return true;
 }
 
+// ---- lockstep groups ------------------------------------------------------------------------------------
+// Every array of a level holds G image pairs back to back (pair g at element offset g * nx * ny) and one
+// launch serves all of them: blockIdx.y = pair.  The pairs of a group run the same launches k = 0, 1, ...
+// but converge on their own: each has its own error slots (err + g * err_stride) and its own ping-pong
+// phase -- bit g of `inmask` says which half pair g reads in THIS launch (the host knows every pair's n
+// at the end of each loop, so it can keep the phases itself).  A pair whose loop has ended just returns.
+template <typename V> struct PairHalves {
+    const V *in;
+    V       *out;
+};
+template <typename V>
+OFX_DEV PairHalves<V> pick_halves(V *h0, V *h1, unsigned inmask, int g, size_t n)
+{
+    const bool in1 = (inmask >> g) & 1u;
+    PairHalves<V> r;
+    r.in = (in1 ? h1 : h0) + (size_t) g * n;
+    r.out = (in1 ? h0 : h1) + (size_t) g * n;
+    return r;
+}
+
 // ---- one iteration per launch ------------------------------------------------------------------------
 // `slot` is where the error of this iteration is accumulated; `check` = index of this iteration in the
-// loop (0 = no stopping test, used for the unconditional redo of a single iteration).
+// loop (0 = no stopping test, used for the unconditional redo of a single iteration).  g0 = first pair of
+// the launch (the redo runs on one pair: gridDim.y = 1, g0 = that pair).
 template <typename T>
 __global__ __launch_bounds__(256) void k_tvl1_iter(
-    const typename Pix<T>::v2 *__restrict__ Uin, typename Pix<T>::v2 *__restrict__ Uout,
-    const typename Pix<T>::v2 *__restrict__ P1in, typename Pix<T>::v2 *__restrict__ P1out,
-    const typename Pix<T>::v2 *__restrict__ P2in, typename Pix<T>::v2 *__restrict__ P2out,
-    const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ R, double *__restrict__ err, int check, int slot,
-    int nx, int ny, int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2)
+    typename Pix<T>::v2 *__restrict__ U0, typename Pix<T>::v2 *__restrict__ U1,
+    typename Pix<T>::v2 *__restrict__ P10, typename Pix<T>::v2 *__restrict__ P11,
+    typename Pix<T>::v2 *__restrict__ P20, typename Pix<T>::v2 *__restrict__ P21,
+    const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int check, int slot,
+    int nx, int ny, int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2,
+    unsigned inmask, int g0, int err_stride)
 {
+    using v2 = typename Pix<T>::v2;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = g0 + blockIdx.y;
+    const size_t npix = (size_t) nx * ny;
+    const PairHalves<v2> hu = pick_halves(U0, U1, inmask, g, npix), h1 = pick_halves(P10, P11, inmask, g, npix),
+                         h2 = pick_halves(P20, P21, inmask, g, npix);
+    const v2 *__restrict__ Uin = hu.in, *__restrict__ P1in = h1.in, *__restrict__ P2in = h2.in;
+    v2 *__restrict__ Uout = hu.out, *__restrict__ P1out = h1.out, *__restrict__ P2out = h2.out;
+    const v2 *__restrict__ A = Ag + (size_t) g * npix;
+    const T *__restrict__ R = Rg + (size_t) g * npix;
+    double *__restrict__ err = errg + (size_t) g * err_stride;
 
     // The previous iterations' error shards are fetched first and tested last, so the ~2 us memory
     // round trip overlaps with the first row's loads instead of preceding them.
@@ -267,14 +299,25 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(
 #endif
 template <typename T, bool NT>
 __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
-    const typename Pix<T>::v2 *__restrict__ Uin, typename Pix<T>::v2 *__restrict__ Uout,
-    const typename Pix<T>::v2 *__restrict__ P1in, typename Pix<T>::v2 *__restrict__ P1out,
-    const typename Pix<T>::v2 *__restrict__ P2in, typename Pix<T>::v2 *__restrict__ P2out,
-    const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ R, double *__restrict__ err, int k, int nx, int ny,
-    int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2)
+    typename Pix<T>::v2 *__restrict__ U0, typename Pix<T>::v2 *__restrict__ U1,
+    typename Pix<T>::v2 *__restrict__ P10, typename Pix<T>::v2 *__restrict__ P11,
+    typename Pix<T>::v2 *__restrict__ P20, typename Pix<T>::v2 *__restrict__ P21,
+    const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int k, int nx, int ny,
+    int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2, unsigned inmask,
+    int err_stride)
 {
+    using v2 = typename Pix<T>::v2;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = blockIdx.y;
+    const size_t npix = (size_t) nx * ny;
+    const PairHalves<v2> hu = pick_halves(U0, U1, inmask, g, npix), h1 = pick_halves(P10, P11, inmask, g, npix),
+                         h2 = pick_halves(P20, P21, inmask, g, npix);
+    const v2 *__restrict__ Uin = hu.in, *__restrict__ P1in = h1.in, *__restrict__ P2in = h2.in;
+    v2 *__restrict__ Uout = hu.out, *__restrict__ P1out = h1.out, *__restrict__ P2out = h2.out;
+    const v2 *__restrict__ A = Ag + (size_t) g * npix;
+    const T *__restrict__ R = Rg + (size_t) g * npix;
+    double *__restrict__ err = errg + (size_t) g * err_stride;
     const double prev1 = loop_fetch_prev(err, k), prev2 = loop_fetch_prev(err, k - 1);
 
     const int strip = gw % strips_pad, band = gw / strips_pad;
@@ -383,13 +426,20 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
 // Warp + linearisation (src/tvl1flow.cpp:94-109): the three bicubic warps of I1, I1x, I1y share one
 // set of tap indices and one 4-wide gather per tap; writes A = (I1wx, I1wy) and R = rho_c.
 template <typename T>
-__global__ void k_tvl1_warp(const typename Pix<T>::v4 *__restrict__ pack, const T *__restrict__ I0,
-                            const typename Pix<T>::v2 *__restrict__ U, typename Pix<T>::v2 *__restrict__ A,
-                            T *__restrict__ R, int nx, int ny)
+__global__ void k_tvl1_warp(const typename Pix<T>::v4 *__restrict__ packg, const T *__restrict__ I0g,
+                            const typename Pix<T>::v2 *__restrict__ U0, const typename Pix<T>::v2 *__restrict__ U1,
+                            typename Pix<T>::v2 *__restrict__ Ag, T *__restrict__ Rg, int nx, int ny, unsigned curmask)
 {
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= ny) return;
+    const int g = blockIdx.z;                                // pair of the lockstep group
+    const size_t goff = (size_t) g * nx * ny;
+    const typename Pix<T>::v4 *__restrict__ pack = packg + goff;
+    const T *__restrict__ I0 = I0g + goff;
+    const typename Pix<T>::v2 *__restrict__ U = (((curmask >> g) & 1u) ? U1 : U0) + goff;
+    typename Pix<T>::v2 *__restrict__ A = Ag + goff;
+    T *__restrict__ R = Rg + goff;
     const size_t p = (size_t) i * nx + j;
     const double2 u = ldw2(U + p);
     const BicubicTaps t = bicubic_taps(j + u.x, i + u.y, nx, ny);
@@ -415,15 +465,17 @@ __global__ void k_tvl1_warp(const typename Pix<T>::v4 *__restrict__ pack, const 
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
+// One level of a lockstep group: every array holds G pairs back to back (pair g at element g * nx * ny).
 template <typename T> struct Tvl1Level {
     using v2 = typename Pix<T>::v2;
     using v4 = typename Pix<T>::v4;
-    int nx, ny;
+    int nx, ny, G;
     T  *I0, *I1;
     v4 *pack;
     v2 *U[2], *P1[2], *P2[2], *A;
     T  *R;
-    int cur;        // which ping-pong half holds the live u / p
+    unsigned cur;   // bit g: which ping-pong half holds the live u / p of pair g
+    size_t n() const { return (size_t) nx * ny; }
 };
 
 struct Tvl1Params {
@@ -432,19 +484,20 @@ struct Tvl1Params {
     bool fixed;     // run exactly max_iter iterations (stopping test disabled)
 };
 
-template <typename T> static int tvl1_level_alloc(ofx_ctx *ctx, Tvl1Level<T> &L, int nx, int ny, bool images)
+template <typename T> static int tvl1_level_alloc(ofx_ctx *ctx, Tvl1Level<T> &L, int nx, int ny, int G, bool images)
 {
-    const size_t n = (size_t) nx * ny;
+    const size_t n = (size_t) nx * ny * G;
     L.nx = nx;
     L.ny = ny;
+    L.G = G;
     L.cur = 0;
     L.I0 = L.I1 = nullptr;
     L.pack = nullptr;
     if (images) {
         OFX_TRY(ofx_alloc(ctx, n, &L.I0));
         OFX_TRY(ofx_alloc(ctx, n, &L.I1));
-        OFX_TRY(ofx_alloc(ctx, n, &L.pack));
     }
+    OFX_TRY(ofx_alloc(ctx, n, &L.pack));
     for (int h = 0; h < 2; h++) {
         OFX_TRY(ofx_alloc(ctx, n, &L.U[h]));
         OFX_TRY(ofx_alloc(ctx, n, &L.P1[h]));
@@ -455,16 +508,16 @@ template <typename T> static int tvl1_level_alloc(ofx_ctx *ctx, Tvl1Level<T> &L,
     return OFX_OK;
 }
 
-static int tvl1_pick_rows(const ofx_ctx *ctx, int nx, int ny)
+static int tvl1_pick_rows(const ofx_ctx *ctx, int nx, int ny, int G)
 {
     if (ctx->rows_per_wave > 0) return ctx->rows_per_wave;
     // Measured on MI355X (tools/tune_iter.py, profiles/r01_b_rows_sweep.txt): short strips win.  Many
     // short-lived waves hide memory latency better than few long ones (each wave keeps only one row of
     // prefetch in flight), and on the small pyramid levels the launch is a pure latency chain of
     // (rows + 1) dependent marching steps, so the strip height must shrink with the image.
-    const int strips = ofx_cdiv(nx, STRIP_OUT);
-    if ((long) strips * ofx_cdiv(ny, 4) >= 2048) return 4;
-    if ((long) strips * ofx_cdiv(ny, 2) >= 1024) return 2;
+    const long strips = (long) ofx_cdiv(nx, STRIP_OUT) * G;
+    if (strips * ofx_cdiv(ny, 4) >= 2048) return 4;
+    if (strips * ofx_cdiv(ny, 2) >= 1024) return 2;
     return 1;
 }
 
@@ -473,11 +526,12 @@ static int tvl1_pick_rows(const ofx_ctx *ctx, int nx, int ny)
 // launch of W waves takes k = ceil(W / 3072) rounds of about (r + 5) step times.  The best strip height is
 // therefore the SMALLEST r whose wave count still fits k rounds exactly (1080p: r = 12 -> 32 x 90 = 2880
 // waves, one round; r = 8 -> 4320 waves = 1.4 rounds is 9 % slower), minimised over k.  Measured on the
-// bench workload at every pyramid level: profiles/r01_g_rows2_on_bench_workload.txt.
-static int tvl1_pick_rows2(const ofx_ctx *ctx, int nx, int ny)
+// bench workload at every pyramid level: profiles/r01_g_rows2_on_bench_workload.txt.  A lockstep group of
+// G pairs is G times the waves of one pair.
+static int tvl1_pick_rows2(const ofx_ctx *ctx, int nx, int ny, int G)
 {
     if (ctx->rows_per_wave2 > 0) return ctx->rows_per_wave2;
-    const long strips_pad = ofx_cdiv(ofx_cdiv(nx, STRIP2_OUT), 4) * 4;
+    const long strips_pad = (long) ofx_cdiv(ofx_cdiv(nx, STRIP2_OUT), 4) * 4 * G;
     const int rmax = 24;
     int best = rmax;
     long best_cost = -1;
@@ -508,146 +562,182 @@ static int tvl1_pick_rows2(const ofx_ctx *ctx, int nx, int ny)
     return best;
 }
 
-static int tvl1_pick_chunk(const ofx_ctx *ctx, int nx, int ny)
+static int tvl1_pick_chunk(const ofx_ctx *ctx, int nx, int ny, int G)
 {
     if (ctx->chunk > 0) return ctx->chunk;
     // one poll (event wait + host wake-up) costs 20-40 us: a chunk should take about that long, because
     // every launch behind the iteration that ends the loop is a wasted ~2.5 us no-op
-    const double est_us = fmax(5.0, (double) nx * ny * 120.0 / 4.0e6);   // ~4 TB/s, small-level floor 5 us
+    const double est_us = fmax(5.0, (double) nx * ny * G * 120.0 / 4.0e6);   // ~4 TB/s, small-level floor 5 us
     int c = (int) (40.0 / est_us);
     return c < 4 ? 4 : (c > 50 ? 50 : c);
 }
 
-// The inner loop of one warp (src/tvl1flow.cpp:111-182).  On return L.cur points at the half holding
-// the result; *n_out / *err_out are what the reference prints.
+// The inner loop of one warp (src/tvl1flow.cpp:111-182) for all pairs of the group in lockstep.  On return
+// L.cur points at the halves holding the results; n_out[g] / err_out[g] are what the reference prints.
 template <typename T>
 static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, int *n_out, double *err_out,
                                float *ms_out)
 {
-    const int nx = L.nx, ny = L.ny;
+    const int nx = L.nx, ny = L.ny, G = L.G;
     if ((long long) nx * ny >= (1LL << 28)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: image larger than 2^28 pixels");
     const double l_t = P.lambda * P.theta, taut = P.tau / P.theta, theta = P.theta;
     const bool pairs = ctx->fuse2 != 0;
     // geometry of the one-iteration kernel (also used for a trailing single iteration and the redo)
-    const int rows = tvl1_pick_rows(ctx, nx, ny);
+    const int rows = tvl1_pick_rows(ctx, nx, ny, G);
     const int strips_x = ofx_cdiv(nx, STRIP_OUT), strips_pad = ofx_cdiv(strips_x, 4) * 4;
-    const dim3 grid((unsigned) (strips_pad / 4) * ofx_cdiv(ny, rows)), block(256);
+    const unsigned gx1 = (unsigned) (strips_pad / 4) * ofx_cdiv(ny, rows);
+    const dim3 block(256);
     // geometry of the fused two-iteration kernel
-    const int rows2 = tvl1_pick_rows2(ctx, nx, ny);
+    const int rows2 = tvl1_pick_rows2(ctx, nx, ny, G);
     const int strips2_x = ofx_cdiv(nx, STRIP2_OUT), strips2_pad = ofx_cdiv(strips2_x, 4) * 4;
-    const dim3 grid2((unsigned) (strips2_pad / 4) * ofx_cdiv(ny, rows2));
+    const dim3 grid2((unsigned) (strips2_pad / 4) * ofx_cdiv(ny, rows2), G);
     LoopSpec S;
     S.max_iter = P.max_iter;
     S.size = nx * ny;
     S.thr = P.epsilon * P.epsilon;
     S.crit = OFX_CRIT_MEAN;
-    S.chunk = tvl1_pick_chunk(ctx, nx, ny);
+    S.chunk = tvl1_pick_chunk(ctx, nx, ny, G);
     S.fixed = P.fixed;
     S.pairs = pairs;
-    const int base = L.cur;
+    const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
+    const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
+    const unsigned base = L.cur & all;
     // one launch touches 15 storage elements per pixel; beyond the Infinity Cache its output is streamed out
-    const bool nt_stores = (double) nx * ny * 15.0 * sizeof(T) > 300e6;
-    // launch unit u (a pair, or a single iteration) reads half (base + u) & 1 and writes the other one
-    auto single = [&](int unit, int check, int slot, double thr) -> int {
-        const int in = (base + unit) & 1, out = in ^ 1;
-        hipLaunchKernelGGL(k_tvl1_iter<T>, grid, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out], L.P2[in],
-                           L.P2[out], L.A, (const T *) L.R, ctx->d_err, check, slot, nx, ny, rows, strips_x, strips_pad,
-                           l_t, theta, taut, thr);
+    const bool nt_stores = (double) nx * ny * G * 15.0 * sizeof(T) > 300e6;
+    // launch unit u (a pair of iterations, or a single one) reads half (base_g + u) & 1 of pair g and writes
+    // the other one
+    auto single = [&](int unit, int check, int slot, double thr, int g0, int gy) -> int {
+        const unsigned inmask = (unit & 1) ? (base ^ all) : base;
+        hipLaunchKernelGGL(k_tvl1_iter<T>, dim3(gx1, gy), block, 0, ctx->stream, L.U[0], L.U[1], L.P1[0], L.P1[1], L.P2[0],
+                           L.P2[1], L.A, (const T *) L.R, ctx->d_err, check, slot, nx, ny, rows, strips_x, strips_pad,
+                           l_t, theta, taut, thr, inmask, g0, err_stride);
         OFX_LAUNCH_CHECK(ctx);
         return OFX_OK;
     };
     auto launch = [&](int k, int cnt, double thr) -> int {
-        if (cnt == 1) return single(pairs ? k / 2 : k, k, k, thr);
-        const int in = (base + k / 2) & 1, out = in ^ 1;
+        if (cnt == 1) return single(pairs ? k / 2 : k, k, k, thr, 0, G);
+        const unsigned inmask = ((k / 2) & 1) ? (base ^ all) : base;
         if (nt_stores)
-            hipLaunchKernelGGL((k_tvl1_iter2<T, true>), grid2, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out],
-                               L.P2[in], L.P2[out], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
-                               strips2_pad, l_t, theta, taut, thr);
+            hipLaunchKernelGGL((k_tvl1_iter2<T, true>), grid2, block, 0, ctx->stream, L.U[0], L.U[1], L.P1[0], L.P1[1],
+                               L.P2[0], L.P2[1], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
+                               strips2_pad, l_t, theta, taut, thr, inmask, err_stride);
         else
-            hipLaunchKernelGGL((k_tvl1_iter2<T, false>), grid2, block, 0, ctx->stream, L.U[in], L.U[out], L.P1[in], L.P1[out],
-                               L.P2[in], L.P2[out], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
-                               strips2_pad, l_t, theta, taut, thr);
+            hipLaunchKernelGGL((k_tvl1_iter2<T, false>), grid2, block, 0, ctx->stream, L.U[0], L.U[1], L.P1[0], L.P1[1],
+                               L.P2[0], L.P2[1], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
+                               strips2_pad, l_t, theta, taut, thr, inmask, err_stride);
         OFX_LAUNCH_CHECK(ctx);
         return OFX_OK;
     };
-    // the loop ended on the first iteration of a pair: recompute that iteration alone (no stopping
-    // test, error into the scratch slot) from the pair's input half, overwriting the pair's output
-    auto redo = [&](int k) -> int { return single(k / 2, 0, S.max_iter, -1.0); };
-    OFX_TRY(ofx_run_loop(ctx, S, launch, redo, n_out, err_out, ms_out));
-    L.cur = (base + (pairs ? (*n_out + 1) / 2 : *n_out)) & 1;
+    // the loop of pair g ended on the first iteration of a fused pair: recompute that iteration alone (no
+    // stopping test, error into the scratch slot) from the pair's input half, overwriting the pair's output
+    auto redo = [&](int g, int k) -> int { return single(k / 2, 0, S.max_iter, -1.0, g, 1); };
+    OFX_TRY(ofx_run_loop_group(ctx, S, G, launch, redo, n_out, err_out, ms_out));
+    unsigned cur = 0;
+    for (int g = 0; g < G; g++) {
+        const unsigned units = (unsigned) (pairs ? (n_out[g] + 1) / 2 : n_out[g]);
+        cur |= ((((base >> g) & 1u) + units) & 1u) << g;
+    }
+    L.cur = cur;
     return OFX_OK;
 }
 
-// src/tvl1flow.cpp:46-212 on device-resident level data; L.U[L.cur] holds the incoming flow.
+// src/tvl1flow.cpp:46-212 on device-resident level data; L.U[half of L.cur] holds the incoming flows.
+// stats[g] = work record of pair g.
 template <typename T>
-static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, int scale)
+static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, int scale, ofx_stats *stats)
 {
-    const int nx = L.nx, ny = L.ny;
-    const size_t n = (size_t) nx * ny;
-    const dim3 g2(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), b2(64, 4);
+    const int nx = L.nx, ny = L.ny, G = L.G;
+    const size_t n = L.n();
+    const dim3 g2(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), G), b2(64, 4);
     if (nx < 2 || ny < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: level %dx%d too small", nx, ny);
 
-    OFX_TRY(op_grad_pack<T>(ctx, L.I1, L.pack, nx, ny));                                                // :84
-    OFX_TRY(op_fill2<T>(ctx, L.P1[L.cur], n));                                                          // :87-90
-    OFX_TRY(op_fill2<T>(ctx, L.P2[L.cur], n));
+    for (int g = 0; g < G; g++) OFX_TRY(op_grad_pack<T>(ctx, L.I1 + g * n, L.pack + g * n, nx, ny));       // :84
+    // p = 0 in the half each pair's u lives in (:87-90); both halves are cleared when the phases differ
+    for (int h = 0; h < 2; h++) {
+        bool used = false;
+        for (int g = 0; g < G; g++) used = used || (((L.cur >> g) & 1u) == (unsigned) h);
+        if (!used) continue;
+        OFX_TRY(op_fill2<T>(ctx, L.P1[h], n * G));
+        OFX_TRY(op_fill2<T>(ctx, L.P2[h], n * G));
+    }
 
-    ofx_stats &S = ctx->stats;
     for (int w = 0; w < P.warps; w++) {
-        hipLaunchKernelGGL(k_tvl1_warp<T>, g2, b2, 0, ctx->stream, L.pack, (const T *) L.I0, L.U[L.cur], L.A, L.R,
-                           nx, ny);                                                                      // :94-109
+        hipLaunchKernelGGL(k_tvl1_warp<T>, g2, b2, 0, ctx->stream, L.pack, (const T *) L.I0, L.U[0], L.U[1], L.A, L.R,
+                           nx, ny, L.cur);                                                               // :94-109
         OFX_LAUNCH_CHECK(ctx);
         // p lives in the same ping-pong half as u
-        int it = 0;
-        double error = 0.0;
+        int it[OFX_MAX_GROUP];
+        double error[OFX_MAX_GROUP];
         float ms = 0.f;
-        OFX_TRY(tvl1_run_iterations<T>(ctx, L, P, &it, &error, ctx->profile ? &ms : nullptr));
-        if (P.verbose) fprintf(stderr, "Warping: %d, Iterations: %d, Error: %f\n", w, it, error);      // :184-188
-        if (scale < OFX_MAX_SCALES) {
-            if (w < OFX_MAX_SOLVES) { S.iters[scale][w] = it; S.error[scale][w] = error; }
-            S.iter_ms[scale] += ms;
-            S.iter_launches[scale] += it;
+        OFX_TRY(tvl1_run_iterations<T>(ctx, L, P, it, error, ctx->profile ? &ms : nullptr));
+        if (P.verbose && G == 1) fprintf(stderr, "Warping: %d, Iterations: %d, Error: %f\n", w, it[0], error[0]);   // :184-188
+        for (int g = 0; g < G; g++) {
+            ofx_stats &S = stats[g];
+            if (scale < OFX_MAX_SCALES) {
+                if (w < OFX_MAX_SOLVES) { S.iters[scale][w] = it[g]; S.error[scale][w] = error[g]; }
+                S.iter_ms[scale] += ms;
+                S.iter_launches[scale] += it[g];
+            }
+            S.work_pix_iters += (double) it[g] * nx * ny;
         }
-        S.work_pix_iters += (double) it * nx * ny;
     }
     return OFX_OK;
 }
 
-static void stats_begin(ofx_ctx *ctx, int nscales, int nsolves)
+static void stats_begin(ofx_stats *st, int nscales, int nsolves)
 {
-    memset(&ctx->stats, 0, sizeof(ctx->stats));
-    ctx->stats.nscales = nscales;
-    ctx->stats.nsolves = nsolves;
+    memset(st, 0, sizeof(*st));
+    st->nscales = nscales;
+    st->nsolves = nsolves;
 }
 
-// src/tvl1flow.cpp:219-328.  dI0 / dI1: device images of storage type T.  On success *Lout[0] holds the flow.
+// src/tvl1flow.cpp:219-328 for G pairs in lockstep.  dI0[g] / dI1[g]: device images of storage type T.  On
+// success lv[0].U[half of lv[0].cur] holds the flows.
 template <typename T>
-static int tvl1_multiscale_dev(ofx_ctx *ctx, const T *dI0, const T *dI1, int nxx, int nyy, const Tvl1Params &P,
-                               int nscales, double zfactor, std::vector<Tvl1Level<T>> &lv)
+static int tvl1_multiscale_dev(ofx_ctx *ctx, int G, const T *const *dI0, const T *const *dI1, int nxx, int nyy,
+                               const Tvl1Params &P, int nscales, double zfactor, std::vector<Tvl1Level<T>> &lv,
+                               ofx_stats *stats)
 {
     if (P.warps < 1) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: warps=%d", P.warps);
+    if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: group of %d pairs", G);
 
-    stats_begin(ctx, nscales, P.warps);
-    std::vector<ImgLevel<T>> img;
-    OFX_TRY(op_build_pyramid<T>(ctx, dI0, dI1, nxx, nyy, nscales, zfactor, TVL1_PRESMOOTHING_SIGMA, img));   // :255-275
+    int nxs[OFX_MAX_SCALES], nys[OFX_MAX_SCALES];
+    OFX_TRY(op_pyramid_sizes(ctx, nxx, nyy, nscales, zfactor, nxs, nys));
+    for (int g = 0; g < G; g++) {
+        stats_begin(&stats[g], nscales, P.warps);
+        for (int s = 0; s < nscales; s++) { stats[g].nx[s] = nxs[s]; stats[g].ny[s] = nys[s]; }
+    }
     lv.resize(nscales);
-    for (int s = 0; s < nscales; s++) {
-        OFX_TRY(tvl1_level_alloc<T>(ctx, lv[s], img[s].nx, img[s].ny, false));
-        lv[s].I0 = img[s].A;
-        lv[s].I1 = img[s].B;
-        OFX_TRY(ofx_alloc(ctx, (size_t) img[s].nx * img[s].ny, &lv[s].pack));
-        ctx->stats.nx[s] = img[s].nx;
-        ctx->stats.ny[s] = img[s].ny;
+    for (int s = 0; s < nscales; s++) OFX_TRY(tvl1_level_alloc<T>(ctx, lv[s], nxs[s], nys[s], G, true));
+    {                                                                                              // :255-275
+        T *tmpA, *tmpB;
+        double *scr;
+        OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpA));
+        OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpB));
+        OFX_TRY(ofx_alloc(ctx, op_pyramid_scratch_doubles(), &scr));
+        std::vector<ImgLevel<T>> img(nscales);
+        for (int g = 0; g < G; g++) {
+            for (int s = 0; s < nscales; s++) {
+                img[s].nx = nxs[s];
+                img[s].ny = nys[s];
+                img[s].A = lv[s].I0 + g * lv[s].n();
+                img[s].B = lv[s].I1 + g * lv[s].n();
+            }
+            OFX_TRY(op_build_pyramid_into<T>(ctx, dI0[g], dI1[g], nscales, zfactor, TVL1_PRESMOOTHING_SIGMA, img, tmpA,
+                                             tmpB, scr));
+        }
     }
     Tvl1Level<T> &C = lv[nscales - 1];
-    OFX_TRY(op_fill2<T>(ctx, C.U[0], (size_t) C.nx * C.ny));                                     // :278-280
+    OFX_TRY(op_fill2<T>(ctx, C.U[0], C.n() * G));                                                // :278-280
 
     for (int s = nscales - 1; s >= 0; s--) {                                                     // :283
-        if (P.verbose) fprintf(stderr, "Scale %d: %dx%d\n", s, lv[s].nx, lv[s].ny);
-        OFX_TRY(tvl1_single_scale_dev<T>(ctx, lv[s], P, s));
+        if (P.verbose && G == 1) fprintf(stderr, "Scale %d: %dx%d\n", s, lv[s].nx, lv[s].ny);
+        OFX_TRY(tvl1_single_scale_dev<T>(ctx, lv[s], P, s, stats));
         if (!s) break;
         lv[s - 1].cur = 0;
-        OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U[lv[s].cur], lv[s - 1].U[0], lv[s].nx, lv[s].ny, lv[s - 1].nx,
-                                   lv[s - 1].ny, 1.0 / zfactor));                                // :302-309
+        for (int g = 0; g < G; g++)
+            OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U[(lv[s].cur >> g) & 1u] + g * lv[s].n(), lv[s - 1].U[0] + g * lv[s - 1].n(),
+                                       lv[s].nx, lv[s].ny, lv[s - 1].nx, lv[s - 1].ny, 1.0 / zfactor));   // :302-309
     }
     return OFX_OK;
 }
@@ -682,11 +772,12 @@ static int tvl1_multiscale_host(ofx_ctx *ctx, const double *I0, const double *I1
     OFX_TRY(upload_image<T>(ctx, I0, n, &dI0));
     OFX_TRY(upload_image<T>(ctx, I1, n, &dI1));
     std::vector<Tvl1Level<T>> lv;
-    OFX_TRY(tvl1_multiscale_dev<T>(ctx, dI0, dI1, nx, ny, P, nscales, zfactor, lv));
+    const T *a = dI0, *b = dI1;
+    OFX_TRY(tvl1_multiscale_dev<T>(ctx, 1, &a, &b, nx, ny, P, nscales, zfactor, lv, &ctx->stats));
     double *d1, *d2;
     OFX_TRY(ofx_alloc(ctx, n, &d1));
     OFX_TRY(ofx_alloc(ctx, n, &d2));
-    OFX_TRY(op_deinterleave2<T>(ctx, lv[0].U[lv[0].cur], d1, d2, n));
+    OFX_TRY(op_deinterleave2<T>(ctx, lv[0].U[lv[0].cur & 1u], d1, d2, n));
     OFX_HIP(ctx, hipMemcpyAsync(u1, d1, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     OFX_HIP(ctx, hipMemcpyAsync(u2, d2, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -708,13 +799,18 @@ extern "C" int ofx_tvl1_multiscale(ofx_ctx *ctx, const double *I0, const double 
     return s;
 }
 
+// G device-resident pairs in lockstep; stats = G records
 template <typename T>
-static int tvl1_multiscale_devapi(ofx_ctx *ctx, const void *dI0, const void *dI1, void *d_flo, int nx, int ny,
-                                  const Tvl1Params &P, int nscales, double zfactor)
+static int tvl1_group_devapi(ofx_ctx *ctx, int G, const void *const *dI0, const void *const *dI1, void *const *d_flo,
+                             int nx, int ny, const Tvl1Params &P, int nscales, double zfactor, ofx_stats *stats)
 {
     std::vector<Tvl1Level<T>> lv;
-    OFX_TRY(tvl1_multiscale_dev<T>(ctx, (const T *) dI0, (const T *) dI1, nx, ny, P, nscales, zfactor, lv));
-    return op_to_flo<T>(ctx, lv[0].U[lv[0].cur], (float2 *) d_flo, (size_t) nx * ny);
+    OFX_TRY(tvl1_multiscale_dev<T>(ctx, G, (const T *const *) dI0, (const T *const *) dI1, nx, ny, P, nscales, zfactor, lv,
+                                   stats));
+    const size_t n = (size_t) nx * ny;
+    for (int g = 0; g < G; g++)
+        OFX_TRY(op_to_flo<T>(ctx, lv[0].U[(lv[0].cur >> g) & 1u] + g * n, (float2 *) d_flo[g], n));
+    return OFX_OK;
 }
 
 extern "C" int ofx_tvl1_multiscale_dev(ofx_ctx *ctx, const void *dI0, const void *dI1, void *d_flo, int nx, int ny,
@@ -725,9 +821,33 @@ extern "C" int ofx_tvl1_multiscale_dev(ofx_ctx *ctx, const void *dI0, const void
     if (!dI0 || !dI1 || !d_flo) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: NULL pointer");
     const double t0 = ofx_now_ms();
     const Tvl1Params P = make_params(ctx, tau, lambda, theta, warps, epsilon, verbose);
-    int s = ctx->precision == OFX_F64 ? tvl1_multiscale_devapi<double>(ctx, dI0, dI1, d_flo, nx, ny, P, nscales, zfactor)
-                                      : tvl1_multiscale_devapi<float>(ctx, dI0, dI1, d_flo, nx, ny, P, nscales, zfactor);
+    int s = ctx->precision == OFX_F64
+                ? tvl1_group_devapi<double>(ctx, 1, &dI0, &dI1, &d_flo, nx, ny, P, nscales, zfactor, &ctx->stats)
+                : tvl1_group_devapi<float>(ctx, 1, &dI0, &dI1, &d_flo, nx, ny, P, nscales, zfactor, &ctx->stats);
     ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}
+
+extern "C" int ofx_tvl1_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *dI0, const void *const *dI1,
+                                  void *const *d_flo, int nx, int ny, double tau, double lambda, double theta,
+                                  int nscales, double zfactor, int warps, double epsilon, ofx_stats *stats_out)
+{
+    OFX_ENTER(ctx);
+    if (!dI0 || !dI1 || !d_flo) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: NULL pointer");
+    if (n_pairs < 1 || n_pairs > OFX_MAX_GROUP)
+        return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: a lockstep group holds 1..%d pairs (got %d)", OFX_MAX_GROUP, n_pairs);
+    for (int g = 0; g < n_pairs; g++)
+        if (!dI0[g] || !dI1[g] || !d_flo[g]) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: NULL pointer (pair %d)", g);
+    const double t0 = ofx_now_ms();
+    const Tvl1Params P = make_params(ctx, tau, lambda, theta, warps, epsilon, 0);
+    ofx_stats local[OFX_MAX_GROUP];
+    ofx_stats *st = stats_out ? stats_out : local;
+    int s = ctx->precision == OFX_F64
+                ? tvl1_group_devapi<double>(ctx, n_pairs, dI0, dI1, d_flo, nx, ny, P, nscales, zfactor, st)
+                : tvl1_group_devapi<float>(ctx, n_pairs, dI0, dI1, d_flo, nx, ny, P, nscales, zfactor, st);
+    const double ms = ofx_now_ms() - t0;
+    for (int g = 0; g < n_pairs; g++) st[g].total_ms = ms;
+    ctx->stats = st[0];
     return s;
 }
 
@@ -736,22 +856,21 @@ static int tvl1_single_scale_host(ofx_ctx *ctx, const double *I0, const double *
                                   int ny, const Tvl1Params &P)
 {
     const size_t n = (size_t) nx * ny;
-    stats_begin(ctx, 1, P.warps);
+    stats_begin(&ctx->stats, 1, P.warps);
     ctx->stats.nx[0] = nx;
     ctx->stats.ny[0] = ny;
     Tvl1Level<T> L;
-    OFX_TRY(tvl1_level_alloc<T>(ctx, L, nx, ny, false));
+    OFX_TRY(tvl1_level_alloc<T>(ctx, L, nx, ny, 1, false));
     OFX_TRY(upload_image<T>(ctx, I0, n, &L.I0));
     OFX_TRY(upload_image<T>(ctx, I1, n, &L.I1));
-    OFX_TRY(ofx_alloc(ctx, n, &L.pack));
     double *d1, *d2;
     OFX_TRY(ofx_alloc(ctx, n, &d1));
     OFX_TRY(ofx_alloc(ctx, n, &d2));
     OFX_HIP(ctx, hipMemcpyAsync(d1, u1, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     OFX_HIP(ctx, hipMemcpyAsync(d2, u2, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     OFX_TRY(op_interleave2<T>(ctx, d1, d2, L.U[0], n));
-    OFX_TRY(tvl1_single_scale_dev<T>(ctx, L, P, 0));
-    OFX_TRY(op_deinterleave2<T>(ctx, L.U[L.cur], d1, d2, n));
+    OFX_TRY(tvl1_single_scale_dev<T>(ctx, L, P, 0, &ctx->stats));
+    OFX_TRY(op_deinterleave2<T>(ctx, L.U[L.cur & 1u], d1, d2, n));
     OFX_HIP(ctx, hipMemcpyAsync(u1, d1, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     OFX_HIP(ctx, hipMemcpyAsync(u2, d2, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -779,11 +898,11 @@ static int tvl1_iterations_host(ofx_ctx *ctx, double *u1, double *u2, double *p1
                                 int ny, const Tvl1Params &P, double *error)
 {
     const size_t n = (size_t) nx * ny;
-    stats_begin(ctx, 1, 1);
+    stats_begin(&ctx->stats, 1, 1);
     ctx->stats.nx[0] = nx;
     ctx->stats.ny[0] = ny;
     Tvl1Level<T> L;
-    OFX_TRY(tvl1_level_alloc<T>(ctx, L, nx, ny, false));
+    OFX_TRY(tvl1_level_alloc<T>(ctx, L, nx, ny, 1, false));
     double *d[2];
     OFX_TRY(ofx_alloc(ctx, n, &d[0]));
     OFX_TRY(ofx_alloc(ctx, n, &d[1]));
@@ -808,8 +927,9 @@ static int tvl1_iterations_host(ofx_ctx *ctx, double *u1, double *u2, double *p1
     ctx->stats.work_pix_iters = (double) it * nx * ny;
     if (error) *error = err;
 
+    const int h = (int) (L.cur & 1u);
     struct { double *a, *b; typename Pix<T>::v2 *src; } down[3] = {
-        {u1, u2, L.U[L.cur]}, {p11, p12, L.P1[L.cur]}, {p21, p22, L.P2[L.cur]}};
+        {u1, u2, L.U[h]}, {p11, p12, L.P1[h]}, {p21, p22, L.P2[h]}};
     for (auto &e : down) {
         OFX_TRY(op_deinterleave2<T>(ctx, e.src, d[0], d[1], n));
         OFX_HIP(ctx, hipMemcpyAsync(e.a, d[0], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -839,7 +959,11 @@ extern "C" int ofx_tvl1_iterations(ofx_ctx *ctx, double *u1, double *u2, double 
     return s;
 }
 
-// ---- batch of pairs: one worker thread per context ----------------------------------------------------
+// ---- batch of pairs: lockstep groups, one worker thread per context --------------------------------------
+// The pairs are cut into groups of `lockstep` (option of ctxs[0]; default 4) consecutive pairs; group q is
+// solved by context q % n_ctx with ofx_tvl1_group_dev, i.e. its pairs share every launch.  On the small
+// pyramid levels a launch is a latency chain that leaves most of the GPU idle, so G pairs per launch cost
+// the time of one; and the convergence polls (one host round trip per warp) are paid once per group.
 extern "C" int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI0, const void *const *dI1,
                                   void *const *d_flo, int n_pairs, int nx, int ny, double tau, double lambda,
                                   double theta, int nscales, double zfactor, int warps, double epsilon,
@@ -848,19 +972,25 @@ extern "C" int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *c
     if (!ctxs || n_ctx < 1 || n_pairs < 0 || !dI0 || !dI1 || !d_flo) return OFX_ERR_ARG;
     for (int w = 0; w < n_ctx; w++)
         if (!ctxs[w] || ctxs[w]->device != ctxs[0]->device || ctxs[w]->precision != ctxs[0]->precision) return OFX_ERR_ARG;
+    int G = ctxs[0]->lockstep > 0 ? ctxs[0]->lockstep : 4;
+    if (G > OFX_MAX_GROUP) G = OFX_MAX_GROUP;
+    const int n_groups = (n_pairs + G - 1) / G;
     std::atomic<int> status(OFX_OK);
     auto worker = [&](int w) {
-        for (int k = w; k < n_pairs; k += n_ctx) {
+        std::vector<ofx_stats> st(G);
+        for (int q = w; q < n_groups; q += n_ctx) {
             if (status.load() != OFX_OK) return;
-            const int s = ofx_tvl1_multiscale_dev(ctxs[w], dI0[k], dI1[k], d_flo[k], nx, ny, tau, lambda, theta, nscales,
-                                                  zfactor, warps, epsilon, 0);
+            const int first = q * G, cnt = (n_pairs - first < G) ? n_pairs - first : G;
+            const int s = ofx_tvl1_group_dev(ctxs[w], cnt, dI0 + first, dI1 + first, d_flo + first, nx, ny, tau, lambda, theta,
+                                             nscales, zfactor, warps, epsilon, st.data());
             if (s != OFX_OK) { int expected = OFX_OK; status.compare_exchange_strong(expected, s); return; }
-            if (work_pix_iters) work_pix_iters[k] = ctxs[w]->stats.work_pix_iters;
+            if (work_pix_iters)
+                for (int g = 0; g < cnt; g++) work_pix_iters[first + g] = st[g].work_pix_iters;
         }
         (void) hipStreamSynchronize(ctxs[w]->stream);
     };
     std::vector<std::thread> th;
-    for (int w = 1; w < n_ctx && w < n_pairs; w++) th.emplace_back(worker, w);
+    for (int w = 1; w < n_ctx && w < n_groups; w++) th.emplace_back(worker, w);
     worker(0);
     for (auto &t : th) t.join();
     return status.load();

@@ -186,3 +186,56 @@ def test_fused_kernel_equals_single_kernel(gpu64, orc, synth, nx, ny):
         gpu64.tvl1_iterations(*gg, I1wx, I1wy, rho_c, PAR["tau"], PAR["lam"], PAR["theta"], n_iter)
         for a, b in zip(gg, go):
             assert np.array_equal(a, b)
+
+
+# ---- lockstep groups (several pairs share every launch) -----------------------------------------------------
+@pytest.mark.parametrize("G", [1, 2, 3, 5, 8])
+def test_lockstep_group_equals_pairs_solved_alone(ofx_mod, gpu64, orc, synth, G):
+    """ofx_tvl1_group_dev: G different pairs through the same launches.  Every pair keeps its own stopping
+    test / iteration counts / ping-pong phase: iteration tables equal the oracle's pair by pair and the .flo
+    payloads equal the oracle's flow cast to float32 (bit for bit)."""
+    import torch
+    nx, ny = 150, 97
+    pairs = [synth.pair("P0" if k % 3 == 2 else "P1", nx, ny, k) for k in range(G)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in pairs]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in pairs]
+    flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    st = gpu64.tvl1_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1],
+                              [flo[k].data_ptr() for k in range(G)], nx, ny, nscales=3, **PAR)
+    gpu64.synchronize()
+    got = flo.cpu().numpy()
+    seen = set()
+    for k in range(G):
+        uo, vo, it, _ = orc.tvl1_multiscale(pairs[k][0], pairs[k][1], nscales=3, **PAR)
+        assert np.array_equal(st[k].iterations(), it), k
+        assert np.array_equal(got[k], np.stack([uo, vo], axis=-1).astype(np.float32)), k
+        seen.add(tuple(int(x) for x in np.asarray(it).ravel()))
+    if G >= 3:
+        assert len(seen) > 1        # the pairs really stop at different iterations
+
+
+def test_lockstep_group_f32_equals_single_pair_f32(ofx_mod, gpu32, synth):
+    import torch
+    nx, ny, G = 131, 80, 4
+    pairs = [synth.pair("P1", nx, ny, k) for k in range(G)]
+    d0 = [torch.from_numpy(p[0].astype(np.float32)).cuda() for p in pairs]
+    d1 = [torch.from_numpy(p[1].astype(np.float32)).cuda() for p in pairs]
+    flo = torch.zeros((2, G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    st = gpu32.tvl1_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1],
+                              [flo[0, k].data_ptr() for k in range(G)], nx, ny, nscales=3, **PAR)
+    gpu32.synchronize()
+    for k in range(G):
+        gpu32.tvl1_multiscale_dev(d0[k].data_ptr(), d1[k].data_ptr(), flo[1, k].data_ptr(), nx, ny, nscales=3, **PAR)
+        gpu32.synchronize()
+        assert np.array_equal(gpu32.stats().iterations(), st[k].iterations())
+    got = flo.cpu().numpy()
+    assert np.array_equal(got[0], got[1])
+
+
+def test_lockstep_group_rejects_bad_sizes(ofx_mod, gpu64):
+    with pytest.raises(ofx_mod.OfxError):
+        gpu64.tvl1_group_dev([], [], [], 64, 48)
+    with pytest.raises(ofx_mod.OfxError):
+        gpu64.tvl1_group_dev([1] * 17, [1] * 17, [1] * 17, 64, 48)
