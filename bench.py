@@ -55,7 +55,7 @@ def parse():
                     help="pairs per lockstep group (they share every kernel launch of one context)")
     ap.add_argument("--concurrency", type=int, default=0, help="override the library's concurrency hint (0 = streams)")
     ap.add_argument("--variants", type=int, default=8, help="distinct synthetic pairs cycled through by the steps")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="image pairs in flight per GPU, each on its own context / HIP stream (SURVEY 8e: >= 2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--rows", type=int, default=0)

@@ -225,6 +225,40 @@ OFX_DEV double bicubic_sample(const T *in, const BicubicTaps &t, int nx)
     return cubic_cell(c[0], c[1], c[2], c[3], t.fx);
 }
 
+// Three-channel sample (f, fx, fy) for the warps: the channels live in a pair plane pa = (f, fx) and a scalar
+// plane pb = fy instead of one padded 4-vector per pixel.  The vector L1 (TCP) works in 64-byte chunks; a wave
+// gathering 16 B out of 32-byte elements touches 32 chunks per load at 25 % efficiency, and PMC showed the warp
+// kernel TA/TCP-bound on exactly that (979 chunk accesses per wave, TA busy 73 %).  16-byte and 8-byte strides
+// touch 16 + 8 chunks per tap instead of 32 + 32.  Taps are addressed as uniform base + 32-bit byte offset.
+template <typename V2, typename S>
+OFX_DEV void bicubic_sample3(const V2 *__restrict__ pa, const S *__restrict__ pb, const BicubicTaps &t, int nx,
+                             double &o0, double &o1, double &o2)
+{
+    const unsigned E = sizeof(S);
+    const unsigned r0 = (unsigned) t.row[0] * nx * E, r1 = (unsigned) t.row[1] * nx * E;
+    const unsigned r2 = (unsigned) t.row[2] * nx * E, r3 = (unsigned) t.row[3] * nx * E;
+    double c0[4], c1[4], c2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned ck = (unsigned) t.col[k] * E;
+        const char *ba = reinterpret_cast<const char *>(pa), *bb = reinterpret_cast<const char *>(pb);
+        const double2 a0 = ldw2(reinterpret_cast<const V2 *>(ba + 2 * (r0 + ck)));
+        const double2 a1 = ldw2(reinterpret_cast<const V2 *>(ba + 2 * (r1 + ck)));
+        const double2 a2 = ldw2(reinterpret_cast<const V2 *>(ba + 2 * (r2 + ck)));
+        const double2 a3 = ldw2(reinterpret_cast<const V2 *>(ba + 2 * (r3 + ck)));
+        const double b0 = ldw(reinterpret_cast<const S *>(bb + r0 + ck));
+        const double b1 = ldw(reinterpret_cast<const S *>(bb + r1 + ck));
+        const double b2 = ldw(reinterpret_cast<const S *>(bb + r2 + ck));
+        const double b3 = ldw(reinterpret_cast<const S *>(bb + r3 + ck));
+        c0[k] = cubic_cell(a0.x, a1.x, a2.x, a3.x, t.fy);
+        c1[k] = cubic_cell(a0.y, a1.y, a2.y, a3.y, t.fy);
+        c2[k] = cubic_cell(b0, b1, b2, b3, t.fy);
+    }
+    o0 = cubic_cell(c0[0], c0[1], c0[2], c0[3], t.fx);
+    o1 = cubic_cell(c1[0], c1[1], c1[2], c1[3], t.fx);
+    o2 = cubic_cell(c2[0], c2[1], c2[2], c2[3], t.fx);
+}
+
 // ---- stencil point functions ----------------------------------------------------------------------
 // Backward-difference divergence at one pixel, src/operators.cpp:35-78.
 //   ac = v1[p], al = v1[p-1], bc = v2[p], bu = v2[p-nx].

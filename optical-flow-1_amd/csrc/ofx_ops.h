@@ -53,8 +53,9 @@ template <typename T> int op_bicubic_warp(ofx_ctx *ctx, const T *in, const T *u,
 template <typename T> int op_bicubic_at(ofx_ctx *ctx, const T *in, const double *uu, const double *vv,
                                         double *out, int n, int nx, int ny, int border_out);
 
-// (f, centred dx, centred dy, 0) packed per pixel: one 4-wide gather per bicubic tap serves three warps
-template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v4 *pack, int nx, int ny);
+// pa = (f, centred dx) pairs, pb = centred dy: one pair gather + one scalar gather per bicubic tap serve the
+// three warps of (f, fx, fy) (see bicubic_sample3 in ofx_device.h for why not one padded 4-vector)
+template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v2 *pa, T *pb, int nx, int ny);
 
 // Shared pyramid prologue (src/tvl1flow.cpp:236-280 == horn_schunck_pyramidal.cpp:279-323 ==
 // brox_optic_flow_spatial.cpp:467-509): joint normalisation, presmoothing, zoom_out chain.

@@ -445,9 +445,10 @@ int op_bicubic_at(ofx_ctx *ctx, const T *in, const double *uu, const double *vv,
     return OFX_OK;
 }
 
-// centred gradient packed next to the image (src/operators.cpp:335-406, nz = 1)
+// centred gradient next to the image (src/operators.cpp:335-406, nz = 1): pa = (f, fx), pb = fy
 template <typename T>
-__global__ void k_grad_pack(const T *__restrict__ f, typename Pix<T>::v4 *__restrict__ pack, int nx, int ny)
+__global__ void k_grad_pack(const T *__restrict__ f, typename Pix<T>::v2 *__restrict__ pa, T *__restrict__ pb, int nx,
+                            int ny)
 {
     const int j = blockIdx.x * BX + threadIdx.x;
     const int i = blockIdx.y * BY + threadIdx.y;
@@ -455,17 +456,15 @@ __global__ void k_grad_pack(const T *__restrict__ f, typename Pix<T>::v4 *__rest
     const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
     const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
     const size_t p = (size_t) i * nx + j;
-    double4 o;
-    o.x = ldw(f + p);
-    o.y = 0.5 * (ldw(f + (size_t) i * nx + jr) - ldw(f + (size_t) i * nx + jl));
-    o.z = 0.5 * (ldw(f + (size_t) id * nx + j) - ldw(f + (size_t) iu * nx + j));
-    o.w = 0.0;
-    stn4(pack + p, o);
+    const double fx = 0.5 * (ldw(f + (size_t) i * nx + jr) - ldw(f + (size_t) i * nx + jl));
+    const double fy = 0.5 * (ldw(f + (size_t) id * nx + j) - ldw(f + (size_t) iu * nx + j));
+    stn2(pa + p, make_double2(ldw(f + p), fx));
+    stn(pb + p, fy);
 }
 
-template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v4 *pack, int nx, int ny)
+template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v2 *pa, T *pb, int nx, int ny)
 {
-    hipLaunchKernelGGL(k_grad_pack<T>, grid2d(nx, ny), block2d(), 0, ctx->stream, f, pack, nx, ny);
+    hipLaunchKernelGGL(k_grad_pack<T>, grid2d(nx, ny), block2d(), 0, ctx->stream, f, pa, pb, nx, ny);
     OFX_LAUNCH_CHECK(ctx);
     return OFX_OK;
 }
@@ -544,7 +543,7 @@ int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nxx, int nyy, i
     template int op_second_derivative<T>(ofx_ctx *, const T *, T *, int, int, int);                                   \
     template int op_bicubic_warp<T>(ofx_ctx *, const T *, const T *, const T *, T *, int, int, int);                  \
     template int op_bicubic_at<T>(ofx_ctx *, const T *, const double *, const double *, double *, int, int, int, int);           \
-    template int op_grad_pack<T>(ofx_ctx *, const T *, Pix<T>::v4 *, int, int);                                        \
+    template int op_grad_pack<T>(ofx_ctx *, const T *, Pix<T>::v2 *, T *, int, int);                                            \
     template int op_build_pyramid<T>(ofx_ctx *, const T *, const T *, int, int, int, double, double,                   \
                                      std::vector<ImgLevel<T>> &);                                                      \
     template int op_build_pyramid_into<T>(ofx_ctx *, const T *, const T *, int, double, double,                        \

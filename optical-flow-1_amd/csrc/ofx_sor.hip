@@ -13,7 +13,7 @@
 // 1-vs-8-thread spread is 3.6e-5).  oracle's `set_sor_order(1)` reproduces this file bit for bit.
 //
 // Storage per level (T = storage type):
-//   HS  : U=(u,v) pairs in place; pack=(I2,I2x,I2y,0); A=(I2wx,I2wy); Dif=dif  -- the five coefficient
+//   HS  : U=(u,v) pairs in place; pa=(I2,I2x), pb=I2y; A=(I2wx,I2wy); Dif=dif  -- the five coefficient
 //         arrays Au,Av,Du,Dv,D of the reference are recomputed from A, Dif in registers (same ops).
 //   Brox: U; G1=(I1x,I1y); PA=(I2,I2x,I2y,I2xx), PB=(I2xy,I2yy); WA/WB = their warps; Psis;
 //         DV=(div_u,div_v), Dd=div_d; CO=(Au,Av,Du,Dv), Dm=D; DU=(du,dv) in place.
@@ -50,7 +50,7 @@ static int sor_pick_chunk(const ofx_ctx *ctx, int nx, int ny, int launches_per_s
 
 // warp of (I2, I2x, I2y) + constant parts of the system, src/horn_schunck_pyramidal.cpp:123-137
 template <typename T>
-__global__ void k_hs_warp(const typename Pix<T>::v4 *__restrict__ pack, const T *__restrict__ I1,
+__global__ void k_hs_warp(const typename Pix<T>::v2 *__restrict__ pa, const T *__restrict__ pb, const T *__restrict__ I1,
                           const typename Pix<T>::v2 *__restrict__ U, typename Pix<T>::v2 *__restrict__ A,
                           T *__restrict__ Dif, int nx, int ny)
 {
@@ -62,20 +62,9 @@ __global__ void k_hs_warp(const typename Pix<T>::v4 *__restrict__ pack, const T 
     const BicubicTaps t = bicubic_taps(j + u.x, i + u.y, nx, ny);
     double I2w = 0.0, I2wx = 0.0, I2wy = 0.0;
     if (!t.out) {
-        double c0[4], c1[4], c2[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double4 v0 = ldw4(pack + (size_t) t.row[0] * nx + t.col[k]);
-            const double4 v1 = ldw4(pack + (size_t) t.row[1] * nx + t.col[k]);
-            const double4 v2 = ldw4(pack + (size_t) t.row[2] * nx + t.col[k]);
-            const double4 v3 = ldw4(pack + (size_t) t.row[3] * nx + t.col[k]);
-            c0[k] = cubic_cell(v0.x, v1.x, v2.x, v3.x, t.fy);
-            c1[k] = cubic_cell(v0.y, v1.y, v2.y, v3.y, t.fy);
-            c2[k] = cubic_cell(v0.z, v1.z, v2.z, v3.z, t.fy);
-        }
-        I2w = cubic_cell(c0[0], c0[1], c0[2], c0[3], t.fx);
-        I2wx = rnd_to<T>(cubic_cell(c1[0], c1[1], c1[2], c1[3], t.fx));
-        I2wy = rnd_to<T>(cubic_cell(c2[0], c2[1], c2[2], c2[3], t.fx));
+        bicubic_sample3(pa, pb, t, nx, I2w, I2wx, I2wy);
+        I2wx = rnd_to<T>(I2wx);
+        I2wy = rnd_to<T>(I2wy);
     }
     const double I2wl = I2wx * u.x + I2wy * u.y;                 // :130
     const double dif = ldw(I1 + p) - I2w + I2wl;                 // :131
@@ -246,7 +235,8 @@ static int sor_exact_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int q
 template <typename T> struct HsLevel {
     int nx, ny;
     T *I1, *I2;
-    typename Pix<T>::v4 *pack;
+    typename Pix<T>::v2 *pa;    // (I2, I2x)
+    T *pb;                      // I2y
     typename Pix<T>::v2 *U, *A, *Uck;
     T *Dif;
 };
@@ -256,7 +246,8 @@ template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int
     const size_t n = (size_t) nx * ny;
     L.nx = nx;
     L.ny = ny;
-    OFX_TRY(ofx_alloc(ctx, n, &L.pack));
+    OFX_TRY(ofx_alloc(ctx, n, &L.pa));
+    OFX_TRY(ofx_alloc(ctx, n, &L.pb));
     OFX_TRY(ofx_alloc(ctx, n, &L.U));
     OFX_TRY(ofx_alloc(ctx, n, &L.Uck));
     OFX_TRY(ofx_alloc(ctx, n, &L.A));
@@ -277,12 +268,12 @@ template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L
     if (P.verbose)
         fprintf(stderr, "Single-scale Horn-Schunck of a %dx%d image\n\ta=%g nw=%d eps=%g mi=%d v=%d\n", nx, ny, P.alpha,
                 P.warps, P.TOL, P.maxiter, P.verbose);
-    OFX_TRY(op_grad_pack<T>(ctx, L.I2, L.pack, nx, ny));                                    // :114
+    OFX_TRY(op_grad_pack<T>(ctx, L.I2, L.pa, L.pb, nx, ny));                                // :114
     ofx_stats &S = ctx->stats;
     const dim3 gc(ofx_cdiv(ofx_cdiv(nx, 2), 64), ofx_cdiv(ofx_cdiv(ny, 2), 4));
     for (int w = 0; w < P.warps; w++) {
         if (P.verbose) fprintf(stderr, "Warping %d:", w);
-        hipLaunchKernelGGL(k_hs_warp<T>, g2d(nx, ny), b2d(), 0, ctx->stream, L.pack, (const T *) L.I1, L.U, L.A, L.Dif,
+        hipLaunchKernelGGL(k_hs_warp<T>, g2d(nx, ny), b2d(), 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I1, L.U, L.A, L.Dif,
                            nx, ny);                                                           // :123-137
         OFX_LAUNCH_CHECK(ctx);
         int niter = 0;

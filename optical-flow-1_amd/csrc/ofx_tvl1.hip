@@ -6,7 +6,7 @@
 //   P2[2]  : (p21,p22)      interleaved pairs, ping-pong          2 T / px each
 //   A      : (I1wx,I1wy)    warped gradient, constant per warp    2 T / px
 //   R      : rho_c          constant part of rho, per warp        1 T / px
-//   I1pack : (I1,I1x,I1y,0) target image + centred gradient       4 T / px (gathered by the warp)
+//   pa, pb : (I1,I1x), I1y  target image + centred gradient       3 T / px (gathered by the warp)
 //   I0     : source image                                          1 T / px
 // Every stream is read/written as whole 16-byte (f64) pairs per lane with unit stride, i.e. each
 // wave-instruction moves one contiguous 1 KiB segment.
@@ -425,17 +425,23 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
 
 // Warp + linearisation (src/tvl1flow.cpp:94-109): the three bicubic warps of I1, I1x, I1y share one
 // set of tap indices and one 4-wide gather per tap; writes A = (I1wx, I1wy) and R = rho_c.
+// Thread block of the warp kernel: BX x BY pixels, a wave covers BX x (64 / BX) of them.
+#ifndef OFX_WARP_BX
+#define OFX_WARP_BX 64
+#define OFX_WARP_BY 4
+#endif
 template <typename T>
-__global__ void k_tvl1_warp(const typename Pix<T>::v4 *__restrict__ packg, const T *__restrict__ I0g,
+__global__ void k_tvl1_warp(const typename Pix<T>::v2 *__restrict__ pag, const T *__restrict__ pbg, const T *__restrict__ I0g,
                             const typename Pix<T>::v2 *__restrict__ U0, const typename Pix<T>::v2 *__restrict__ U1,
                             typename Pix<T>::v2 *__restrict__ Ag, T *__restrict__ Rg, int nx, int ny, unsigned curmask)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    const int i = blockIdx.y * 4 + threadIdx.y;
+    const int j = blockIdx.x * OFX_WARP_BX + threadIdx.x;
+    const int i = blockIdx.y * OFX_WARP_BY + threadIdx.y;
     if (j >= nx || i >= ny) return;
     const int g = blockIdx.z;                                // pair of the lockstep group
     const size_t goff = (size_t) g * nx * ny;
-    const typename Pix<T>::v4 *__restrict__ pack = packg + goff;
+    const typename Pix<T>::v2 *__restrict__ pa = pag + goff;
+    const T *__restrict__ pb = pbg + goff;
     const T *__restrict__ I0 = I0g + goff;
     const typename Pix<T>::v2 *__restrict__ U = (((curmask >> g) & 1u) ? U1 : U0) + goff;
     typename Pix<T>::v2 *__restrict__ A = Ag + goff;
@@ -445,20 +451,9 @@ __global__ void k_tvl1_warp(const typename Pix<T>::v4 *__restrict__ packg, const
     const BicubicTaps t = bicubic_taps(j + u.x, i + u.y, nx, ny);
     double I1w = 0.0, I1wx = 0.0, I1wy = 0.0;
     if (!t.out) {                                            // border_out = true, :94-96
-        double c0[4], c1[4], c2[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double4 v0 = ldw4(pack + (size_t) t.row[0] * nx + t.col[k]);
-            const double4 v1 = ldw4(pack + (size_t) t.row[1] * nx + t.col[k]);
-            const double4 v2 = ldw4(pack + (size_t) t.row[2] * nx + t.col[k]);
-            const double4 v3 = ldw4(pack + (size_t) t.row[3] * nx + t.col[k]);
-            c0[k] = cubic_cell(v0.x, v1.x, v2.x, v3.x, t.fy);
-            c1[k] = cubic_cell(v0.y, v1.y, v2.y, v3.y, t.fy);
-            c2[k] = cubic_cell(v0.z, v1.z, v2.z, v3.z, t.fy);
-        }
-        I1w = cubic_cell(c0[0], c0[1], c0[2], c0[3], t.fx);
-        I1wx = rnd_to<T>(cubic_cell(c1[0], c1[1], c1[2], c1[3], t.fx));
-        I1wy = rnd_to<T>(cubic_cell(c2[0], c2[1], c2[2], c2[3], t.fx));
+        bicubic_sample3(pa, pb, t, nx, I1w, I1wx, I1wy);
+        I1wx = rnd_to<T>(I1wx);
+        I1wy = rnd_to<T>(I1wy);
     }
     stn2(A + p, make_double2(I1wx, I1wy));
     stn(R + p, (I1w - I1wx * u.x - I1wy * u.y - ldw(I0 + p)));       // :107-108
@@ -471,7 +466,8 @@ template <typename T> struct Tvl1Level {
     using v4 = typename Pix<T>::v4;
     int nx, ny, G;
     T  *I0, *I1;
-    v4 *pack;
+    v2 *pa;         // (I1, I1x): gathered by the warp
+    T  *pb;         // I1y
     v2 *U[2], *P1[2], *P2[2], *A;
     T  *R;
     unsigned cur;   // bit g: which ping-pong half holds the live u / p of pair g
@@ -492,12 +488,12 @@ template <typename T> static int tvl1_level_alloc(ofx_ctx *ctx, Tvl1Level<T> &L,
     L.G = G;
     L.cur = 0;
     L.I0 = L.I1 = nullptr;
-    L.pack = nullptr;
     if (images) {
         OFX_TRY(ofx_alloc(ctx, n, &L.I0));
         OFX_TRY(ofx_alloc(ctx, n, &L.I1));
     }
-    OFX_TRY(ofx_alloc(ctx, n, &L.pack));
+    OFX_TRY(ofx_alloc(ctx, n, &L.pa));
+    OFX_TRY(ofx_alloc(ctx, n, &L.pb));
     for (int h = 0; h < 2; h++) {
         OFX_TRY(ofx_alloc(ctx, n, &L.U[h]));
         OFX_TRY(ofx_alloc(ctx, n, &L.P1[h]));
@@ -579,7 +575,7 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
                                float *ms_out)
 {
     const int nx = L.nx, ny = L.ny, G = L.G;
-    if ((long long) nx * ny >= (1LL << 28)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: image larger than 2^28 pixels");
+    if ((long long) nx * ny >= (1LL << 27)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: image larger than 2^27 pixels");
     const double l_t = P.lambda * P.theta, taut = P.tau / P.theta, theta = P.theta;
     const bool pairs = ctx->fuse2 != 0;
     // geometry of the one-iteration kernel (also used for a trailing single iteration and the redo)
@@ -648,10 +644,10 @@ static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params
 {
     const int nx = L.nx, ny = L.ny, G = L.G;
     const size_t n = L.n();
-    const dim3 g2(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), G), b2(64, 4);
+    const dim3 g2(ofx_cdiv(nx, OFX_WARP_BX), ofx_cdiv(ny, OFX_WARP_BY), G), b2(OFX_WARP_BX, OFX_WARP_BY);
     if (nx < 2 || ny < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: level %dx%d too small", nx, ny);
 
-    for (int g = 0; g < G; g++) OFX_TRY(op_grad_pack<T>(ctx, L.I1 + g * n, L.pack + g * n, nx, ny));       // :84
+    for (int g = 0; g < G; g++) OFX_TRY(op_grad_pack<T>(ctx, L.I1 + g * n, L.pa + g * n, L.pb + g * n, nx, ny));   // :84
     // p = 0 in the half each pair's u lives in (:87-90); both halves are cleared when the phases differ
     for (int h = 0; h < 2; h++) {
         bool used = false;
@@ -662,8 +658,8 @@ static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params
     }
 
     for (int w = 0; w < P.warps; w++) {
-        hipLaunchKernelGGL(k_tvl1_warp<T>, g2, b2, 0, ctx->stream, L.pack, (const T *) L.I0, L.U[0], L.U[1], L.A, L.R,
-                           nx, ny, L.cur);                                                               // :94-109
+        hipLaunchKernelGGL(k_tvl1_warp<T>, g2, b2, 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I0, L.U[0], L.U[1],
+                           L.A, L.R, nx, ny, L.cur);                                                               // :94-109
         OFX_LAUNCH_CHECK(ctx);
         // p lives in the same ping-pong half as u
         int it[OFX_MAX_GROUP];
