@@ -85,9 +85,11 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *   "profile"        0/1  bracket the inner-iteration launches with HIP events -> stats.iter_ms
  *   "fixed_work"     0/1  TV-L1: every warp runs exactly OFX_TVL1_MAX_ITERATIONS iterations (stopping
  *                         test disabled; the reference with epsilon = 0)
- *   "sor_exact"      1/0  HS / Brox: 1 (default) = the reference's sweep order, bit-identical results;
+ *   "sor_exact"      HS / Brox: 1 (default) = the reference's sweep order, bit-identical results, K time steps
+ *                         of the pipelined schedule per launch; 2 = the same schedule, one launch per time step;
  *                         0 = colour-ordered sweeps (much faster, result drifts by ~1e-5..1e-3 px)
- *   "sor_batch"      sweeps in flight per batch in exact mode (default 64)
+ *   "sor_batch"      sweeps in flight per batch in the exact modes (default 32 / 64)
+ *   "sor_window"     time steps per launch of sor_exact = 1 (default 8)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
  *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default 4, at most 16)
  *   "concurrency"    number of contexts that will be solving on the same device at the same time

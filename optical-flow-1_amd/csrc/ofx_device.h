@@ -78,6 +78,29 @@ OFX_DEV void stn4(float4 *p, double4 v)
     *p = make_float4((float) v.x, (float) v.y, (float) v.z, (float) v.w);
 }
 
+// Loads of unknowns that other waves of the SAME workgroup rewrite inside one launch (windowed SOR sweeps):
+// COH = true bypasses the vector L1 (agent-scope relaxed atomic loads = global_load ... sc1, served by L2), so a
+// line cached before a neighbour's store can never be returned stale.  8-byte pieces: a pixel's pair is written
+// by one thread in one store, and the protocol never reads a pixel in the step it is written.
+template <bool COH> OFX_DEV double2 ldu2(const double2 *p)
+{
+    if (!COH) return *p;
+    const double *q = reinterpret_cast<const double *>(p);
+    double2 r;
+    r.x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return r;
+}
+template <bool COH> OFX_DEV double2 ldu2(const float2 *p)
+{
+    if (!COH) { const float2 v = *p; return make_double2((double) v.x, (double) v.y); }
+    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    float2 v;
+    __builtin_memcpy(&v, &w, 8);
+    return make_double2((double) v.x, (double) v.y);
+}
+
 // ---- wave64 primitives --------------------------------------------------------------------------
 // Neighbour-lane moves.  gfx950 (GFX9 family) has whole-wavefront DPP shifts: one v_mov_b32_dpp per
 // dword, no LDS crossbar round trip and no address arithmetic (a __shfl compiles to ds_bpermute_b32 +

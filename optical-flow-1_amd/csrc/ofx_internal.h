@@ -56,8 +56,9 @@ struct ofx_ctx {
     int lockstep;       // pairs per lockstep group in ofx_tvl1_batch_dev (0 = default)
     int chunk;
     int fixed_work;
-    int sor_exact;      // 1: reference sweep order (hyperplane-pipelined), 0: colour order (fast)
-    int sor_batch;      // sweeps in flight per batch in exact mode (0 = 64)
+    int sor_exact;      // 1: reference sweep order, windowed launches; 2: same, one launch per time step; 0: colour order
+    int sor_batch;      // sweeps in flight per batch in exact mode (0 = default)
+    int sor_window;     // time steps per launch of the windowed exact mode (0 = 8)
     unsigned long long poll_seq;
 
     ofx_stats stats;

@@ -72,27 +72,42 @@ __global__ void k_hs_warp(const typename Pix<T>::v2 *__restrict__ pa, const T *_
     stn(Dif + p, dif);
 }
 
+// ---- how a sweep kernel reaches the in-place unknowns -------------------------------------------------------
+// UGlobal: straight from / to the global array (COH: past the L1, see ldu2; SNAP: also into the sweep's snapshot).
+// (An accessor that served same-launch hand-offs from an LDS ring was built and measured: correct, but slower --
+// a windowed step is bound by the memory latency of the PREVIOUS sweep's values and by one CU's f64 rate, not by
+// the store drain the ring removes.  DESIGN.md 5.3.)
+template <typename T, bool COH, bool SNAP> struct UGlobal {
+    typename Pix<T>::v2 *U, *snap;
+    int nx;
+    OFX_DEV double2 get(int ii, int jj) const { return ldu2<COH>(U + (size_t) ii * nx + jj); }
+    OFX_DEV void put(int i, int j, double2 v) const
+    {
+        stn2(U + (size_t) i * nx + j, v);
+        if (SNAP) stn2(snap + (size_t) i * nx + j, v);
+    }
+};
 // SOR update of one pixel, src/horn_schunck_pyramidal.cpp:31-71.  Neighbour indices are the clamped
 // coordinates -- exactly what the reference's replicated border indices are (:161-228) -- in the order
 // up-left, up-right, bottom-left, bottom-right / up, left, bottom, right, with ONE quirk kept for
 // bit-exactness: the bottom-right corner lists its diagonal taps bottom pair first (:222-228).
 // Returns the squared update (:70).
-template <typename T>
-OFX_DEV double hs_point(typename Pix<T>::v2 *__restrict__ U, const typename Pix<T>::v2 *__restrict__ A,
-                        const T *__restrict__ Dif, int i, int j, int nx, int ny, double alpha2)
+template <typename T, class Acc>
+OFX_DEV double hs_point_acc(const Acc &acc, const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif, int i,
+                            int j, int nx, int ny, double alpha2)
 {
     const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
     const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
     const size_t p = (size_t) i * nx + j;
-    double2 p1 = ldw2(U + (size_t) iu * nx + jl), p2 = ldw2(U + (size_t) iu * nx + jr);
-    double2 p3 = ldw2(U + (size_t) id * nx + jl), p4 = ldw2(U + (size_t) id * nx + jr);
+    double2 p1 = acc.get(iu, jl), p2 = acc.get(iu, jr);
+    double2 p3 = acc.get(id, jl), p4 = acc.get(id, jr);
     if (i == ny - 1 && j == nx - 1) {
         const double2 a1 = p1, a2 = p2;
         p1 = p3; p2 = p4; p3 = a1; p4 = a2;
     }
-    const double2 p5 = ldw2(U + (size_t) iu * nx + j), p6 = ldw2(U + (size_t) i * nx + jl);
-    const double2 p7 = ldw2(U + (size_t) id * nx + j), p8 = ldw2(U + (size_t) i * nx + jr);
-    const double2 c = ldw2(U + p);
+    const double2 p5 = acc.get(iu, j), p6 = acc.get(i, jl);
+    const double2 p7 = acc.get(id, j), p8 = acc.get(i, jr);
+    const double2 c = acc.get(i, j);
     const double2 a = ldw2(A + p);
     const double dif = ldw(Dif + p);
     const double w = HS_SOR_W;
@@ -104,8 +119,17 @@ OFX_DEV double hs_point(typename Pix<T>::v2 *__restrict__ U, const typename Pix<
     const double uk = c.x, vk = c.y;
     const double un = rnd_to<T>((1.0 - w) * uk + w * (Au - D * vk + alpha2 * ula) / Du);   // :66
     const double vn = rnd_to<T>((1.0 - w) * vk + w * (Av - D * un + alpha2 * vla) / Dv);   // :67
-    stn2(U + p, make_double2(un, vn));
+    acc.put(i, j, make_double2(un, vn));
     return (un - uk) * (un - uk) + (vn - vk) * (vn - vk);                     // :70
+}
+
+template <typename T, bool COH = false, bool SNAP = false>
+OFX_DEV double hs_point(typename Pix<T>::v2 *U, const typename Pix<T>::v2 *__restrict__ A,
+                        const T *__restrict__ Dif, int i, int j, int nx, int ny, double alpha2,
+                        typename Pix<T>::v2 *snap = nullptr)
+{
+    const UGlobal<T, COH, SNAP> acc = {U, snap, nx};
+    return hs_point_acc<T>(acc, A, Dif, i, j, nx, ny, alpha2);
 }
 
 // One colour of one SOR sweep (fast, order-changing mode).
@@ -173,6 +197,100 @@ __global__ __launch_bounds__(64) void k_hs_plane(typename Pix<T>::v2 *__restrict
     loop_accumulate(err, s, e, blockIdx.x);
 }
 
+// ---- exact mode, windowed: K time steps per launch ----------------------------------------------------------
+// One launch per time step makes the exact mode host-launch-bound (~4.5 us per step, thousands of steps per
+// solve).  The schedule t = pos + C s stays valid for any LARGER sweep spacing, so sweeps are spaced K + C steps
+// apart and a launch executes the K steps [tau0, tau0 + K) of every sweep in flight, ONE WORKGROUP PER SWEEP:
+// sweep s runs its local steps q = tau - (K + C) s, thread r of its workgroup owns plane item r (k_hs_plane's
+// numbering), and consecutive steps are separated by a store drain + workgroup barrier.  Everything sweep s
+// reads from sweep s - 1 (pos <= q + C - 1, i.e. tau' <= tau - K - 1) was written in an EARLIER launch, so
+// workgroups never communicate inside a launch: no flags, no spinning, no placement assumptions -- only
+// same-workgroup hand-offs (L1-bypassing loads, ldu2) and kernel boundaries.  Launches per batch of S sweeps:
+// (qmax + (K + C) S) / K instead of qmax + C S.
+// Every sweep also writes its values into its own snapshot plane: the state after sweep n is snapshot n,
+// whatever later sweeps of the batch have overwritten in place, so a batch that ran past the stopping sweep
+// needs no rollback and re-run.
+// OFX_SOR_COH = 1: unknowns are read past the L1 (sc1).  0 (default): plain loads -- within a workgroup the L1 is
+// coherent (same CU, write-through), and everything read from other sweeps was written before this launch began.
+#ifndef OFX_SOR_COH
+#define OFX_SOR_COH 0
+#endif
+template <typename T>
+__global__ __launch_bounds__(1024) void k_hs_window(typename Pix<T>::v2 *U, typename Pix<T>::v2 *snap,
+                                                    const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif,
+                                                    double *__restrict__ err, int tau0, int K, int lag, int s_first,
+                                                    int nx, int ny, double alpha2)
+{
+    const int s = s_first + blockIdx.x;
+    const int qmax = 2 * ny + nx - 2, n_items = ny + 3;
+    typename Pix<T>::v2 *mysnap = snap + (size_t) s * nx * ny;
+    double e = 0.0;
+    for (int tau = tau0; tau < tau0 + K; tau++) {
+        const int q = tau - lag * s;
+        if (q >= 0 && q <= qmax) {
+            for (int r = threadIdx.x; r < n_items; r += blockDim.x) {
+                int i, j;
+                if (r == ny + 2) {
+                    for (int corner = 0; corner < 4; corner++)
+                        if (hs_plane_item(r, q, nx, ny, corner, i, j))
+                            e += hs_point<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
+                } else if (hs_plane_item(r, q, nx, ny, 0, i, j)) {
+                    e += hs_point<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this step's stores have reached L2 ...
+        __syncthreads();                                       // ... before any wave of the workgroup reads them
+    }
+    loop_accumulate(err, s, e, threadIdx.x >> 6);
+}
+
+// Batch driver of the windowed exact mode.  launch(tau0, K, lag, s_first, count) enqueues one window; take(n)
+// makes snapshot n - 1 the current state.  Same contract as sor_exact_loop.
+template <class WindowFn, class TakeFn>
+static int sor_window_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int qmax, int C, int batch, WindowFn launch,
+                           TakeFn take, int *n_out, double *err_out)
+{
+    int niter = 0;
+    double error = 1000;
+    const int K = ctx->sor_window > 0 ? ctx->sor_window : 8;
+    const int lag = K + C;
+    OFX_TRY(ofx_loop_reserve(ctx, batch + 1));
+    LoopSpec LS;
+    LS.size = size;
+    LS.thr = TOL;
+    LS.crit = OFX_CRIT_SQRT_MEAN;
+    LS.chunk = 0;
+    LS.fixed = false;
+    LS.pairs = false;
+    while (error > TOL && niter < maxiter) {
+        const int ns = (maxiter - niter < batch) ? maxiter - niter : batch;
+        OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) ns * OFX_NSHARD, ctx->stream));
+        OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
+        const long total = (long) qmax + 1 + (long) lag * (ns - 1);
+        for (long tau0 = 0; tau0 < total; tau0 += K) {
+            long s_lo = (tau0 - qmax + lag - 1) / lag;          // smallest s with tau0 - lag s <= qmax
+            if (tau0 - qmax < 0) s_lo = 0;
+            long s_hi = (tau0 + K - 1) / lag;                   // largest s with tau0 + K - 1 - lag s >= 0
+            if (s_hi > ns - 1) s_hi = ns - 1;
+            if (s_hi < s_lo) continue;
+            OFX_TRY(launch((int) tau0, K, lag, (int) s_lo, (int) (s_hi - s_lo + 1)));
+        }
+        LS.max_iter = ns;
+        const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
+        OFX_TRY(ofx_loop_finalize(ctx, LS, 0, ns, &ctx->h_state[slot * OFX_MAX_GROUP]));
+        OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
+        OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
+        const OfxIterState st = ctx->h_state[slot * OFX_MAX_GROUP];
+        if (st.n < ns) OFX_TRY(take(st.n));                     // stopped inside the batch: the state is snapshot n - 1
+        niter += st.n;
+        error = st.error;
+    }
+    *n_out = niter;
+    *err_out = error;
+    return OFX_OK;
+}
+
 // Exact SOR loop:  while (error > TOL && n < maxiter) sweep.   Sweeps run in batches of up to `batch`
 // pipelined sweeps (launch_plane(t, s_lo, s_cnt) = one time step).  The per-sweep errors of a batch are
 // only known when it has drained, so a batch that ran past the stopping sweep is rolled back to its
@@ -232,6 +350,21 @@ static int sor_exact_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int q
     return OFX_OK;
 }
 
+// sweeps per batch of the windowed mode: option "sor_batch", else 32, capped by maxiter and by ~4 GiB of snapshots
+static int sor_pick_batch(const ofx_ctx *ctx, size_t npix, size_t elem_bytes, int maxiter)
+{
+    int b = ctx->sor_batch > 0 ? ctx->sor_batch : 32;
+    const size_t cap = (size_t) 4 << 30;
+    while (b > 1 && (size_t) b * npix * elem_bytes > cap) b /= 2;
+    if (b > maxiter) b = maxiter;
+    return b < 1 ? 1 : b;
+}
+static int sor_window_threads(int n_items)
+{
+    const int t = ofx_cdiv(n_items, 64) * 64;
+    return t > 1024 ? 1024 : t;
+}
+
 template <typename T> struct HsLevel {
     int nx, ny;
     T *I1, *I2;
@@ -239,6 +372,8 @@ template <typename T> struct HsLevel {
     T *pb;                      // I2y
     typename Pix<T>::v2 *U, *A, *Uck;
     T *Dif;
+    typename Pix<T>::v2 *Snap;  // windowed exact mode: one snapshot plane per sweep of a batch (allocated on first use)
+    int snap_planes;
 };
 
 template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int nx, int ny)
@@ -252,6 +387,8 @@ template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int
     OFX_TRY(ofx_alloc(ctx, n, &L.Uck));
     OFX_TRY(ofx_alloc(ctx, n, &L.A));
     OFX_TRY(ofx_alloc(ctx, n, &L.Dif));
+    L.Snap = nullptr;
+    L.snap_planes = 0;
     return OFX_OK;
 }
 
@@ -279,7 +416,29 @@ template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L
         int niter = 0;
         double error = 1000;                                                                  // :140
         float ms = 0.f;
-        if (ctx->sor_exact && nx >= 3 && ny >= 3) {
+        if (ctx->sor_exact == 1 && nx >= 3 && ny >= 3) {
+            // windowed exact mode (default)
+            const size_t ub = (size_t) nx * ny * sizeof(typename Pix<T>::v2);
+            const int batch = sor_pick_batch(ctx, (size_t) nx * ny, sizeof(typename Pix<T>::v2), P.maxiter);
+            if (L.snap_planes < batch) {
+                OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny * batch, &L.Snap));
+                L.snap_planes = batch;
+            }
+            const int threads = sor_window_threads(ny + 3);
+            auto window = [&](int tau0, int K, int lag, int s_first, int count) -> int {
+                hipLaunchKernelGGL(k_hs_window<T>, dim3(count), dim3(threads), 0, ctx->stream, L.U, L.Snap, L.A,
+                                   (const T *) L.Dif, ctx->d_err, tau0, K, lag, s_first, nx, ny, alpha2);
+                OFX_LAUNCH_CHECK(ctx);
+                return OFX_OK;
+            };
+            auto take = [&](int n) -> int {
+                OFX_HIP(ctx, hipMemcpyAsync(L.U, L.Snap + (size_t) (n - 1) * nx * ny, ub, hipMemcpyDeviceToDevice, ctx->stream));
+                return OFX_OK;
+            };
+            OFX_TRY(sor_window_loop(ctx, nx * ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, batch, window, take, &niter,
+                                    &error));
+        } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
+            // one launch per time step (option sor_exact = 2): the reference implementation of the exact schedule
             const size_t ub = (size_t) nx * ny * sizeof(typename Pix<T>::v2);
             const dim3 gp(ofx_cdiv(ny + 3, 64), 1), bp(64);
             auto plane = [&](int t, int s_lo, int s_cnt) -> int {
@@ -653,16 +812,16 @@ __global__ void k_brox_coeff(const T *__restrict__ I1, const typename Pix<T>::v2
 }
 
 // SOR update of one pixel, src/brox_optic_flow_spatial.cpp:129-172; returns the squared update (:166)
-template <typename T>
-OFX_DEV double brox_point(typename Pix<T>::v2 *__restrict__ DU, const typename Pix<T>::v4 *__restrict__ CO,
-                          const T *__restrict__ Dm, const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha)
+template <typename T, class Acc>
+OFX_DEV double brox_point_acc(const Acc &acc, const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
+                              const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha)
 {
     const size_t p = (size_t) i * nx + j;
     const Psi4 s = brox_psi4(Psis, i, j, nx, ny);
     // a missing neighbour is addressed as the pixel itself (offset 0) with psi = 0, :332-388
-    const double2 c = ldw2(DU + p);
-    const double2 dn = (i < ny - 1) ? ldw2(DU + p + nx) : c, up = (i > 0) ? ldw2(DU + p - nx) : c;
-    const double2 rt = (j < nx - 1) ? ldw2(DU + p + 1) : c, lf = (j > 0) ? ldw2(DU + p - 1) : c;
+    const double2 c = acc.get(i, j);
+    const double2 dn = (i < ny - 1) ? acc.get(i + 1, j) : c, up = (i > 0) ? acc.get(i - 1, j) : c;
+    const double2 rt = (j < nx - 1) ? acc.get(i, j + 1) : c, lf = (j > 0) ? acc.get(i, j - 1) : c;
     const double4 co = ldw4(CO + p);
     const double D = ldw(Dm + p);
     const double w = BROX_SOR_W;
@@ -671,8 +830,17 @@ OFX_DEV double brox_point(typename Pix<T>::v2 *__restrict__ DU, const typename P
     const double duk = c.x, dvk = c.y;
     const double dun = rnd_to<T>((1. - w) * duk + w * (co.x - D * dvk + alpha * div_du) / co.z);   // :162
     const double dvn = rnd_to<T>((1. - w) * dvk + w * (co.y - D * dun + alpha * div_dv) / co.w);   // :163
-    stn2(DU + p, make_double2(dun, dvn));
+    acc.put(i, j, make_double2(dun, dvn));
     return (dun - duk) * (dun - duk) + (dvn - dvk) * (dvn - dvk);                     // :166
+}
+
+template <typename T, bool COH = false, bool SNAP = false>
+OFX_DEV double brox_point(typename Pix<T>::v2 *DU, const typename Pix<T>::v4 *__restrict__ CO,
+                          const T *__restrict__ Dm, const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha,
+                          typename Pix<T>::v2 *snap = nullptr)
+{
+    const UGlobal<T, COH, SNAP> acc = {DU, snap, nx};
+    return brox_point_acc<T>(acc, CO, Dm, Psis, i, j, nx, ny, alpha);
 }
 
 // one colour of one SOR sweep (fast, order-changing mode): every pixel with (i + j) % 2 == colour
@@ -732,6 +900,37 @@ __global__ __launch_bounds__(64) void k_brox_plane(typename Pix<T>::v2 *__restri
     loop_accumulate(err, s, e, blockIdx.x);
 }
 
+// windowed exact mode (see k_hs_window): K steps of every sweep in flight per launch, one workgroup per sweep
+template <typename T>
+__global__ __launch_bounds__(1024) void k_brox_window(typename Pix<T>::v2 *DU, typename Pix<T>::v2 *snap,
+                                                      const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
+                                                      const T *__restrict__ Psis, double *__restrict__ err, int tau0, int K,
+                                                      int lag, int s_first, int nx, int ny, double alpha)
+{
+    const int s = s_first + blockIdx.x;
+    const int qmax = ny + nx - 2, n_items = ny + 3;
+    typename Pix<T>::v2 *mysnap = snap + (size_t) s * nx * ny;
+    double e = 0.0;
+    for (int tau = tau0; tau < tau0 + K; tau++) {
+        const int q = tau - lag * s;
+        if (q >= 0 && q <= qmax) {
+            for (int r = threadIdx.x; r < n_items; r += blockDim.x) {
+                int i, j;
+                if (r == ny + 2) {
+                    for (int corner = 0; corner < 4; corner++)
+                        if (brox_plane_item(r, q, nx, ny, corner, i, j))
+                            e += brox_point<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
+                } else if (brox_plane_item(r, q, nx, ny, 0, i, j)) {
+                    e += brox_point<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    loop_accumulate(err, s, e, threadIdx.x >> 6);
+}
+
 // u += du, v += dv, :398-401
 template <typename T>
 __global__ void k_brox_add(typename Pix<T>::v2 *__restrict__ U, const typename Pix<T>::v2 *__restrict__ DU, int n)
@@ -749,6 +948,8 @@ template <typename T> struct BroxLevel {
     T *I1, *I2, *Psis, *Dd, *Dm;
     v2 *G1, *PB, *WB, *U, *DV, *DU, *DUck;
     v4 *PA, *WA, *CO;
+    v2 *Snap;           // windowed exact mode: one snapshot plane of (du, dv) per sweep of a batch
+    int snap_planes;
 };
 
 template <typename T> static int brox_level_alloc(ofx_ctx *ctx, BroxLevel<T> &L, int nx, int ny)
@@ -769,6 +970,8 @@ template <typename T> static int brox_level_alloc(ofx_ctx *ctx, BroxLevel<T> &L,
     OFX_TRY(ofx_alloc(ctx, n, &L.PA));
     OFX_TRY(ofx_alloc(ctx, n, &L.WA));
     OFX_TRY(ofx_alloc(ctx, n, &L.CO));
+    L.Snap = nullptr;
+    L.snap_planes = 0;
     return OFX_OK;
 }
 
@@ -800,7 +1003,27 @@ template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T
             int nsor = 0;
             double error = 1000;                                                                  // :312
             float ms = 0.f;
-            if (ctx->sor_exact && nx >= 3 && ny >= 3) {
+            if (ctx->sor_exact == 1 && nx >= 3 && ny >= 3) {
+                const size_t ub = (size_t) n * sizeof(typename Pix<T>::v2);
+                const int batch = sor_pick_batch(ctx, (size_t) n, sizeof(typename Pix<T>::v2), OFX_BROX_MAX_ITERATIONS);
+                if (L.snap_planes < batch) {
+                    OFX_TRY(ofx_alloc(ctx, (size_t) n * batch, &L.Snap));
+                    L.snap_planes = batch;
+                }
+                const int threads = sor_window_threads(ny + 3);
+                auto window = [&](int tau0, int K, int lag, int s_first, int count) -> int {
+                    hipLaunchKernelGGL(k_brox_window<T>, dim3(count), dim3(threads), 0, ctx->stream, L.DU, L.Snap, L.CO,
+                                       (const T *) L.Dm, (const T *) L.Psis, ctx->d_err, tau0, K, lag, s_first, nx, ny, P.alpha);
+                    OFX_LAUNCH_CHECK(ctx);
+                    return OFX_OK;
+                };
+                auto take = [&](int k) -> int {
+                    OFX_HIP(ctx, hipMemcpyAsync(L.DU, L.Snap + (size_t) (k - 1) * n, ub, hipMemcpyDeviceToDevice, ctx->stream));
+                    return OFX_OK;
+                };
+                OFX_TRY(sor_window_loop(ctx, n, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window, take,
+                                        &nsor, &error));
+            } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
                 const size_t ub = (size_t) n * sizeof(typename Pix<T>::v2);
                 const unsigned gpx = ofx_cdiv(ny + 3, 64);
                 auto plane = [&](int t, int s_lo, int s_cnt) -> int {

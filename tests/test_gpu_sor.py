@@ -146,3 +146,46 @@ def test_sor_f32_storage(gpu32, orc, synth):
     ur, vr, _ = orc.hs_pyramidal(I1, I2, alpha=20.0, nscales=3, warps=5)
     ug, vg = gpu32.hs_pyramidal(I1, I2, alpha=20.0, nscales=3, warps=5)
     assert aepe(ug, vg, ur, vr) < 1e-3
+
+
+# ---- the two implementations of the exact schedule ----------------------------------------------------------
+@pytest.mark.parametrize("mode,window", [(2, 0), (1, 1), (1, 5), (1, 32), (1, 200)])
+def test_exact_schedule_variants_agree_with_reference(gpu64, orc, synth, mode, window):
+    """sor_exact = 2: one launch per time step; sor_exact = 1: K time steps per launch (windowed, one workgroup
+    per sweep, snapshots instead of rollback).  Both must reproduce the reference order for any window."""
+    I1, I2 = synth.pair("P1", 90, 61)
+    z = np.zeros((61, 90))
+    uo, vo, it_o = orc.hs_single_scale(I1, I2, z, z, alpha=12.0, warps=3)
+    kw = dict(alpha=50.0, gamma=10.0, nscales=2, nu=0.5, TOL=1e-4, inner=2, outer=3)
+    ur, vr, it_r = orc.brox_spatial(I1, I2, **kw)
+    gpu64.set_option("sor_exact", mode)
+    gpu64.set_option("sor_window", window)
+    try:
+        ug, vg = gpu64.hs_single_scale(I1, I2, z, z, alpha=12.0, warps=3)
+        it_g = list(gpu64.stats().iterations()[0])
+        ub, vb = gpu64.brox_spatial(I1, I2, **kw)
+        it_b = gpu64.stats().iterations()
+    finally:
+        gpu64.set_option("sor_exact", 1)
+        gpu64.set_option("sor_window", 0)
+    assert it_g == it_o and np.array_equal(it_b, it_r)
+    assert np.abs(ug - uo).max() < 1e-12 and np.abs(vg - vo).max() < 1e-12
+    assert np.abs(ub - ur).max() < 1e-11 and np.abs(vb - vr).max() < 1e-11
+
+
+@pytest.mark.parametrize("nx,ny", [(24, 1100), (20, 1250), (1100, 24), (3, 3), (3, 40), (40, 3)])
+def test_exact_windowed_extreme_shapes(gpu64, orc, synth, nx, ny):
+    """more plane items than threads of a workgroup (ny + 3 > 1024), and the smallest images with an interior"""
+    I1, I2 = synth.pair("P1", nx, ny, 2)
+    z = np.zeros((ny, nx))
+    uo, vo, it_o = orc.hs_single_scale(I1, I2, z, z, alpha=15.0, warps=2, maxiter=40)
+    ug, vg = gpu64.hs_single_scale(I1, I2, z, z, alpha=15.0, warps=2, maxiter=40)
+    assert list(gpu64.stats().iterations()[0]) == it_o
+    assert np.abs(ug - uo).max() < 1e-12 and np.abs(vg - vo).max() < 1e-12
+    if min(nx, ny) < 5:
+        return          # Brox presmooths (radius 5 > image: "sigma too large" in the reference, operators.cpp:520)
+    kw = dict(alpha=30.0, gamma=5.0, nscales=1, nu=0.5, TOL=1e-4, inner=1, outer=2)
+    ur, vr, it_r = orc.brox_spatial(I1, I2, **kw)
+    ub, vb = gpu64.brox_spatial(I1, I2, **kw)
+    assert np.array_equal(gpu64.stats().iterations(), it_r)
+    assert np.abs(ub - ur).max() < 1e-11 and np.abs(vb - vr).max() < 1e-11

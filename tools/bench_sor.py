@@ -12,6 +12,12 @@ ctx = ofx.Ofx(0, ofx.F64)
 cpu = oracle.Ref() if oracle.have_ref() else oracle.Oracle()
 cores = min(oracle.host_cores(), 32)
 small = "--small" in sys.argv
+MODES = ("exact", "colour") if "--no-per-step" in sys.argv else ("exact", "exact_per_step", "colour")
+for a in sys.argv[1:]:
+    if a.startswith("--window="):
+        ctx.set_option("sor_window", int(a.split("=")[1]))
+    if a.startswith("--batch="):
+        ctx.set_option("sor_batch", int(a.split("=")[1]))
 
 
 def aepe(a, b):
@@ -21,8 +27,8 @@ def aepe(a, b):
 def run(name, gpu_fn, cpu_fn, I1, I2, kw):
     out = {"config": name, "size": "%dx%d" % (I1.shape[1], I1.shape[0])}
     res = {}
-    for mode in ("exact", "colour"):
-        ctx.set_option("sor_exact", 1 if mode == "exact" else 0)
+    for mode in MODES:
+        ctx.set_option("sor_exact", {"exact": 1, "exact_per_step": 2, "colour": 0}[mode])
         gpu_fn(I1, I2, **kw)                                   # warm (arena, clocks)
         t0 = time.perf_counter()
         res[mode] = gpu_fn(I1, I2, **kw)
