@@ -9,12 +9,15 @@ DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 
 shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, tag + "_bench.json"))
+for extra in ("bench_4k", "bench_f32", "bench_4k_f32"):
+    if os.path.exists(os.path.join(SRC, extra + ".json")) and os.path.getsize(os.path.join(SRC, extra + ".json")):
+        shutil.copy(os.path.join(SRC, extra + ".json"), os.path.join(DST, tag + "_" + extra + ".json"))
 bench = json.load(open(os.path.join(SRC, "bench.json")))
 
 # ---- kernel stats of the bench command ----
 stats = list(csv.DictReader(open(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0])))
 trace = list(csv.DictReader(open(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv"))[0])))
-out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu --streams 1   (MI355X, f64, 1920x1080 P1)",
+out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu --streams 1 --lockstep 1   (MI355X, f64, 1920x1080 P1)",
        "# the run contains the reference-semantics steps (eps=0.01) AND the fixed-work passes (300 iterations / warp)",
        "# kernel | calls | total ms | average us | % of GPU time", ""]
 for r in stats:
