@@ -90,6 +90,7 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         0 = colour-ordered sweeps (much faster, result drifts by ~1e-5..1e-3 px)
  *   "sor_batch"      sweeps in flight per batch in the exact modes (default 32 / 64)
  *   "sor_window"     time steps per launch of sor_exact = 1 (default 8)
+ *   "sor_rows"       rows per workgroup (row block of a sweep) of sor_exact = 1 (default 64)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
  *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default 4, at most 16)
  *   "concurrency"    number of contexts that will be solving on the same device at the same time

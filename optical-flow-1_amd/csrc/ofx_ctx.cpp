@@ -68,6 +68,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->sor_exact = 1;
     ctx->sor_batch = 0;
     ctx->sor_window = 0;
+    ctx->sor_rows = 0;
     ctx->poll_seq = 0;
     ctx->errmsg[0] = 0;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
@@ -143,6 +144,11 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "sor_exact")) {
         if (value != 0 && value != 1 && value != 2) return ofx_fail(ctx, OFX_ERR_ARG, "sor_exact must be 0, 1 or 2");
         ctx->sor_exact = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "sor_rows")) {
+        if (value < 0 || value > 4096) return ofx_fail(ctx, OFX_ERR_ARG, "sor_rows out of range");
+        ctx->sor_rows = (int) value;
         return OFX_OK;
     }
     if (!strcmp(name, "sor_window")) {

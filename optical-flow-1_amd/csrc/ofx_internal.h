@@ -59,6 +59,7 @@ struct ofx_ctx {
     int sor_exact;      // 1: reference sweep order, windowed launches; 2: same, one launch per time step; 0: colour order
     int sor_batch;      // sweeps in flight per batch in exact mode (0 = default)
     int sor_window;     // time steps per launch of the windowed exact mode (0 = 8)
+    int sor_rows;       // rows per block (workgroup) of a sweep in the windowed exact mode (0 = 64)
     unsigned long long poll_seq;
 
     ofx_stats stats;

@@ -215,46 +215,79 @@ __global__ __launch_bounds__(64) void k_hs_plane(typename Pix<T>::v2 *__restrict
 #ifndef OFX_SOR_COH
 #define OFX_SOR_COH 0
 #endif
+// Geometry of one windowed launch (see sor_window_loop).  A sweep is further cut into row blocks of R rows,
+// one workgroup per (sweep, block): block b runs lag_b steps behind block b - 1 of its sweep, sweeps are
+// lag_s apart, and a border pixel is executed by the block of the interior row it depends on last.
+struct SorWin {
+    int tau0, K, lag_s, lag_b, s_first, R;
+};
+// which plane item thread t of block b plays: its R rows, then the three shared items (first column, last
+// column, corners) of which a block accepts only the pixels assigned to it (sor_border_block)
+OFX_DEV int sor_window_item(const SorWin &w, int b, int t, int ny)
+{
+    if (t < w.R) { const int r = b * w.R + t; return r < ny ? r : -1; }
+    return t < w.R + 3 ? ny + (t - w.R) : -1;
+}
+// block of a border-column / corner pixel: the row below for the columns (the interior pixel (i+1, 1) precedes
+// (i, 0) in the reference order), row 2 for the top corners, the last row for the bottom corners
+OFX_DEV int sor_border_block(int i, int ny, int R)
+{
+    int r;
+    if (i == 0) r = ny - 1 < 2 ? ny - 1 : 2;
+    else if (i == ny - 1) r = ny - 1;
+    else r = i + 1;
+    return r / R;
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void k_hs_window(typename Pix<T>::v2 *U, typename Pix<T>::v2 *snap,
                                                     const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif,
-                                                    double *__restrict__ err, int tau0, int K, int lag, int s_first,
-                                                    int nx, int ny, double alpha2)
+                                                    double *__restrict__ err, SorWin w, int nx, int ny, double alpha2)
 {
-    const int s = s_first + blockIdx.x;
-    const int qmax = 2 * ny + nx - 2, n_items = ny + 3;
+    const int b = blockIdx.x, s = w.s_first + blockIdx.y;
+    const int qmax = 2 * ny + nx - 2;
+    const int q_first = w.tau0 - w.lag_s * s - w.lag_b * b;
+    if (q_first > qmax || q_first + w.K - 1 < 0) return;         // this (sweep, block) has no step in the window
     typename Pix<T>::v2 *mysnap = snap + (size_t) s * nx * ny;
+    const int r = sor_window_item(w, b, threadIdx.x, ny);
     double e = 0.0;
-    for (int tau = tau0; tau < tau0 + K; tau++) {
-        const int q = tau - lag * s;
-        if (q >= 0 && q <= qmax) {
-            for (int r = threadIdx.x; r < n_items; r += blockDim.x) {
-                int i, j;
-                if (r == ny + 2) {
-                    for (int corner = 0; corner < 4; corner++)
-                        if (hs_plane_item(r, q, nx, ny, corner, i, j))
-                            e += hs_point<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
-                } else if (hs_plane_item(r, q, nx, ny, 0, i, j)) {
-                    e += hs_point<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
-                }
+    for (int q = q_first; q < q_first + w.K; q++) {
+        if (q >= 0 && q <= qmax && r >= 0) {
+            int i, j;
+            if (r == ny + 2) {
+                for (int corner = 0; corner < 4; corner++)
+                    if (hs_plane_item(r, q, nx, ny, corner, i, j) && sor_border_block(i, ny, w.R) == b)
+                        e += hs_point<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
+            } else if (hs_plane_item(r, q, nx, ny, 0, i, j) && (r < ny || sor_border_block(i, ny, w.R) == b)) {
+                e += hs_point<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this step's stores have reached L2 ...
         __syncthreads();                                       // ... before any wave of the workgroup reads them
     }
-    loop_accumulate(err, s, e, threadIdx.x >> 6);
+    loop_accumulate(err, s, e, b * 4 + (threadIdx.x >> 6));
 }
 
-// Batch driver of the windowed exact mode.  launch(tau0, K, lag, s_first, count) enqueues one window; take(n)
-// makes snapshot n - 1 the current state.  Same contract as sor_exact_loop.
+// Batch driver of the windowed exact mode.  launch(w, blocks, sweeps) enqueues one window over `blocks` row
+// blocks x `sweeps` sweeps starting at w.s_first; take(n) makes snapshot n - 1 the current state.  Same contract
+// as sor_exact_loop.  Spacing: lag_b = K between the row blocks of a sweep, lag_s = 2 K + C between sweeps (K + C
+// when a sweep is one block): with these every value a workgroup reads from ANOTHER (sweep, block) was written
+// at least one launch earlier and is overwritten at least one launch later (checked exhaustively on small
+// images for both stencils, tools/check_sor_schedule.py).
 template <class WindowFn, class TakeFn>
-static int sor_window_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int qmax, int C, int batch, WindowFn launch,
-                           TakeFn take, int *n_out, double *err_out)
+static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxiter, int qmax, int C, int batch,
+                           WindowFn launch, TakeFn take, int *n_out, double *err_out)
 {
     int niter = 0;
     double error = 1000;
-    const int K = ctx->sor_window > 0 ? ctx->sor_window : 8;
-    const int lag = K + C;
+    SorWin w;
+    w.K = ctx->sor_window > 0 ? ctx->sor_window : 8;
+    w.R = ctx->sor_rows > 0 ? ctx->sor_rows : 64;
+    if (w.R < 2) w.R = 2;
+    if (w.R > 1021) w.R = 1021;                                  // R + 3 threads per workgroup
+    const int B = ofx_cdiv(ny, w.R);
+    w.lag_b = w.K;
+    w.lag_s = (B > 1 ? 2 * w.K : w.K) + C;
     OFX_TRY(ofx_loop_reserve(ctx, batch + 1));
     LoopSpec LS;
     LS.size = size;
@@ -267,14 +300,17 @@ static int sor_window_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int 
         const int ns = (maxiter - niter < batch) ? maxiter - niter : batch;
         OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) ns * OFX_NSHARD, ctx->stream));
         OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
-        const long total = (long) qmax + 1 + (long) lag * (ns - 1);
-        for (long tau0 = 0; tau0 < total; tau0 += K) {
-            long s_lo = (tau0 - qmax + lag - 1) / lag;          // smallest s with tau0 - lag s <= qmax
-            if (tau0 - qmax < 0) s_lo = 0;
-            long s_hi = (tau0 + K - 1) / lag;                   // largest s with tau0 + K - 1 - lag s >= 0
+        const long tail = (long) w.lag_b * (B - 1);              // the last block of a sweep ends this much later
+        const long total = (long) qmax + 1 + tail + (long) w.lag_s * (ns - 1);
+        for (long tau0 = 0; tau0 < total; tau0 += w.K) {
+            long s_lo = (tau0 - qmax - tail + w.lag_s - 1) / w.lag_s;   // smallest s still inside the image
+            if (tau0 - qmax - tail < 0) s_lo = 0;
+            long s_hi = (tau0 + w.K - 1) / w.lag_s;              // largest s that has started
             if (s_hi > ns - 1) s_hi = ns - 1;
             if (s_hi < s_lo) continue;
-            OFX_TRY(launch((int) tau0, K, lag, (int) s_lo, (int) (s_hi - s_lo + 1)));
+            w.tau0 = (int) tau0;
+            w.s_first = (int) s_lo;
+            OFX_TRY(launch(w, B, (int) (s_hi - s_lo + 1)));
         }
         LS.max_iter = ns;
         const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
@@ -424,10 +460,9 @@ template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L
                 OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny * batch, &L.Snap));
                 L.snap_planes = batch;
             }
-            const int threads = sor_window_threads(ny + 3);
-            auto window = [&](int tau0, int K, int lag, int s_first, int count) -> int {
-                hipLaunchKernelGGL(k_hs_window<T>, dim3(count), dim3(threads), 0, ctx->stream, L.U, L.Snap, L.A,
-                                   (const T *) L.Dif, ctx->d_err, tau0, K, lag, s_first, nx, ny, alpha2);
+            auto window = [&](const SorWin &w, int blocks, int sweeps) -> int {
+                hipLaunchKernelGGL(k_hs_window<T>, dim3(blocks, sweeps), dim3(sor_window_threads(w.R + 3)), 0, ctx->stream,
+                                   L.U, L.Snap, L.A, (const T *) L.Dif, ctx->d_err, w, nx, ny, alpha2);
                 OFX_LAUNCH_CHECK(ctx);
                 return OFX_OK;
             };
@@ -435,8 +470,8 @@ template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L
                 OFX_HIP(ctx, hipMemcpyAsync(L.U, L.Snap + (size_t) (n - 1) * nx * ny, ub, hipMemcpyDeviceToDevice, ctx->stream));
                 return OFX_OK;
             };
-            OFX_TRY(sor_window_loop(ctx, nx * ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, batch, window, take, &niter,
-                                    &error));
+            OFX_TRY(sor_window_loop(ctx, nx * ny, ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, batch, window, take,
+                                    &niter, &error));
         } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
             // one launch per time step (option sor_exact = 2): the reference implementation of the exact schedule
             const size_t ub = (size_t) nx * ny * sizeof(typename Pix<T>::v2);
@@ -900,35 +935,35 @@ __global__ __launch_bounds__(64) void k_brox_plane(typename Pix<T>::v2 *__restri
     loop_accumulate(err, s, e, blockIdx.x);
 }
 
-// windowed exact mode (see k_hs_window): K steps of every sweep in flight per launch, one workgroup per sweep
+// windowed exact mode (see k_hs_window): K steps per launch, one workgroup per (sweep, row block)
 template <typename T>
 __global__ __launch_bounds__(1024) void k_brox_window(typename Pix<T>::v2 *DU, typename Pix<T>::v2 *snap,
                                                       const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
-                                                      const T *__restrict__ Psis, double *__restrict__ err, int tau0, int K,
-                                                      int lag, int s_first, int nx, int ny, double alpha)
+                                                      const T *__restrict__ Psis, double *__restrict__ err, SorWin w,
+                                                      int nx, int ny, double alpha)
 {
-    const int s = s_first + blockIdx.x;
-    const int qmax = ny + nx - 2, n_items = ny + 3;
+    const int b = blockIdx.x, s = w.s_first + blockIdx.y;
+    const int qmax = ny + nx - 2;
+    const int q_first = w.tau0 - w.lag_s * s - w.lag_b * b;
+    if (q_first > qmax || q_first + w.K - 1 < 0) return;
     typename Pix<T>::v2 *mysnap = snap + (size_t) s * nx * ny;
+    const int r = sor_window_item(w, b, threadIdx.x, ny);
     double e = 0.0;
-    for (int tau = tau0; tau < tau0 + K; tau++) {
-        const int q = tau - lag * s;
-        if (q >= 0 && q <= qmax) {
-            for (int r = threadIdx.x; r < n_items; r += blockDim.x) {
-                int i, j;
-                if (r == ny + 2) {
-                    for (int corner = 0; corner < 4; corner++)
-                        if (brox_plane_item(r, q, nx, ny, corner, i, j))
-                            e += brox_point<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
-                } else if (brox_plane_item(r, q, nx, ny, 0, i, j)) {
-                    e += brox_point<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
-                }
+    for (int q = q_first; q < q_first + w.K; q++) {
+        if (q >= 0 && q <= qmax && r >= 0) {
+            int i, j;
+            if (r == ny + 2) {
+                for (int corner = 0; corner < 4; corner++)
+                    if (brox_plane_item(r, q, nx, ny, corner, i, j) && sor_border_block(i, ny, w.R) == b)
+                        e += brox_point<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
+            } else if (brox_plane_item(r, q, nx, ny, 0, i, j) && (r < ny || sor_border_block(i, ny, w.R) == b)) {
+                e += brox_point<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    loop_accumulate(err, s, e, threadIdx.x >> 6);
+    loop_accumulate(err, s, e, b * 4 + (threadIdx.x >> 6));
 }
 
 // u += du, v += dv, :398-401
@@ -1010,10 +1045,10 @@ template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T
                     OFX_TRY(ofx_alloc(ctx, (size_t) n * batch, &L.Snap));
                     L.snap_planes = batch;
                 }
-                const int threads = sor_window_threads(ny + 3);
-                auto window = [&](int tau0, int K, int lag, int s_first, int count) -> int {
-                    hipLaunchKernelGGL(k_brox_window<T>, dim3(count), dim3(threads), 0, ctx->stream, L.DU, L.Snap, L.CO,
-                                       (const T *) L.Dm, (const T *) L.Psis, ctx->d_err, tau0, K, lag, s_first, nx, ny, P.alpha);
+                auto window = [&](const SorWin &w, int blocks, int sweeps) -> int {
+                    hipLaunchKernelGGL(k_brox_window<T>, dim3(blocks, sweeps), dim3(sor_window_threads(w.R + 3)), 0,
+                                       ctx->stream, L.DU, L.Snap, L.CO, (const T *) L.Dm, (const T *) L.Psis, ctx->d_err, w,
+                                       nx, ny, P.alpha);
                     OFX_LAUNCH_CHECK(ctx);
                     return OFX_OK;
                 };
@@ -1021,8 +1056,8 @@ template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T
                     OFX_HIP(ctx, hipMemcpyAsync(L.DU, L.Snap + (size_t) (k - 1) * n, ub, hipMemcpyDeviceToDevice, ctx->stream));
                     return OFX_OK;
                 };
-                OFX_TRY(sor_window_loop(ctx, n, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window, take,
-                                        &nsor, &error));
+                OFX_TRY(sor_window_loop(ctx, n, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
+                                        take, &nsor, &error));
             } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
                 const size_t ub = (size_t) n * sizeof(typename Pix<T>::v2);
                 const unsigned gpx = ofx_cdiv(ny + 3, 64);

@@ -149,10 +149,11 @@ def test_sor_f32_storage(gpu32, orc, synth):
 
 
 # ---- the two implementations of the exact schedule ----------------------------------------------------------
-@pytest.mark.parametrize("mode,window", [(2, 0), (1, 1), (1, 5), (1, 32), (1, 200)])
-def test_exact_schedule_variants_agree_with_reference(gpu64, orc, synth, mode, window):
+@pytest.mark.parametrize("mode,window,rows", [(2, 0, 0), (1, 1, 2), (1, 5, 3), (1, 8, 7), (1, 32, 0), (1, 200, 16), (1, 8, 1000)])
+def test_exact_schedule_variants_agree_with_reference(gpu64, orc, synth, mode, window, rows):
     """sor_exact = 2: one launch per time step; sor_exact = 1: K time steps per launch (windowed, one workgroup
-    per sweep, snapshots instead of rollback).  Both must reproduce the reference order for any window."""
+    per (sweep, row block), snapshots instead of rollback).  Both must reproduce the reference order for any window
+    length and block height."""
     I1, I2 = synth.pair("P1", 90, 61)
     z = np.zeros((61, 90))
     uo, vo, it_o = orc.hs_single_scale(I1, I2, z, z, alpha=12.0, warps=3)
@@ -160,6 +161,7 @@ def test_exact_schedule_variants_agree_with_reference(gpu64, orc, synth, mode, w
     ur, vr, it_r = orc.brox_spatial(I1, I2, **kw)
     gpu64.set_option("sor_exact", mode)
     gpu64.set_option("sor_window", window)
+    gpu64.set_option("sor_rows", rows)          # rows per workgroup: a sweep is cut into row blocks
     try:
         ug, vg = gpu64.hs_single_scale(I1, I2, z, z, alpha=12.0, warps=3)
         it_g = list(gpu64.stats().iterations()[0])
@@ -168,6 +170,7 @@ def test_exact_schedule_variants_agree_with_reference(gpu64, orc, synth, mode, w
     finally:
         gpu64.set_option("sor_exact", 1)
         gpu64.set_option("sor_window", 0)
+        gpu64.set_option("sor_rows", 0)
     assert it_g == it_o and np.array_equal(it_b, it_r)
     assert np.abs(ug - uo).max() < 1e-12 and np.abs(vg - vo).max() < 1e-12
     assert np.abs(ub - ur).max() < 1e-11 and np.abs(vb - vr).max() < 1e-11

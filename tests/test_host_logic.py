@@ -144,3 +144,15 @@ def test_synthetic_pairs_are_stable(synth):
     a0, _ = synth.pair("P1", 64, 48, 0)
     a1, _ = synth.pair("P1", 64, 48, 1)
     assert not np.array_equal(a0, a1)
+
+
+def test_windowed_sor_schedule_is_valid():
+    """the (sweep, row block, step) schedule of the windowed exact SOR kernels never reads a value of another
+    workgroup from the same launch, and never has one overwritten in it (tools/check_sor_schedule.py)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_sor_schedule", os.path.join(ROOT, "tools", "check_sor_schedule.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for solver in ("hs", "brox"):
+        for nx, ny, K, B in [(23, 30, 8, 3), (9, 12, 4, 5), (12, 40, 1, 4), (7, 9, 8, 1), (16, 9, 8, 2)]:
+            assert mod.check(nx, ny, K, B, solver, 2) == 0

@@ -16,6 +16,8 @@ MODES = ("exact", "colour") if "--no-per-step" in sys.argv else ("exact", "exact
 for a in sys.argv[1:]:
     if a.startswith("--window="):
         ctx.set_option("sor_window", int(a.split("=")[1]))
+    if a.startswith("--rows="):
+        ctx.set_option("sor_rows", int(a.split("=")[1]))
     if a.startswith("--batch="):
         ctx.set_option("sor_batch", int(a.split("=")[1]))
 

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Exhaustive check of the windowed exact-SOR schedule of optical-flow-1_amd/csrc/ofx_sor.hip (sor_window_loop,
+k_hs_window / k_brox_window) on small images.
+
+Pixel X of sweep s, executed by row block blk(X), runs at global step
+    tau(X, s) = pos(X) + lag_b * blk(X) + lag_s * s,      lag_b = K,  lag_s = m K + C  (the kernels use m = 2)
+and launch L executes the steps [K L, K L + K).  For every pixel and every neighbour the in-place sweep of the
+reference (interior rows lexicographic, then border rows, border columns, corners) reads a definite version of
+that neighbour; the schedule is valid iff
+  (1) that version was written earlier and is overwritten later,
+  (2) if it was written by another workgroup (other sweep or other row block): in an EARLIER launch,
+  (3) if it is overwritten by another workgroup: in a LATER launch.
+check(...) returns the number of violated (pixel, neighbour) pairs.  Run as a script for the full table; a
+subset runs in tests/test_host_logic.py."""
+import sys
+
+
+def check(nx, ny, K, B, solver, m, verbose=False):
+    if solver=="hs":
+        C=6
+        def pos(i,j):
+            if (i,j)==(0,0): return 7
+            if (i,j)==(0,nx-1): return nx+4
+            if (i,j)==(ny-1,0): return 2*ny+1
+            if (i,j)==(ny-1,nx-1): return 2*ny+nx-2
+            if i==0: return j+4
+            if i==ny-1: return 2*(ny-1)+j
+            if j==0: return 2*i+4
+            if j==nx-1: return 2*i+nx+1
+            return 2*i+j
+        nbrs=[(-1,-1),(-1,0),(-1,1),(0,-1),(0,1),(1,-1),(1,0),(1,1)]
+    else:
+        C=2
+        def pos(i,j):
+            if (i,j)==(0,0): return 4
+            if (i,j)==(0,nx-1): return nx+1
+            if (i,j)==(ny-1,0): return ny+1
+            if (i,j)==(ny-1,nx-1): return ny+nx-2
+            if i==0: return j+2
+            if i==ny-1: return ny-1+j
+            if j==0: return i+2
+            if j==nx-1: return i+nx-1
+            return i+j
+        nbrs=[(-1,0),(0,-1),(0,1),(1,0)]
+    R=-(-ny//B)
+    lag_b=K; lag_s=m*K+C if B>1 else K+C
+    order=[]
+    for i in range(1,ny-1):
+        for j in range(1,nx-1): order.append((i,j))
+    for j in range(1,nx-1): order.append((0,j)); order.append((ny-1,j))
+    for i in range(1,ny-1): order.append((i,0)); order.append((i,nx-1))
+    order+=[(0,0),(0,nx-1),(ny-1,0),(ny-1,nx-1)]
+    rank={x:k for k,x in enumerate(order)}
+    def blk(i,j):
+        # block that executes pixel (i,j): interior/last-row pixels by their row; first row with row 1;
+        # border columns with the row below; top corners with row 2; bottom corners with the last row
+        if i==0 and (j==0 or j==nx-1): r=min(2,ny-1)
+        elif i==ny-1: r=ny-1
+        elif i==0: r=1
+        elif j==0 or j==nx-1: r=min(i+1,ny-1)
+        else: r=i
+        return r//R
+    tau=lambda i,j,s: pos(i,j)+lag_b*blk(i,j)+lag_s*s
+    bad=0
+    for s in (1,2):
+      for i in range(ny):
+        for j in range(nx):
+            tx=tau(i,j,s)
+            for di,dj in nbrs:
+                ii=min(max(i+di,0),ny-1); jj=min(max(j+dj,0),nx-1)
+                if (ii,jj)==(i,j): continue
+                before = rank[(ii,jj)]<rank[(i,j)]
+                sv = s if before else s-1
+                ty=tau(ii,jj,sv)
+                ok = ty < tx and tau(ii,jj,sv+1) > tx
+                if ok and (blk(ii,jj)!=blk(i,j) or sv!=s):
+                    ok = (ty//K) < (tx//K)
+                if ok and (blk(ii,jj)!=blk(i,j) or sv+1!=s):
+                    ok = (tau(ii,jj,sv+1)//K) > (tx//K)
+                if not ok:
+                    bad+=1
+                    if verbose and bad<4: print("viol",solver,nx,ny,K,B,m,(i,j),(ii,jj),tx,ty,before)
+    return bad
+
+if __name__ == "__main__":
+    bad = 0
+    for solver in ("hs", "brox"):
+        for nx, ny in [(23, 52), (36, 37), (7, 9), (5, 5), (40, 11), (12, 64), (3, 8)]:
+            for K in (1, 4, 8):
+                for B in (1, 2, 3, 5):
+                    if B > 1 and -(-ny // B) < 2:
+                        continue
+                    bad += check(nx, ny, K, B, solver, 2, verbose=True)
+    print("violations", bad)
+    sys.exit(1 if bad else 0)

@@ -7,7 +7,9 @@ d = sys.argv[1]
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 f = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]))
+# SOR window kernels: one workgroup per sweep, the workgroup size tells the pyramid level -> keyed by it
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+             int(r["Workgroup_Size_X"]) if "_window" in r["Kernel_Name"] else int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]))
             for r in rows)
 t0, t1 = ev[0][0], max(e[1] for e in ev)
 cut = t0 + skip * (t1 - t0)
@@ -26,7 +28,7 @@ print("span %.3f ms  busy(union) %.3f ms = %.1f %%  kernels %d" % ((t1 - t0) / 1
 agg = collections.defaultdict(lambda: [0, 0])
 for s, e, name, gx, gy in ev:
     short = name.split("(")[0].replace("void ", "")[:40]
-    key = (short, gx, gy) if "tvl1_iter" in name or "warp" in name else (short, 0, 0)
+    key = (short, gx, gy) if "tvl1_iter" in name or "warp" in name or "_window" in name else (short, 0, 0)
     agg[key][0] += 1
     agg[key][1] += e - s
 print("%-42s %9s %4s %8s %10s %9s" % ("kernel", "grid_x", "gy", "calls", "total_ms", "avg_us"))
