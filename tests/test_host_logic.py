@@ -156,3 +156,18 @@ def test_windowed_sor_schedule_is_valid():
     for solver in ("hs", "brox"):
         for nx, ny, K, B in [(23, 30, 8, 3), (9, 12, 4, 5), (12, 40, 1, 4), (7, 9, 8, 1), (16, 9, 8, 2)]:
             assert mod.check(nx, ny, K, B, solver, 2) == 0
+
+
+def test_flo_reader_on_the_reference_own_flow_file(io):
+    """tests/golden/ipol_tvl1flow_3_uv.flo is the one data file the reference ships (3rdparty/tvl1flow_3/uv.flo,
+    a 256x256 flow written by the IPOL original's iio; its input images were removed upstream, so it pins the
+    .flo layout our reader / writer use, not a solver)."""
+    path = os.path.join(ROOT, "tests", "golden", "ipol_tvl1flow_3_uv.flo")
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"PIEH" and struct.unpack("<II", raw[4:12]) == (256, 256) and len(raw) == 12 + 256 * 256 * 8
+    want = np.frombuffer(raw[12:], dtype=np.float32).reshape(256, 256, 2)
+    w, h = C.c_int(), C.c_int()
+    p = io.ofx_read_flo(path.encode(), C.byref(w), C.byref(h))
+    assert (w.value, h.value) == (256, 256)
+    got = np.ctypeslib.as_array(p, shape=(256, 256, 2))
+    assert np.array_equal(got, want) and np.isfinite(got).all()
