@@ -2,6 +2,8 @@
 #include "ofx_io.h"
 
 #include <ctype.h>
+#include <dlfcn.h>
+#include <setjmp.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -78,12 +80,122 @@ static float *read_pfm(FILE *f, int colour, int *w, int *h, int *pd)
     return data;                                          /* no flip, no byte swap (iio.cpp:2216) */
 }
 
+/* ---- PNG through the system's libpng16, bound at run time ---------------------------------------------
+ * The reference decodes PNG with libpng (iio.cpp:1365-1438): png_read_png with PNG_TRANSFORM_PACKING |
+ * PNG_TRANSFORM_EXPAND, i.e. 1/2/4-bit gray scaled to 8 bit, palettes expanded to RGB, tRNS to an alpha channel;
+ * 8-bit samples become IIO_TYPE_CHAR (= uint8, :493-494), 16-bit samples host-order uint16 (:1421-1432).
+ * iio_read_image_double (:3580-3605) then collapses exactly-3-channel images to gray
+ * (uint8)(.299 R + .587 G + .114 B) -- double arithmetic truncated to uint8 (:1100-1108; uint16 colour is
+ * "uncolorize type not supported", :1119-1121) -- and rejects every other channel count but 1 ("non-scalar image").
+ * There are no libpng headers in the build image, so the handful of entry points used is declared here and the
+ * library is dlopen'ed; without it PNG input fails with a message, the other formats are unaffected. */
+typedef struct ofx_png_struct ofx_png_struct;
+typedef struct ofx_png_info ofx_png_info;
+#define OFX_PNG_TRANSFORM_PACKING 0x0004
+#define OFX_PNG_TRANSFORM_EXPAND 0x0010
+struct ofx_png_api {
+    void *lib;
+    const char *(*get_libpng_ver)(const ofx_png_struct *);
+    ofx_png_struct *(*create_read_struct)(const char *, void *, void *, void *);
+    ofx_png_info *(*create_info_struct)(ofx_png_struct *);
+    jmp_buf *(*set_longjmp_fn)(ofx_png_struct *, void (*)(jmp_buf, int), size_t);
+    void (*init_io)(ofx_png_struct *, FILE *);
+    void (*read_png)(ofx_png_struct *, ofx_png_info *, int, void *);
+    uint32_t (*get_image_width)(const ofx_png_struct *, const ofx_png_info *);
+    uint32_t (*get_image_height)(const ofx_png_struct *, const ofx_png_info *);
+    unsigned char (*get_channels)(const ofx_png_struct *, const ofx_png_info *);
+    unsigned char (*get_bit_depth)(const ofx_png_struct *, const ofx_png_info *);
+    unsigned char **(*get_rows)(const ofx_png_struct *, const ofx_png_info *);
+    void (*destroy_read_struct)(ofx_png_struct **, ofx_png_info **, ofx_png_info **);
+};
+
+static const struct ofx_png_api *png_api(void)
+{
+    static struct ofx_png_api api;
+    static int state = 0;                                  /* 0 untried, 1 ok, -1 unavailable */
+    if (state) return state > 0 ? &api : NULL;
+    state = -1;
+    api.lib = dlopen("libpng16.so.16", RTLD_NOW | RTLD_LOCAL);
+    if (!api.lib) api.lib = dlopen("libpng16.so", RTLD_NOW | RTLD_LOCAL);
+    if (!api.lib) return NULL;
+#define OFX_PNG_SYM(field, name)                                                                  \
+    do {                                                                                          \
+        *(void **) (&api.field) = dlsym(api.lib, name);                                           \
+        if (!api.field) return NULL;                                                              \
+    } while (0)
+    OFX_PNG_SYM(get_libpng_ver, "png_get_libpng_ver");
+    OFX_PNG_SYM(create_read_struct, "png_create_read_struct");
+    OFX_PNG_SYM(create_info_struct, "png_create_info_struct");
+    OFX_PNG_SYM(set_longjmp_fn, "png_set_longjmp_fn");
+    OFX_PNG_SYM(init_io, "png_init_io");
+    OFX_PNG_SYM(read_png, "png_read_png");
+    OFX_PNG_SYM(get_image_width, "png_get_image_width");
+    OFX_PNG_SYM(get_image_height, "png_get_image_height");
+    OFX_PNG_SYM(get_channels, "png_get_channels");
+    OFX_PNG_SYM(get_bit_depth, "png_get_bit_depth");
+    OFX_PNG_SYM(get_rows, "png_get_rows");
+    OFX_PNG_SYM(destroy_read_struct, "png_destroy_read_struct");
+#undef OFX_PNG_SYM
+    state = 1;
+    return &api;
+}
+
+/* f is positioned at the start of the file.  Returns gray samples as double, or NULL. */
+static double *read_png(FILE *f, int *w, int *h)
+{
+    const struct ofx_png_api *P = png_api();
+    if (!P) {
+        fprintf(stderr, "PNG input needs libpng16.so.16 at run time (not found)\n");
+        return NULL;
+    }
+    ofx_png_struct *pp = P->create_read_struct(P->get_libpng_ver(NULL), NULL, NULL, NULL);
+    if (!pp) return NULL;
+    ofx_png_info *pi = P->create_info_struct(pp);
+    double *volatile out = NULL;
+    if (!pi) { P->destroy_read_struct(&pp, NULL, NULL); return NULL; }
+    jmp_buf *jb = P->set_longjmp_fn(pp, longjmp, sizeof(jmp_buf));
+    if (!jb || setjmp(*jb)) {                              /* libpng reports a broken file by longjmp */
+        P->destroy_read_struct(&pp, &pi, NULL);
+        free(out);
+        return NULL;
+    }
+    P->init_io(pp, f);
+    P->read_png(pp, pi, OFX_PNG_TRANSFORM_PACKING | OFX_PNG_TRANSFORM_EXPAND, NULL);      /* iio.cpp:1386-1390 */
+    const uint32_t ww = P->get_image_width(pp, pi), hh = P->get_image_height(pp, pi);
+    const int ch = P->get_channels(pp, pi), depth = P->get_bit_depth(pp, pi);
+    unsigned char **rows = P->get_rows(pp, pi);
+    const int ok = rows && ww > 0 && hh > 0 && ((depth == 8 && (ch == 1 || ch == 3)) || (depth == 16 && ch == 1));
+    if (!ok) fprintf(stderr, "PNG with %d channel(s) of %d bits: not a scalar image for the reference either\n", ch, depth);
+    if (ok) out = (double *) malloc((size_t) ww * hh * sizeof(double));
+    if (ok && out) {
+        for (uint32_t j = 0; j < hh; j++)
+            for (uint32_t i = 0; i < ww; i++) {
+                const unsigned char *b = rows[j] + (size_t) i * ch * (depth / 8);
+                double v;
+                if (depth == 16) v = (double) (uint16_t) ((b[0] << 8) | b[1]);                  /* :1425-1429 */
+                else if (ch == 1) v = (double) b[0];
+                else v = (double) (uint8_t) (.299 * b[0] + .587 * b[1] + .114 * b[2]);          /* :1104-1105 */
+                out[(size_t) j * ww + i] = v;
+            }
+        *w = (int) ww;
+        *h = (int) hh;
+    }
+    P->destroy_read_struct(&pp, &pi, NULL);
+    return out;
+}
+
 double *ofx_read_image_double(const char *fname, int *w, int *h)
 {
     FILE *f = fopen(fname, "rb");
     if (!f) return NULL;
     int c1 = fgetc(f), c2 = fgetc(f), pd = 1;
     float *data = NULL;
+    if (c1 == 0x89 && c2 == 'P') {                          /* PNG signature 89 50 4E 47 ... */
+        rewind(f);
+        double *png = read_png(f, w, h);
+        fclose(f);
+        return png;
+    }
     if (c1 == 'P' && c2 >= '2' && c2 <= '6' && c2 != '4') data = read_pnm(f, c2 - '0', w, h, &pd);
     else if (c1 == 'P' && (c2 == 'f' || c2 == 'F')) data = read_pfm(f, c2 == 'F', w, h, &pd);
     fclose(f);

@@ -153,3 +153,48 @@ def test_batch_front_end_writes_the_same_flo_as_tvl1flow(orc, synth, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     for k in range(3):
         assert np.array_equal(read_flo(tmp_path / "o2" / ("out%d.flo" % k)), want[k])
+
+
+def test_tvl1flow_cli_reads_png(synth, tmp_path):
+    """the same pair as 8-bit gray PNG: identical .flo to PGM input; as an RGB PNG with r = g = b: identical to PGM
+    input of the collapsed image (uint8)(.299x+.587x+.114x), which is x - 1 for 65 of the 256 gray levels because
+    the double sum lands just below x (iio.cpp:1104-1105)"""
+    import struct
+    import zlib
+
+    def png(path, img, rgb):
+        h, w = img.shape
+        rows = np.repeat(img[:, :, None], 3, axis=2).reshape(h, w * 3) if rgb else img
+
+        def chunk(tag, data):
+            return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+        raw = b"".join(b"\x00" + r.astype(np.uint8).tobytes() for r in rows)
+        open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if rgb else 0, 0, 0, 0))
+                               + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    nx, ny = 96, 64
+    I0, I1 = synth.pair("P1", nx, ny)
+    args = ["0", "0.25", "0.15", "0.3", "3", "0.5", "5", "0.01", "0"]
+    def collapse(img):          # iio.cpp:1104-1105 on r = g = b = img
+        x = img.astype(np.float64)
+        return (.299 * x + .587 * x + .114 * x).astype(np.uint8)
+    flows = {}
+    for kind in ("pgm", "gray", "rgb", "pgm_collapsed"):
+        ext = "pgm" if kind.startswith("pgm") else "png"
+        a, b = tmp_path / ("a_%s.%s" % (kind, ext)), tmp_path / ("b_%s.%s" % (kind, ext))
+        if kind == "pgm":
+            write_pgm(a, I0)
+            write_pgm(b, I1)
+        elif kind == "pgm_collapsed":
+            write_pgm(a, collapse(I0.astype(np.uint8)))
+            write_pgm(b, collapse(I1.astype(np.uint8)))
+        else:
+            png(a, I0.astype(np.uint8), kind == "rgb")
+            png(b, I1.astype(np.uint8), kind == "rgb")
+        out = tmp_path / ("o_%s.flo" % kind)
+        r = subprocess.run([os.path.join(BIN, "tvl1flow"), str(a), str(b), str(out)] + args, capture_output=True, text=True)
+        if ext == "png" and "libpng16" in r.stderr:
+            pytest.skip("libpng16 not present on this machine")
+        assert r.returncode == 0, r.stderr
+        flows[kind] = read_flo(out)
+    assert np.array_equal(flows["gray"], flows["pgm"])
+    assert np.array_equal(flows["rgb"], flows["pgm_collapsed"])

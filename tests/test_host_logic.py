@@ -171,3 +171,54 @@ def test_flo_reader_on_the_reference_own_flow_file(io):
     assert (w.value, h.value) == (256, 256)
     got = np.ctypeslib.as_array(p, shape=(256, 256, 2))
     assert np.array_equal(got, want) and np.isfinite(got).all()
+
+
+def _png(path, w, h, depth, color_type, rows, palette=None):
+    """minimal PNG writer (filter 0 rows): color_type 0 gray, 2 RGB, 3 palette, 4 gray+alpha, 6 RGBA"""
+    import zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    raw = b"".join(b"\x00" + bytes(r) for r in rows)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(palette))
+    out += chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    open(path, "wb").write(out)
+
+
+def test_png_input_follows_iio_semantics(io, tmp_path):
+    """PNG through the run-time-bound libpng: 8-bit gray as is; RGB -> (uint8)(.299R+.587G+.114B) in double arithmetic
+    (iio.cpp:1100-1108); palettes expanded to RGB first; 4-bit gray scaled to 8 bit (PNG_TRANSFORM_EXPAND); 16-bit gray
+    as host-order uint16; alpha / 16-bit colour are rejected like in the reference (iio.cpp:3595-3597,1119-1121).
+    Parity unpinned against iio itself (it cannot be built here: no libpng headers) -- restated from its source."""
+    import ctypes.util
+    if not (ctypes.util.find_library("png16") or os.path.exists("/lib/x86_64-linux-gnu/libpng16.so.16")):
+        pytest.skip("libpng16 not present on this machine")
+    rng = np.random.default_rng(5)
+    w, h = 7, 5
+    g8 = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    _png(tmp_path / "g8.png", w, h, 8, 0, g8)
+    assert np.array_equal(read_image(io, tmp_path / "g8.png"), g8.astype(np.float64))
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    _png(tmp_path / "rgb.png", w, h, 8, 2, rgb.reshape(h, w * 3))
+    want = (.299 * rgb[..., 0].astype(np.float64) + .587 * rgb[..., 1] + .114 * rgb[..., 2]).astype(np.uint8)
+    assert np.array_equal(read_image(io, tmp_path / "rgb.png"), want.astype(np.float64))
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, (h, w), dtype=np.uint8)
+    _png(tmp_path / "pal.png", w, h, 8, 3, idx, palette=pal.reshape(-1))
+    p = pal[idx]
+    want = (.299 * p[..., 0].astype(np.float64) + .587 * p[..., 1] + .114 * p[..., 2]).astype(np.uint8)
+    assert np.array_equal(read_image(io, tmp_path / "pal.png"), want.astype(np.float64))
+    g4 = rng.integers(0, 16, (h, 8), dtype=np.uint8)                       # 8 pixels per row, two per byte
+    _png(tmp_path / "g4.png", 8, h, 4, 0, (g4[:, 0::2] << 4) | g4[:, 1::2])
+    assert np.array_equal(read_image(io, tmp_path / "g4.png"), (g4 * 17).astype(np.float64))
+    g16 = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+    _png(tmp_path / "g16.png", w, h, 16, 0, g16.astype(">u2").view(np.uint8).reshape(h, w * 2))
+    assert np.array_equal(read_image(io, tmp_path / "g16.png"), g16.astype(np.float64))
+    rgba = rng.integers(0, 256, (h, w * 4), dtype=np.uint8)
+    _png(tmp_path / "rgba.png", w, h, 8, 6, rgba)
+    wv, hv = C.c_int(), C.c_int()
+    assert not io.ofx_read_image_double(str(tmp_path / "rgba.png").encode(), C.byref(wv), C.byref(hv))
+    (tmp_path / "broken.png").write_bytes(open(tmp_path / "g8.png", "rb").read()[:40])
+    assert not io.ofx_read_image_double(str(tmp_path / "broken.png").encode(), C.byref(wv), C.byref(hv))
