@@ -54,3 +54,27 @@ def pair(name, nx, ny, k=0):
     if name == "P1":
         return pair_p1(nx, ny, k)
     raise ValueError(name)
+
+
+def sequence(nx, ny, frames, k=0):
+    """`frames` images of the P1 scene in uniform motion (frame t = background moved by t * flow, foreground
+    rectangle moved by t * (mx, my)): input of the temporal Brox method.  Shape (frames, ny, nx)."""
+    i, j = _grid(nx, ny)
+    fx, fy = _flow(i, j)
+    phase = 0.3 + 0.1 * k
+    mx, my = 2 + (k % 3), -1.5
+
+    def tex_b(x, y):
+        return _tex(x, y, phase) + 15 * np.sin(1.3 * x) * np.cos(1.1 * y)
+
+    def tex_f(x, y):
+        return 127.5 + 60 * np.sin(0.9 * x + 0.4 * y) + 50 * np.cos(0.7 * y - 0.3 * x)
+
+    def fg(x, y):
+        return (x >= nx // 4) & (x < nx // 2) & (y >= ny // 4) & (y < ny // 2)
+
+    out = np.empty((frames, ny, nx))
+    for t in range(frames):
+        out[t] = np.floor(np.where(fg(j - t * mx, i - t * my), tex_f(j - t * mx, i - t * my),
+                                   tex_b(j - 0.6 * t * fx, i - 0.6 * t * fy)))
+    return out

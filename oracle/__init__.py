@@ -135,6 +135,17 @@ class _Lib:
         self._fn("zoom_in", None, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int)(_f64(I), out, nx, ny, nxx, nyy)
         return out
 
+    def centered_gradient3(self, f):
+        nz, ny, nx = f.shape
+        dx, dy, dz = np.empty_like(f, dtype=np.float64), np.empty_like(f, dtype=np.float64), np.empty_like(f, dtype=np.float64)
+        self._fn("centered_gradient3", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int)(_f64(f), dx, dy, dz, nx, ny, nz)
+        return dx, dy, dz
+
+    def image_normalization_1(self, I):
+        out = np.empty(I.shape)
+        self._fn("image_normalization_1", None, _dp, _dp, C.c_int)(_f64(I), out, I.size)
+        return out
+
     def image_normalization_2(self, I1, I2):
         a, b = np.empty(I1.shape), np.empty(I2.shape)
         self._fn("image_normalization_2", None, _dp, _dp, _dp, _dp, C.c_int)(_f64(I1), _f64(I2), a, b, I1.size)
@@ -228,6 +239,21 @@ class Oracle(_Lib):
             raise ValueError("GaussianSmooth: sigma too large")
         return u, v, np.array(list(iters)).reshape(nscales, inner * outer)
 
+    def brox_temporal(self, I, alpha=18.0, gamma=7.0, nscales=10, nu=0.75, TOL=1e-4, inner=1, outer=15, verbose=0):
+        """I: (frames, ny, nx).  Returns u, v of shape (frames - 1, ny, nx) and the sweep counts [scale][solve]."""
+        frames, ny, nx = I.shape
+        u, v = np.zeros((frames - 1, ny, nx)), np.zeros((frames - 1, ny, nx))
+        iters = (C.c_int * (inner * outer * nscales))()
+        rc = self._fn("brox_temporal", C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                      C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _ip)(
+            _f64(I), u, v, nx, ny, frames, alpha, gamma, nscales, nu, TOL, inner, outer, verbose, iters)
+        if rc == 1:
+            raise ValueError("GaussianSmooth: sigma too large")
+        if rc:
+            raise ValueError("The method needs more than two frames")
+        return u, v, np.array(list(iters)).reshape(nscales, inner * outer)
+
+
 
 class Ref(_Lib):
     """The compiled reference itself (oracle/_ref/libofref.so via oracle/ref_shim.cpp)."""
@@ -295,4 +321,16 @@ class Ref(_Lib):
             _f64(I1), _f64(I2), u, v, nx, ny, alpha, gamma, nscales, nu, TOL, inner, outer, verbose)
         if rc:
             raise ValueError("GaussianSmooth: sigma too large")
+        return u, v
+
+    def brox_temporal(self, I, alpha=18.0, gamma=7.0, nscales=10, nu=0.75, TOL=1e-4, inner=1, outer=15, verbose=0):
+        frames, ny, nx = I.shape
+        u, v = np.zeros((frames - 1, ny, nx)), np.zeros((frames - 1, ny, nx))
+        rc = self._fn("brox_temporal", C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                      C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int)(
+            _f64(I), u, v, nx, ny, frames, alpha, gamma, nscales, nu, TOL, inner, outer, verbose)
+        if rc == 1:
+            raise ValueError("GaussianSmooth: sigma too large")
+        if rc:
+            raise ValueError("The method needs more than two frames")
         return u, v

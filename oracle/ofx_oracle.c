@@ -1099,3 +1099,314 @@ int orc_brox_spatial(const double *I1, const double *I2, double *u, double *v, i
     pyramid_free(&P);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Brox temporal: src/brox_optic_flow_temporal.cpp + src/brox_temporal_mask.cpp.
+ * A sequence of `frames` images gives nz = frames - 1 flow fields coupled through a temporal smoothness term.
+ * Arrays are frame-major: element k = f * nx * ny + i * nx + j. */
+
+/* src/operators.cpp:413-499: per-frame centred gradient (same border rule as centered_gradient) + temporal
+ * centred difference, one-sided x 0.5 in the first / last frame */
+void orc_centered_gradient3(const double *in, double *dx, double *dy, double *dz, int nx, int ny, int nz)
+{
+    const int df = nx * ny;
+    for (int f = 0; f < nz; f++) orc_centered_gradient(in + (size_t) f * df, dx + (size_t) f * df, dy + (size_t) f * df, nx, ny);
+    if (nz > 1) {
+        for (int f = 1; f < nz - 1; f++)
+            for (int i = 0; i < df; i++) {
+                const int k = f * df + i;
+                dz[k] = 0.5 * (in[k + df] - in[k - df]);
+            }
+        for (int i = 0; i < df; i++) {
+            int k = i;
+            dz[k] = 0.5 * (in[k + df] - in[k]);
+            k = (nz - 1) * df + i;
+            dz[k] = 0.5 * (in[k] - in[k - df]);
+        }
+    } else {
+        for (int i = 0; i < df; i++) dz[i] = 0;
+    }
+}
+
+/* src/utils.cpp:251-276 + getminmax :509-525 */
+void orc_image_normalization_1(const double *I, double *In, int size)
+{
+    double lo = I[0], hi = I[0];
+    for (int i = 1; i < size; i++) { if (I[i] < lo) lo = I[i]; if (I[i] > hi) hi = I[i]; }
+    const double den = hi - lo;
+    if (den > 0) {
+        #pragma omp parallel for
+        for (int i = 0; i < size; i++) In[i] = 255.0 * (I[i] - lo) / den;
+    } else {
+        #pragma omp parallel for
+        for (int i = 0; i < size; i++) In[i] = I[i];
+    }
+}
+
+/* src/brox_temporal_mask.cpp:18-132: psi1..4 per frame as in the spatial method, psi5 / psi6 = half-sums with
+ * the previous / following frame, 0 outside the sequence */
+static void brox_t_psi_divergence(const double *psi, double *psi1, double *psi2, double *psi3, double *psi4,
+                                  double *psi5, double *psi6, int nx, int ny, int nz)
+{
+    const int df = nx * ny;
+    for (int f = 0; f < nz; f++)
+        brox_psi_divergence(psi + (size_t) f * df, psi1 + (size_t) f * df, psi2 + (size_t) f * df, psi3 + (size_t) f * df,
+                            psi4 + (size_t) f * df, nx, ny);
+    if (nz > 1) {
+        for (int f = 1; f < nz - 1; f++)
+            for (int i = 0; i < df; i++) {
+                const int k = f * df + i;
+                psi5[k] = 0.5 * (psi[k - df] + psi[k]);
+                psi6[k] = 0.5 * (psi[k + df] + psi[k]);
+            }
+        for (int i = 0; i < df; i++) {
+            int k = i;
+            psi5[k] = 0;
+            psi6[k] = 0.5 * (psi[k + df] + psi[k]);
+            k = (nz - 1) * df + i;
+            psi5[k] = 0.5 * (psi[k - df] + psi[k]);
+            psi6[k] = 0;
+        }
+    } else {
+        for (int i = 0; i < df; i++) psi5[i] = psi6[i] = 0;
+    }
+}
+
+/* src/brox_temporal_mask.cpp:140-239: the spatial divergence per frame, then `+=` the temporal terms (both as
+ * ONE added expression in the interior frames) */
+static void brox_t_divergence_u(const double *u, const double *v, const double *psi1, const double *psi2,
+                                const double *psi3, const double *psi4, const double *psi5, const double *psi6,
+                                double *div_u, double *div_v, int nx, int ny, int nz)
+{
+    const int df = nx * ny;
+    for (int f = 0; f < nz; f++) {
+        const size_t o = (size_t) f * df;
+        brox_divergence_u(u + o, v + o, psi1 + o, psi2 + o, psi3 + o, psi4 + o, div_u + o, div_v + o, nx, ny);
+    }
+    if (nz > 1) {
+        for (int f = 1; f < nz - 1; f++)
+            for (int i = 0; i < df; i++) {
+                const int k = f * df + i;
+                div_u[k] += psi5[k] * (u[k - df] - u[k]) + psi6[k] * (u[k + df] - u[k]);
+                div_v[k] += psi5[k] * (v[k - df] - v[k]) + psi6[k] * (v[k + df] - v[k]);
+            }
+        for (int i = 0; i < df; i++) {
+            int k = i;
+            div_u[k] += psi6[k] * (u[k + df] - u[k]);
+            div_v[k] += psi6[k] * (v[k + df] - v[k]);
+            k = (nz - 1) * df + i;
+            div_u[k] += psi5[k] * (u[k - df] - u[k]);
+            div_v[k] += psi5[k] * (v[k - df] - v[k]);
+        }
+    }
+}
+
+/* src/brox_optic_flow_temporal.cpp:120-170.  Offsets to the previous / following frame, row and column; 0 for a
+ * missing neighbour (the tap lands on the pixel itself, with psi = 0 there). */
+static inline double brox_t_sor_point(const double *Au, const double *Av, const double *Du, const double *Dv,
+                                      const double *D, double *du, double *dv, double alpha, const double *psi1,
+                                      const double *psi2, const double *psi3, const double *psi4, const double *psi5,
+                                      const double *psi6, int f, int df0, int df1, int i, int ny, int dy0, int dy1,
+                                      int j, int nx, int dx0, int dx1)
+{
+    const double w = BROX_SOR_W;
+    const int k = f * ny * nx + i * nx + j;
+    const double div_du = psi1[k] * du[k + dy1] + psi2[k] * du[k - dy0] + psi3[k] * du[k + dx1] + psi4[k] * du[k - dx0] +
+                          psi5[k] * du[k - df0] + psi6[k] * du[k + df1];
+    const double div_dv = psi1[k] * dv[k + dy1] + psi2[k] * dv[k - dy0] + psi3[k] * dv[k + dx1] + psi4[k] * dv[k - dx0] +
+                          psi5[k] * dv[k - df0] + psi6[k] * dv[k + df1];
+    const double duk = du[k], dvk = dv[k];
+    du[k] = (1. - w) * du[k] + w * (Au[k] - D[k] * dv[k] + alpha * div_du) / Du[k];
+    dv[k] = (1. - w) * dv[k] + w * (Av[k] - D[k] * du[k] + alpha * div_dv) / Dv[k];
+    return (du[k] - duk) * (du[k] - duk) + (dv[k] - dvk) * (dv[k] - dvk);
+}
+
+/* src/brox_optic_flow_temporal.cpp:178-275: one frame of one sweep, the spatial method's visiting order */
+static double brox_t_process_frame(const double *Au, const double *Av, const double *Du, const double *Dv,
+                                   const double *D, double *du, double *dv, double alpha, const double *psi1,
+                                   const double *psi2, const double *psi3, const double *psi4, const double *psi5,
+                                   const double *psi6, int f, int nx, int ny, int df0, int df1)
+{
+#define BT(i, dy0, dy1, j, dx0, dx1) \
+    brox_t_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, psi5, psi6, f, df0, df1, i, ny, dy0, dy1, j, nx, dx0, dx1)
+    double error = 0;
+    #pragma omp parallel for reduction(+:error)
+    for (int i = 1; i < ny - 1; i++)
+        for (int j = 1; j < nx - 1; j++) error += BT(i, nx, nx, j, 1, 1);
+    for (int j = 1; j < nx - 1; j++) {
+        error += BT(0, 0, nx, j, 1, 1);
+        error += BT(ny - 1, nx, 0, j, 1, 1);
+    }
+    for (int i = 1; i < ny - 1; i++) {
+        error += BT(i, nx, nx, 0, 0, 1);
+        error += BT(i, nx, nx, nx - 1, 1, 0);
+    }
+    error += BT(0, 0, nx, 0, 0, 1);
+    error += BT(0, 0, nx, nx - 1, 1, 0);
+    error += BT(ny - 1, nx, 0, 0, 0, 1);
+    error += BT(ny - 1, nx, 0, nx - 1, 1, 0);
+#undef BT
+    return error;
+}
+
+/* src/brox_optic_flow_temporal.cpp:282-512 */
+static void brox_t_single_scale(const double *I, double *u, double *v, int nx, int ny, int frames, double alpha,
+                                double gamma, double TOL, int inner_iter, int outer_iter, int verbose, int *iters)
+{
+    const int nz = frames - 1, df = nx * ny;
+    const int size = df * frames, size1 = df * nz;
+    enum { NARR1 = 33 };
+    double *a[NARR1];
+    for (int q = 0; q < NARR1; q++) a[q] = dalloc((size_t) size1);
+    double *du = a[0], *dv = a[1], *ux = a[2], *uy = a[3], *ut = a[4], *vx = a[5], *vy = a[6], *vt = a[7];
+    double *Iw = a[8], *Iwx = a[9], *Iwy = a[10], *Ixx = a[11], *Iyy = a[12], *Ixy = a[13];
+    double *Iwxx = a[14], *Iwyy = a[15], *Iwxy = a[16], *div_u = a[17], *div_v = a[18], *div_d = a[19];
+    double *Au = a[20], *Av = a[21], *Du = a[22], *Dv = a[23], *D = a[24], *psid = a[25], *psig = a[26], *psis = a[27];
+    double *psi1 = a[28], *psi2 = a[29], *psi3 = a[30], *psi4 = a[31], *psi5 = a[32];
+    double *psi6 = dalloc((size_t) size1), *Ix = dalloc((size_t) size), *Iy = dalloc((size_t) size);
+    int solve = 0;
+
+    for (int f = 0; f < frames; f++) orc_centered_gradient(I + (size_t) f * df, Ix + (size_t) f * df, Iy + (size_t) f * df, nx, ny);   /* :346-348 */
+    for (int f = 0; f < nz; f++) {                                                    /* :351-355 */
+        orc_dxx(I + (size_t) df * (f + 1), Ixx + (size_t) f * df, nx, ny);
+        orc_dyy(I + (size_t) df * (f + 1), Iyy + (size_t) f * df, nx, ny);
+        orc_dxy(I + (size_t) df * (f + 1), Ixy + (size_t) f * df, nx, ny);
+    }
+    for (int no = 0; no < outer_iter; no++) {                                         /* :358 */
+        for (int f = 0; f < nz; f++) {                                                /* :360-367 */
+            const size_t o = (size_t) f * df, o1 = (size_t) df * (f + 1);
+            orc_bicubic_warp(I + o1,  u + o, v + o, Iw + o,   nx, ny, 1);
+            orc_bicubic_warp(Ix + o1, u + o, v + o, Iwx + o,  nx, ny, 1);
+            orc_bicubic_warp(Iy + o1, u + o, v + o, Iwy + o,  nx, ny, 1);
+            orc_bicubic_warp(Ixx + o, u + o, v + o, Iwxx + o, nx, ny, 1);
+            orc_bicubic_warp(Ixy + o, u + o, v + o, Iwxy + o, nx, ny, 1);
+            orc_bicubic_warp(Iyy + o, u + o, v + o, Iwyy + o, nx, ny, 1);
+        }
+        orc_centered_gradient3(u, ux, uy, ut, nx, ny, nz);                           /* :370-371 */
+        orc_centered_gradient3(v, vx, vy, vt, nx, ny, nz);
+        #pragma omp parallel for
+        for (int i = 0; i < size1; i++) {                                             /* psi_smooth :94-118 */
+            const double gu = ux[i] * ux[i] + uy[i] * uy[i] + ut[i] * ut[i];
+            const double gv = vx[i] * vx[i] + vy[i] * vy[i] + vt[i] * vt[i];
+            const double d2 = gu + gv;
+            psis[i] = 1. / sqrt(d2 + BROX_EPSILON * BROX_EPSILON);
+        }
+        brox_t_psi_divergence(psis, psi1, psi2, psi3, psi4, psi5, psi6, nx, ny, nz);                 /* :377 */
+        brox_t_divergence_u(u, v, psi1, psi2, psi3, psi4, psi5, psi6, div_u, div_v, nx, ny, nz);     /* :380 */
+        #pragma omp parallel for
+        for (int i = 0; i < size1; i++) {                                             /* :383-390 */
+            div_d[i] = alpha * (psi1[i] + psi2[i] + psi3[i] + psi4[i] + psi5[i] + psi6[i]);
+            du[i] = dv[i] = 0;
+        }
+        for (int ni = 0; ni < inner_iter; ni++) {                                     /* :394 */
+            #pragma omp parallel for
+            for (int i = 0; i < size1; i++) {                                         /* psi_data :36-55 */
+                const double dI = Iw[i] - I[i] + Iwx[i] * du[i] + Iwy[i] * dv[i];
+                const double dI2 = dI * dI;
+                psid[i] = 1. / sqrt(dI2 + BROX_EPSILON * BROX_EPSILON);
+            }
+            #pragma omp parallel for
+            for (int i = 0; i < size1; i++) {                                         /* psi_gradient :63-86 */
+                const double dIx = Iwx[i] - Ix[i] + Iwxx[i] * du[i] + Iwxy[i] * dv[i];
+                const double dIy = Iwy[i] - Iy[i] + Iwxy[i] * du[i] + Iwyy[i] * dv[i];
+                const double dI2 = dIx * dIx + dIy * dIy;
+                psig[i] = 1. / sqrt(dI2 + BROX_EPSILON * BROX_EPSILON);
+            }
+            for (int i = 0; i < size1; i++) {                                         /* :400-427 */
+                const double p = psid[i];
+                const double g = gamma * psig[i];
+                const double dif = Iw[i] - I[i];
+                const double BNu = -p * dif * Iwx[i];
+                const double BNv = -p * dif * Iwy[i];
+                const double BDu = p * Iwx[i] * Iwx[i];
+                const double BDv = p * Iwy[i] * Iwy[i];
+                const double dx = (Iwx[i] - Ix[i]);
+                const double dy = (Iwy[i] - Iy[i]);
+                const double GNu = -g * (dx * Iwxx[i] + dy * Iwxy[i]);
+                const double GNv = -g * (dx * Iwxy[i] + dy * Iwyy[i]);
+                const double GDu = g * (Iwxx[i] * Iwxx[i] + Iwxy[i] * Iwxy[i]);
+                const double GDv = g * (Iwyy[i] * Iwyy[i] + Iwxy[i] * Iwxy[i]);
+                const double DI = (Iwxx[i] + Iwyy[i]) * Iwxy[i];
+                const double Duv = p * Iwy[i] * Iwx[i] + g * DI;
+                Au[i] = BNu + GNu + alpha * div_u[i];
+                Av[i] = BNv + GNv + alpha * div_v[i];
+                Du[i] = BDu + GDu + div_d[i];
+                Dv[i] = BDv + GDv + div_d[i];
+                D[i] = Duv;
+            }
+            double error = 1000;
+            int nsor = 0;
+            while (error > TOL && nsor < BROX_MAXITER) {                              /* :433-461 */
+                error = 0;
+                nsor++;
+                for (int f = 1; f < nz - 1; f++)                                      /* interior frames first */
+                    error += brox_t_process_frame(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, psi5, psi6, f,
+                                                  nx, ny, df, df);
+                error += brox_t_process_frame(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, psi5, psi6, 0, nx,
+                                              ny, 0, df);
+                error += brox_t_process_frame(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, psi5, psi6,
+                                              nz - 1, nx, ny, df, 0);
+                error = sqrt(error / size1);
+            }
+            if (verbose) printf("Iterations: %d\n", nsor);
+            if (iters) iters[solve] = nsor;
+            solve++;
+        }
+        for (int i = 0; i < size1; i++) { u[i] += du[i]; v[i] += dv[i]; }            /* :469-472 */
+    }
+    for (int q = 0; q < NARR1; q++) free(a[q]);
+    free(psi6); free(Ix); free(Iy);
+}
+
+/* src/brox_optic_flow_temporal.cpp:520-627.  u, v: (frames - 1) * nx * ny; `iters` is laid out
+ * [scale][outer*inner].  Returns 1 where the reference throws ("sigma too large"), 2 for frames <= 2 (the
+ * reference prints a message and returns without touching u, v). */
+int orc_brox_temporal(const double *I, double *u, double *v, int nxx, int nyy, int frames, double alpha, double gamma,
+                      int nscales, double nu, double TOL, int inner_iter, int outer_iter, int verbose, int *iters)
+{
+    if (frames <= 2) return 2;
+    int *nx = (int *) malloc(sizeof(int) * nscales), *ny = (int *) malloc(sizeof(int) * nscales);
+    double **Is = (double **) calloc(nscales, sizeof(double *));
+    double **us = (double **) calloc(nscales, sizeof(double *)), **vs = (double **) calloc(nscales, sizeof(double *));
+    int rc = 0;
+    nx[0] = nxx; ny[0] = nyy;
+    Is[0] = dalloc((size_t) nxx * nyy * frames);
+    orc_image_normalization_1(I, Is[0], nxx * nyy * frames);                          /* :548 */
+    for (int f = 0; f < frames; f++) rc |= orc_gaussian(Is[0] + (size_t) f * nxx * nyy, nxx, nyy, BROX_SIGMA);   /* :551-553 */
+    us[0] = u; vs[0] = v;
+    for (int s = 1; s < nscales && !rc; s++) {                                        /* :561-575 */
+        orc_zoom_size(nx[s - 1], ny[s - 1], &nx[s], &ny[s], nu);
+        const size_t n = (size_t) nx[s] * ny[s];
+        Is[s] = dalloc(n * frames);
+        us[s] = dalloc(n * (frames - 1));
+        vs[s] = dalloc(n * (frames - 1));
+        for (int f = 0; f < frames; f++)
+            rc |= orc_zoom_out(Is[s - 1] + (size_t) f * nx[s - 1] * ny[s - 1], Is[s] + f * n, nx[s - 1], ny[s - 1], nu);
+    }
+    if (!rc) {
+        const int c = nscales - 1;
+        for (int i = 0; i < nx[c] * ny[c] * (frames - 1); i++) us[c][i] = vs[c][i] = 0.0;           /* :578-580 */
+        for (int s = nscales - 1; s >= 0; s--) {                                      /* :587-614 */
+            if (verbose) printf("Scale: %d\n", s);
+            brox_t_single_scale(Is[s], us[s], vs[s], nx[s], ny[s], frames, alpha, gamma, TOL, inner_iter, outer_iter,
+                                verbose, iters ? iters + s * inner_iter * outer_iter : NULL);
+            if (s) {
+                const size_t n = (size_t) nx[s] * ny[s], n1 = (size_t) nx[s - 1] * ny[s - 1];
+                for (int f = 0; f < frames - 1; f++) {
+                    orc_zoom_in(us[s] + f * n, us[s - 1] + f * n1, nx[s], ny[s], nx[s - 1], ny[s - 1]);
+                    orc_zoom_in(vs[s] + f * n, vs[s - 1] + f * n1, nx[s], ny[s], nx[s - 1], ny[s - 1]);
+                }
+                for (size_t i = 0; i < n1 * (frames - 1); i++) {
+                    us[s - 1][i] *= 1.0 / nu;
+                    vs[s - 1][i] *= 1.0 / nu;
+                }
+            }
+        }
+    }
+    for (int s = 0; s < nscales; s++) {
+        free(Is[s]);
+        if (s) { free(us[s]); free(vs[s]); }
+    }
+    free(Is); free(us); free(vs); free(nx); free(ny);
+    return rc;
+}

@@ -80,6 +80,13 @@ int  orc_brox_spatial(const double *I1, const double *I2, double *u, double *v, 
                       double alpha, double gamma, int nscales, double nu, double TOL,
                       int inner_iter, int outer_iter, int verbose, int *iters);
 
+/* brox_optic_flow_temporal.cpp + brox_temporal_mask.cpp (+ operators.cpp centered_gradient3, utils.cpp
+ * image_normalization_1) */
+void orc_centered_gradient3(const double *in, double *dx, double *dy, double *dz, int nx, int ny, int nz);
+void orc_image_normalization_1(const double *I, double *In, int size);
+int  orc_brox_temporal(const double *I, double *u, double *v, int nx, int ny, int frames, double alpha, double gamma,
+                       int nscales, double nu, double TOL, int inner_iter, int outer_iter, int verbose, int *iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,4 +134,20 @@ int ref_brox_spatial(const double *I1, const double *I2, double *u, double *v, i
     return 0;
 }
 
+int ref_brox_temporal(const double *I, double *u, double *v, int nx, int ny, int frames, double alpha,
+                      double gamma, int nscales, double nu, double TOL, int inner_iter, int outer_iter, int verbose)
+{
+    if (frames <= 2) return 2;
+    try {
+        brox_optic_flow_temporal(I, u, v, nx, ny, frames, alpha, gamma, nscales, nu, TOL, inner_iter, outer_iter,
+                                 verbose != 0);
+    } catch (const std::runtime_error &) { return 1; }
+    return 0;
+}
+
+void ref_centered_gradient3(const double *in, double *dx, double *dy, double *dz, int nx, int ny, int nz)
+{ centered_gradient3(in, dx, dy, dz, nx, ny, nz); }
+
+void ref_image_normalization_1(const double *I, double *In, int size) { image_normalization_1(I, In, size); }
+
 } // extern "C"

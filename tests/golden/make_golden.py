@@ -33,6 +33,9 @@ SOLVER_CASES = {
     "tvl1_p1_96x64_z07": ("tvl1", "P1", 96, 64, dict(nscales=3, zfactor=0.7, **TVL1)),
     "hs_p1_96x64": ("hs", "P1", 96, 64, dict(alpha=20.0, nscales=3, zfactor=0.5, warps=4, TOL=1e-4, maxiter=150)),
     "brox_p1_96x64": ("brox", "P1", 96, 64, dict(alpha=50.0, gamma=10.0, nscales=3, nu=0.5, TOL=1e-4, inner=1, outer=4)),
+    # temporal Brox: "pair" is the number of frames of synth.sequence
+    "broxt_seq4_64x48": ("broxt", 4, 64, 48, dict(alpha=18.0, gamma=7.0, nscales=2, nu=0.75, TOL=1e-4, inner=1, outer=3)),
+    "broxt_seq3_48x40": ("broxt", 3, 48, 40, dict(alpha=30.0, gamma=0.0, nscales=2, nu=0.5, TOL=1e-4, inner=2, outer=2)),
 }
 
 
@@ -41,8 +44,9 @@ def run_verbose(case):
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", case], capture_output=True, text=True,
                          check=True)
     kind = SOLVER_CASES[case][0]
-    text = out.stderr if kind != "brox" else out.stdout
-    pat = {"tvl1": r"Iterations: (\d+),", "hs": r"Iterations (\d+) \(", "brox": r"Iterations: (\d+)"}[kind]
+    text = out.stderr if kind not in ("brox", "broxt") else out.stdout
+    pat = {"tvl1": r"Iterations: (\d+),", "hs": r"Iterations (\d+) \(", "brox": r"Iterations: (\d+)",
+           "broxt": r"Iterations: (\d+)"}[kind]
     iters = [int(x) for x in re.findall(pat, text)]
     data = np.load(os.path.join(HERE, "_child.npz"))
     u, v = data["u"], data["v"]
@@ -54,9 +58,12 @@ def child(case):
     kind, pair, nx, ny, kw = SOLVER_CASES[case]
     ref = oracle.Ref()
     ref.set_num_threads(1)
-    I0, I1 = synth.pair(pair, nx, ny)
-    fn = {"tvl1": ref.tvl1_multiscale, "hs": ref.hs_pyramidal, "brox": ref.brox_spatial}[kind]
-    u, v = fn(I0, I1, verbose=1, **kw)
+    if kind == "broxt":
+        u, v = ref.brox_temporal(synth.sequence(nx, ny, pair), verbose=1, **kw)
+    else:
+        I0, I1 = synth.pair(pair, nx, ny)
+        fn = {"tvl1": ref.tvl1_multiscale, "hs": ref.hs_pyramidal, "brox": ref.brox_spatial}[kind]
+        u, v = fn(I0, I1, verbose=1, **kw)
     sys.stdout.flush()
     np.savez(os.path.join(HERE, "_child.npz"), u=u, v=v)
 
@@ -68,6 +75,10 @@ def main():
         oracle.build()
     ref = oracle.Ref()
     ref.set_num_threads(1)
+    only = None                     # `--only case1,case2`: (re)generate just these solver cases, keep the rest
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":
+        only = sys.argv[2].split(",")
+        return solvers(only)
     rng = np.random.default_rng(20261004)
 
     # ---- operators on tiny arrays (borders, odd sizes, negative / far-out warp coordinates) ----
@@ -102,9 +113,17 @@ def main():
                                   for f in (0.5, 0.75)], dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, "operators.npz"), **ops)
 
+    solvers(None)
+
+
+def solvers(only):
     # ---- solvers: flow + iteration counts of the reference itself ----
     meta = {}
+    if only is not None and os.path.exists(os.path.join(HERE, "cases.json")):
+        meta = json.load(open(os.path.join(HERE, "cases.json")))
     for case, (kind, pair, nx, ny, kw) in SOLVER_CASES.items():
+        if only is not None and case not in only:
+            continue
         u, v, iters = run_verbose(case)
         np.savez_compressed(os.path.join(HERE, case + ".npz"), u=u, v=v, iters=iters)
         meta[case] = dict(kind=kind, pair=pair, nx=nx, ny=ny, params=kw, mean_u=float(u.mean()), mean_v=float(v.mean()),

@@ -55,9 +55,12 @@ def test_bicubic_at_and_zoom_size(orc):
 def test_solvers(orc, synth, case):
     c = CASES[case]
     g = load(case)
-    I0, I1 = synth.pair(c["pair"], c["nx"], c["ny"])
-    fn = {"tvl1": orc.tvl1_multiscale, "hs": orc.hs_pyramidal, "brox": orc.brox_spatial}[c["kind"]]
-    out = fn(I0, I1, **c["params"])
+    if c["kind"] == "broxt":        # temporal Brox: "pair" holds the number of frames of synth.sequence
+        out = orc.brox_temporal(synth.sequence(c["nx"], c["ny"], c["pair"]), **c["params"])
+    else:
+        I0, I1 = synth.pair(c["pair"], c["nx"], c["ny"])
+        fn = {"tvl1": orc.tvl1_multiscale, "hs": orc.hs_pyramidal, "brox": orc.brox_spatial}[c["kind"]]
+        out = fn(I0, I1, **c["params"])
     u, v, iters = out[0], out[1], out[2]
     assert np.array_equal(u, g["u"]) and np.array_equal(v, g["v"])
     # the reference prints coarse-to-fine; the oracle stores [scale][solve] with scale 0 = finest

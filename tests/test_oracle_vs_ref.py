@@ -74,6 +74,22 @@ def test_hs_and_brox(orc, ref, synth):
     assert np.array_equal(uo, ur) and np.array_equal(vo, vr)
 
 
+def test_brox_temporal(orc, ref, synth):
+    """3 frames (no interior frame), 5 frames, and a case that runs into the 300-sweep limit"""
+    for nx, ny, frames, kw in [(48, 40, 3, dict(nscales=2, outer=3)), (64, 48, 5, dict(nscales=2, outer=3, inner=2)),
+                               (33, 47, 4, dict(nscales=1, outer=2, alpha=30.0, gamma=0.0))]:
+        I = synth.sequence(nx, ny, frames)
+        uo, vo, _ = orc.brox_temporal(I, **kw)
+        ur, vr = ref.brox_temporal(I, **kw)
+        assert np.array_equal(uo, ur) and np.array_equal(vo, vr)
+    g = np.random.default_rng(0).standard_normal((4, 9, 7))
+    for a, b in zip(orc.centered_gradient3(g), ref.centered_gradient3(g)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(orc.image_normalization_1(g), ref.image_normalization_1(g))
+    with pytest.raises(ValueError):
+        orc.brox_temporal(g[:2])
+
+
 def test_known_answer_anchor_p0_640x480(ref, synth):
     """mean(u, v) of the reference's flow on P0 640x480, 5 scales."""
     I0, I1 = synth.pair("P0", 640, 480)
