@@ -188,6 +188,14 @@ int ofx_brox_spatial(ofx_ctx *ctx, const double *I1, const double *I2, double *u
                      int nxx, int nyy, double alpha, double gamma, int nscales, double nu,
                      double TOL, int inner_iter, int outer_iter, int verbose);
 
+/* ---- Brox temporal (replace src/brox_optic_flow.h:41-55) ---------------------------*/
+/* I: `frames` images of nx*ny, frame-major; u, v: frames - 1 flow fields (u[f] takes frame f to frame f + 1).
+ * frames <= 2 is an error ("The method needs more than two frames", brox_optic_flow_temporal.cpp:537-541: the
+ * reference prints that and returns).  SOR sweeps run in the reference's order (windowed exact schedule). */
+int ofx_brox_temporal(ofx_ctx *ctx, const double *I, double *u, double *v, int nxx, int nyy, int frames,
+                      double alpha, double gamma, int nscales, double nu, double TOL, int inner_iter,
+                      int outer_iter, int verbose);
+
 #ifdef __cplusplus
 }
 #endif

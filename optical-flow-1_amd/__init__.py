@@ -107,6 +107,7 @@ def lib():
         "ofx_hs_single_scale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _i]),
         "ofx_hs_pyramidal": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _d, _i, _i]),
         "ofx_brox_spatial": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
+        "ofx_brox_temporal": (_i, [_vp, _dp, _dp, _dp, _i, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
     }
     L.ofx_missing = []
     for name, (res, args) in sig.items():
@@ -312,4 +313,12 @@ class Ofx:
         u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
         self._ck(self.L.ofx_brox_spatial(self.h, _f64(I1), _f64(I2), u, v, nx, ny, alpha, gamma, nscales, nu, TOL,
                                          inner, outer, verbose))
+        return u, v
+
+    def brox_temporal(self, I, alpha=18.0, gamma=7.0, nscales=10, nu=0.75, TOL=1e-4, inner=1, outer=15, verbose=0):
+        """I: (frames, ny, nx) -> u, v of shape (frames - 1, ny, nx)"""
+        frames, ny, nx = I.shape
+        u, v = np.zeros((max(frames - 1, 0), ny, nx)), np.zeros((max(frames - 1, 0), ny, nx))
+        self._ck(self.L.ofx_brox_temporal(self.h, _f64(I), u, v, nx, ny, frames, alpha, gamma, nscales, nu, TOL, inner,
+                                          outer, verbose))
         return u, v

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64) void k_hs_plane(typename Pix<T>::v2 *__restrict
 // one workgroup per (sweep, block): block b runs lag_b steps behind block b - 1 of its sweep, sweeps are
 // lag_s apart, and a border pixel is executed by the block of the interior row it depends on last.
 struct SorWin {
-    int tau0, K, lag_s, lag_b, s_first, R;
+    int tau0, K, lag_s, lag_b, lag_f, s_first, R;      // lag_f: spacing of the frames of a sequence (temporal Brox)
 };
 // which plane item thread t of block b plays: its R rows, then the three shared items (first column, last
 // column, corners) of which a block accepts only the pixels assigned to it (sor_border_block)
@@ -274,9 +274,11 @@ __global__ __launch_bounds__(1024) void k_hs_window(typename Pix<T>::v2 *U, type
 // when a sweep is one block): with these every value a workgroup reads from ANOTHER (sweep, block) was written
 // at least one launch earlier and is overwritten at least one launch later (checked exhaustively on small
 // images for both stencils, tools/check_sor_schedule.py).
+// nz > 1 (temporal Brox): a sweep visits nz frames one after the other; frame number o (in visiting order) runs
+// lag_f = K steps behind frame o - 1 and the sweeps move lag_f (nz - 1) further apart.
 template <class WindowFn, class TakeFn>
 static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxiter, int qmax, int C, int batch,
-                           WindowFn launch, TakeFn take, int *n_out, double *err_out)
+                           WindowFn launch, TakeFn take, int *n_out, double *err_out, int nz = 1)
 {
     int niter = 0;
     double error = 1000;
@@ -287,7 +289,8 @@ static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxit
     if (w.R > 1021) w.R = 1021;                                  // R + 3 threads per workgroup
     const int B = ofx_cdiv(ny, w.R);
     w.lag_b = w.K;
-    w.lag_s = (B > 1 ? 2 * w.K : w.K) + C;
+    w.lag_f = nz > 1 ? w.K : 0;
+    w.lag_s = (B > 1 ? 2 * w.K : w.K) + C + w.lag_f * (nz - 1);
     OFX_TRY(ofx_loop_reserve(ctx, batch + 1));
     LoopSpec LS;
     LS.size = size;
@@ -300,7 +303,7 @@ static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxit
         const int ns = (maxiter - niter < batch) ? maxiter - niter : batch;
         OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) ns * OFX_NSHARD, ctx->stream));
         OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
-        const long tail = (long) w.lag_b * (B - 1);              // the last block of a sweep ends this much later
+        const long tail = (long) w.lag_b * (B - 1) + (long) w.lag_f * (nz - 1);   // the last unit of a sweep ends this much later
         const long total = (long) qmax + 1 + tail + (long) w.lag_s * (ns - 1);
         for (long tau0 = 0; tau0 < total; tau0 += w.K) {
             long s_lo = (tau0 - qmax - tail + w.lag_s - 1) / w.lag_s;   // smallest s still inside the image
@@ -1153,6 +1156,333 @@ extern "C" int ofx_brox_spatial(ofx_ctx *ctx, const double *I1, const double *I2
     const BroxParams P = {alpha, gamma, TOL, inner_iter, outer_iter, verbose};
     int s = ctx->precision == OFX_F64 ? brox_spatial_host<double>(ctx, I1, I2, u, v, nxx, nyy, P, nscales, nu)
                                       : brox_spatial_host<float>(ctx, I1, I2, u, v, nxx, nyy, P, nscales, nu);
+    ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}
+
+
+// ============================================================================================
+// Brox temporal: src/brox_optic_flow_temporal.cpp, src/brox_temporal_mask.cpp
+// ============================================================================================
+// A sequence of `frames` images gives nz = frames - 1 flow fields, coupled by a temporal smoothness term.  All
+// arrays are frame-major (frame f at element f * nx * ny); flow field f uses I1 = frame f, I2 = frame f + 1, so the
+// per-frame kernels of the spatial method (prepare, warp, coefficient assembly) are reused unchanged.  New: the
+// smoothness weight with the temporal flow derivative, psi5 / psi6 and their divergence terms, the 7-point SOR
+// update, and the frame dimension in the exact schedule (a sweep visits frames 1 .. nz-2, then 0, then nz-1,
+// :439-459; every frame in the spatial method's pixel order).
+
+struct Psi6 { double p1, p2, p3, p4, p5, p6; };
+// src/brox_temporal_mask.cpp:18-132 at one pixel: psi1..4 within the frame, psi5 / psi6 = half-sums with the previous /
+// following frame (0 outside the sequence)
+template <typename T> OFX_DEV Psi6 broxt_psi6(const T *Psis, int f, int i, int j, int nx, int ny, int nz)
+{
+    const size_t df = (size_t) nx * ny;
+    const Psi4 a = brox_psi4(Psis + f * df, i, j, nx, ny);
+    const size_t k = f * df + (size_t) i * nx + j;
+    const double c = ldw(Psis + k);
+    Psi6 r;
+    r.p1 = a.p1; r.p2 = a.p2; r.p3 = a.p3; r.p4 = a.p4;
+    r.p5 = (f > 0) ? 0.5 * (ldw(Psis + k - df) + c) : 0.0;
+    r.p6 = (f < nz - 1) ? 0.5 * (ldw(Psis + k + df) + c) : 0.0;
+    return r;
+}
+
+// psi_smooth (:94-118) of centered_gradient3 (src/operators.cpp:413-499): the in-frame centred gradient plus the
+// temporal centred difference (one-sided, still x 0.5, in the first / last frame)
+template <typename T>
+__global__ void k_broxt_psis(const typename Pix<T>::v2 *__restrict__ U, T *__restrict__ Psis, int nx, int ny, int nz)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (j >= nx || i >= ny) return;
+    const size_t df = (size_t) nx * ny;
+    const typename Pix<T>::v2 *Uf = U + f * df;
+    const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+    const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+    const size_t p = (size_t) i * nx + j;
+    const double2 r = ldw2(Uf + (size_t) i * nx + jr), l = ldw2(Uf + (size_t) i * nx + jl);
+    const double2 d = ldw2(Uf + (size_t) id * nx + j), t = ldw2(Uf + (size_t) iu * nx + j);
+    const double2 hi = ldw2(U + (f < nz - 1 ? f + 1 : f) * df + p), lo = ldw2(U + (f > 0 ? f - 1 : f) * df + p);
+    const double ux = 0.5 * (r.x - l.x), uy = 0.5 * (d.x - t.x), ut = 0.5 * (hi.x - lo.x);
+    const double vx = 0.5 * (r.y - l.y), vy = 0.5 * (d.y - t.y), vt = 0.5 * (hi.y - lo.y);
+    const double du = ux * ux + uy * uy + ut * ut;
+    const double dv = vx * vx + vy * vy + vt * vt;
+    const double d2 = du + dv;
+    stn(Psis + f * df + p, 1. / sqrt(d2 + BROX_EPSILON * BROX_EPSILON));
+}
+
+// div_u, div_v (src/brox_temporal_mask.cpp:140-239: the in-frame sum, then `+=` the temporal terms as ONE added
+// expression), div_d = alpha (psi1 + ... + psi6) and du = dv = 0 (:383-390)
+template <typename T>
+__global__ void k_broxt_div(const typename Pix<T>::v2 *__restrict__ U, const T *__restrict__ Psis,
+                            typename Pix<T>::v2 *__restrict__ DV, T *__restrict__ Dd, typename Pix<T>::v2 *__restrict__ DU,
+                            int nx, int ny, int nz, double alpha)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (j >= nx || i >= ny) return;
+    const size_t df = (size_t) nx * ny;
+    const size_t k = f * df + (size_t) i * nx + j;
+    const Psi6 s = broxt_psi6(Psis, f, i, j, nx, ny, nz);
+    const double2 c = ldw2(U + k);
+    double du = 0.0, dv = 0.0;
+    bool have = false;
+    if (i < ny - 1) { const double2 q = ldw2(U + k + nx); du = s.p1 * (q.x - c.x); dv = s.p1 * (q.y - c.y); have = true; }
+    if (i > 0) {
+        const double2 q = ldw2(U + k - nx);
+        const double a = s.p2 * (q.x - c.x), b = s.p2 * (q.y - c.y);
+        du = have ? du + a : a; dv = have ? dv + b : b; have = true;
+    }
+    if (j < nx - 1) {
+        const double2 q = ldw2(U + k + 1);
+        const double a = s.p3 * (q.x - c.x), b = s.p3 * (q.y - c.y);
+        du = have ? du + a : a; dv = have ? dv + b : b; have = true;
+    }
+    if (j > 0) {
+        const double2 q = ldw2(U + k - 1);
+        const double a = s.p4 * (q.x - c.x), b = s.p4 * (q.y - c.y);
+        du = have ? du + a : a; dv = have ? dv + b : b; have = true;
+    }
+    if (nz > 1) {
+        if (f > 0 && f < nz - 1) {
+            const double2 lo = ldw2(U + k - df), hi = ldw2(U + k + df);
+            du += s.p5 * (lo.x - c.x) + s.p6 * (hi.x - c.x);
+            dv += s.p5 * (lo.y - c.y) + s.p6 * (hi.y - c.y);
+        } else if (f == 0) {
+            const double2 hi = ldw2(U + k + df);
+            du += s.p6 * (hi.x - c.x);
+            dv += s.p6 * (hi.y - c.y);
+        } else {
+            const double2 lo = ldw2(U + k - df);
+            du += s.p5 * (lo.x - c.x);
+            dv += s.p5 * (lo.y - c.y);
+        }
+    }
+    stn2(DV + k, make_double2(du, dv));
+    stn(Dd + k, alpha * (s.p1 + s.p2 + s.p3 + s.p4 + s.p5 + s.p6));
+    stn2(DU + k, make_double2(0.0, 0.0));
+}
+
+// SOR update of one pixel of frame f, :120-170; a missing neighbour (row, column or frame) is the pixel itself with
+// psi = 0.  The new value also goes into the sweep's snapshot.
+template <typename T>
+OFX_DEV double broxt_point(typename Pix<T>::v2 *DU, typename Pix<T>::v2 *snap, const typename Pix<T>::v4 *__restrict__ CO,
+                           const T *__restrict__ Dm, const T *__restrict__ Psis, int f, int i, int j, int nx, int ny, int nz,
+                           double alpha)
+{
+    const size_t df = (size_t) nx * ny;
+    const size_t k = f * df + (size_t) i * nx + j;
+    const Psi6 s = broxt_psi6(Psis, f, i, j, nx, ny, nz);
+    const double2 c = ldw2(DU + k);
+    const double2 dn = (i < ny - 1) ? ldw2(DU + k + nx) : c, up = (i > 0) ? ldw2(DU + k - nx) : c;
+    const double2 rt = (j < nx - 1) ? ldw2(DU + k + 1) : c, lf = (j > 0) ? ldw2(DU + k - 1) : c;
+    const double2 pv = (f > 0) ? ldw2(DU + k - df) : c, nxt = (f < nz - 1) ? ldw2(DU + k + df) : c;
+    const double4 co = ldw4(CO + k);
+    const double D = ldw(Dm + k);
+    const double w = BROX_SOR_W;
+    const double div_du = s.p1 * dn.x + s.p2 * up.x + s.p3 * rt.x + s.p4 * lf.x + s.p5 * pv.x + s.p6 * nxt.x;      // :157-159
+    const double div_dv = s.p1 * dn.y + s.p2 * up.y + s.p3 * rt.y + s.p4 * lf.y + s.p5 * pv.y + s.p6 * nxt.y;      // :160-162
+    const double duk = c.x, dvk = c.y;
+    const double dun = rnd_to<T>((1. - w) * duk + w * (co.x - D * dvk + alpha * div_du) / co.z);   // :167
+    const double dvn = rnd_to<T>((1. - w) * dvk + w * (co.y - D * dun + alpha * div_dv) / co.w);   // :168
+    stn2(DU + k, make_double2(dun, dvn));
+    stn2(snap + k, make_double2(dun, dvn));
+    return (dun - duk) * (dun - duk) + (dvn - dvk) * (dvn - dvk);                                  // :171
+}
+
+// Windowed exact schedule (k_brox_window) with the frame dimension: one workgroup per (sweep, frame, row block).
+// blockIdx.y = position o of the frame in the sweep's visiting order: frames 1 .. nz-2, then 0, then nz-1 (:439-459).
+template <typename T>
+__global__ __launch_bounds__(1024) void k_broxt_window(typename Pix<T>::v2 *DU, typename Pix<T>::v2 *snap,
+                                                       const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
+                                                       const T *__restrict__ Psis, double *__restrict__ err, SorWin w,
+                                                       int nx, int ny, int nz, double alpha)
+{
+    const int b = blockIdx.x, o = blockIdx.y, s = w.s_first + blockIdx.z;
+    const int f = (o < nz - 2) ? o + 1 : (o == nz - 2 ? 0 : nz - 1);
+    const int qmax = ny + nx - 2;
+    const int q_first = w.tau0 - w.lag_s * s - w.lag_f * o - w.lag_b * b;
+    if (q_first > qmax || q_first + w.K - 1 < 0) return;
+    typename Pix<T>::v2 *mysnap = snap + (size_t) s * nz * nx * ny;
+    const int r = sor_window_item(w, b, threadIdx.x, ny);
+    double e = 0.0;
+    for (int q = q_first; q < q_first + w.K; q++) {
+        if (q >= 0 && q <= qmax && r >= 0) {
+            int i, j;
+            if (r == ny + 2) {
+                for (int corner = 0; corner < 4; corner++)
+                    if (brox_plane_item(r, q, nx, ny, corner, i, j) && sor_border_block(i, ny, w.R) == b)
+                        e += broxt_point<T>(DU, mysnap, CO, Dm, Psis, f, i, j, nx, ny, nz, alpha);
+            } else if (brox_plane_item(r, q, nx, ny, 0, i, j) && (r < ny || sor_border_block(i, ny, w.R) == b)) {
+                e += broxt_point<T>(DU, mysnap, CO, Dm, Psis, f, i, j, nx, ny, nz, alpha);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    loop_accumulate(err, s, e, (o * 8 + b) * 4 + (threadIdx.x >> 6));
+}
+
+template <typename T> struct BroxtLevel {
+    using v2 = typename Pix<T>::v2;
+    using v4 = typename Pix<T>::v4;
+    int nx, ny;
+    T *I;                       // frames * n
+    T *Psis, *Dd, *Dm;          // nz * n each
+    v2 *G1, *PB, *WB, *U, *DV, *DU, *Snap;
+    v4 *PA, *WA, *CO;
+    int snap_planes;
+};
+
+template <typename T> static int broxt_level_alloc(ofx_ctx *ctx, BroxtLevel<T> &L, int nx, int ny, int frames)
+{
+    const size_t n1 = (size_t) nx * ny * (frames - 1);
+    L.nx = nx;
+    L.ny = ny;
+    OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny * frames, &L.I));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.Psis));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.Dd));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.Dm));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.G1));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.PB));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.WB));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.U));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.DV));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.DU));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.PA));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.WA));
+    OFX_TRY(ofx_alloc(ctx, n1, &L.CO));
+    L.Snap = nullptr;
+    L.snap_planes = 0;
+    return OFX_OK;
+}
+
+// src/brox_optic_flow_temporal.cpp:282-512 on device data
+template <typename T>
+static int broxt_single_scale_dev(ofx_ctx *ctx, BroxtLevel<T> &L, const BroxParams &P, int frames, int scale)
+{
+    const int nx = L.nx, ny = L.ny, nz = frames - 1, n = nx * ny;
+    const size_t n1 = (size_t) n * nz;
+    if ((long long) n1 >= (1LL << 31)) return ofx_fail(ctx, OFX_ERR_ARG, "brox temporal: sequence larger than 2^31 pixels");
+    if (nx < 3 || ny < 3) return ofx_fail(ctx, OFX_ERR_ARG, "brox temporal: level %dx%d has no interior", nx, ny);
+    const dim3 g = g2d(nx, ny), b = b2d(), g3(g.x, g.y, nz);
+    const dim3 g1((unsigned) ((n1 + 255) / 256)), b1(256);
+    ofx_stats &S = ctx->stats;
+    int solve = 0;
+    for (int f = 0; f < nz; f++) {                                                                   // :346-355
+        hipLaunchKernelGGL(k_brox_prepare<T>, g, b, 0, ctx->stream, (const T *) (L.I + (size_t) f * n),
+                           (const T *) (L.I + (size_t) (f + 1) * n), L.G1 + (size_t) f * n, L.PA + (size_t) f * n,
+                           L.PB + (size_t) f * n, nx, ny);
+    }
+    OFX_LAUNCH_CHECK(ctx);
+    for (int no = 0; no < P.outer_iter; no++) {                                                      // :358
+        for (int f = 0; f < nz; f++)                                                                 // :360-367
+            hipLaunchKernelGGL(k_brox_warp<T>, g, b, 0, ctx->stream, L.PA + (size_t) f * n, L.PB + (size_t) f * n,
+                               L.U + (size_t) f * n, L.WA + (size_t) f * n, L.WB + (size_t) f * n, nx, ny);
+        hipLaunchKernelGGL(k_broxt_psis<T>, g3, b, 0, ctx->stream, L.U, L.Psis, nx, ny, nz);          // :370-374
+        hipLaunchKernelGGL(k_broxt_div<T>, g3, b, 0, ctx->stream, L.U, (const T *) L.Psis, L.DV, L.Dd, L.DU, nx, ny, nz,
+                           P.alpha);                                                                 // :377-390
+        OFX_LAUNCH_CHECK(ctx);
+        for (int ni = 0; ni < P.inner_iter; ni++) {                                                  // :394
+            hipLaunchKernelGGL(k_brox_coeff<T>, g1, b1, 0, ctx->stream, (const T *) L.I, L.G1, L.WA, L.WB, L.DU, L.DV,
+                               (const T *) L.Dd, L.CO, L.Dm, (int) n1, P.alpha, P.gamma);            // :396-427
+            OFX_LAUNCH_CHECK(ctx);
+            int nsor = 0;
+            double error = 1000;
+            const size_t ub = n1 * sizeof(typename Pix<T>::v2);
+            const int batch = sor_pick_batch(ctx, n1, sizeof(typename Pix<T>::v2), OFX_BROX_MAX_ITERATIONS);
+            if (L.snap_planes < batch) {
+                OFX_TRY(ofx_alloc(ctx, n1 * batch, &L.Snap));
+                L.snap_planes = batch;
+            }
+            auto window = [&](const SorWin &w, int blocks, int sweeps) -> int {
+                hipLaunchKernelGGL(k_broxt_window<T>, dim3(blocks, nz, sweeps), dim3(sor_window_threads(w.R + 3)), 0,
+                                   ctx->stream, L.DU, L.Snap, L.CO, (const T *) L.Dm, (const T *) L.Psis, ctx->d_err, w, nx,
+                                   ny, nz, P.alpha);
+                OFX_LAUNCH_CHECK(ctx);
+                return OFX_OK;
+            };
+            auto take = [&](int k) -> int {
+                OFX_HIP(ctx, hipMemcpyAsync(L.DU, L.Snap + (size_t) (k - 1) * n1, ub, hipMemcpyDeviceToDevice, ctx->stream));
+                return OFX_OK;
+            };
+            OFX_TRY(sor_window_loop(ctx, (int) n1, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
+                                    take, &nsor, &error, nz));                                       // :430-461
+            if (P.verbose) { printf("Iterations: %d\n", nsor); fflush(stdout); }                     // :463-465
+            if (scale < OFX_MAX_SCALES) {
+                if (solve < OFX_MAX_SOLVES) { S.iters[scale][solve] = nsor; S.error[scale][solve] = error; }
+                S.iter_launches[scale] += nsor;
+            }
+            S.work_pix_iters += (double) nsor * n1;
+            solve++;
+        }
+        hipLaunchKernelGGL(k_brox_add<T>, g1, b1, 0, ctx->stream, L.U, L.DU, (int) n1);                // :469-472
+        OFX_LAUNCH_CHECK(ctx);
+    }
+    return OFX_OK;
+}
+
+// src/brox_optic_flow_temporal.cpp:520-627
+template <typename T>
+static int broxt_host(ofx_ctx *ctx, const double *I, double *u, double *v, int nx, int ny, int frames, const BroxParams &P,
+                      int nscales, double nu)
+{
+    const size_t n = (size_t) nx * ny;
+    int nxs[OFX_MAX_SCALES], nys[OFX_MAX_SCALES];
+    OFX_TRY(op_pyramid_sizes(ctx, nx, ny, nscales, nu, nxs, nys));
+    sor_stats_begin(ctx, nscales, P.inner_iter * P.outer_iter);
+    T *dI, *dummy, *tmpA, *tmpB;
+    double *scr;
+    OFX_TRY(upload_plane<T>(ctx, I, n * frames, &dI));
+    OFX_TRY(ofx_alloc(ctx, n * frames, &dummy));
+    OFX_TRY(ofx_alloc(ctx, n, &tmpA));
+    OFX_TRY(ofx_alloc(ctx, n, &tmpB));
+    OFX_TRY(ofx_alloc(ctx, op_pyramid_scratch_doubles(), &scr));
+    std::vector<BroxtLevel<T>> lv(nscales);
+    for (int s = 0; s < nscales; s++) {
+        OFX_TRY(broxt_level_alloc<T>(ctx, lv[s], nxs[s], nys[s], frames));
+        ctx->stats.nx[s] = nxs[s];
+        ctx->stats.ny[s] = nys[s];
+    }
+    // image_normalization_1 over the whole sequence (:548): the joint-min/max kernel of normalization_2 fed the
+    // sequence twice computes the same 255 (I - min) / den
+    OFX_TRY(op_normalize2<T>(ctx, dI, dI, lv[0].I, dummy, (int) (n * frames), scr));
+    for (int f = 0; f < frames; f++) OFX_TRY(op_gaussian<T>(ctx, lv[0].I + f * n, tmpA, nx, ny, BROX_SIGMA));     // :551-553
+    for (int s = 1; s < nscales; s++) {                                                              // :561-575
+        const size_t np = (size_t) nxs[s - 1] * nys[s - 1], nc = (size_t) nxs[s] * nys[s];
+        for (int f = 0; f < frames; f++)
+            OFX_TRY(op_zoom_out<T>(ctx, lv[s - 1].I + f * np, lv[s].I + f * nc, tmpA, tmpB, nxs[s - 1], nys[s - 1], nu));
+    }
+    BroxtLevel<T> &C = lv[nscales - 1];
+    OFX_TRY(op_fill2<T>(ctx, C.U, (size_t) C.nx * C.ny * (frames - 1)));                             // :578-580
+    for (int s = nscales - 1; s >= 0; s--) {                                                        // :587
+        if (P.verbose) { printf("Scale: %d\n", s); fflush(stdout); }
+        OFX_TRY(broxt_single_scale_dev<T>(ctx, lv[s], P, frames, s));
+        if (s) {
+            const size_t nc = (size_t) lv[s].nx * lv[s].ny, nf = (size_t) lv[s - 1].nx * lv[s - 1].ny;
+            for (int f = 0; f < frames - 1; f++)
+                OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U + f * nc, lv[s - 1].U + f * nf, lv[s].nx, lv[s].ny, lv[s - 1].nx,
+                                           lv[s - 1].ny, 1.0 / nu));                                 // :600-612
+        }
+    }
+    return download_flow<T>(ctx, lv[0].U, u, v, n * (frames - 1));
+}
+
+extern "C" int ofx_brox_temporal(ofx_ctx *ctx, const double *I, double *u, double *v, int nxx, int nyy, int frames,
+                                 double alpha, double gamma, int nscales, double nu, double TOL, int inner_iter,
+                                 int outer_iter, int verbose)
+{
+    OFX_ENTER(ctx);
+    if (!I || !u || !v) return ofx_fail(ctx, OFX_ERR_ARG, "brox temporal: NULL pointer");
+    if (frames <= 2) return ofx_fail(ctx, OFX_ERR_ARG, "The method needs more than two frames");     // :537-541
+    if (inner_iter < 0 || outer_iter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "brox temporal: negative iteration count");
+    if (nxx < 3 || nyy < 3) return ofx_fail(ctx, OFX_ERR_ARG, "brox temporal: images smaller than 3x3");
+    const double t0 = ofx_now_ms();
+    const BroxParams P = {alpha, gamma, TOL, inner_iter, outer_iter, verbose};
+    int s = ctx->precision == OFX_F64 ? broxt_host<double>(ctx, I, u, v, nxx, nyy, frames, P, nscales, nu)
+                                      : broxt_host<float>(ctx, I, u, v, nxx, nyy, frames, P, nscales, nu);
     ctx->stats.total_ms = ofx_now_ms() - t0;
     return s;
 }

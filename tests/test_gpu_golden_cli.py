@@ -198,3 +198,29 @@ def test_tvl1flow_cli_reads_png(synth, tmp_path):
         flows[kind] = read_flo(out)
     assert np.array_equal(flows["gray"], flows["pgm"])
     assert np.array_equal(flows["rgb"], flows["pgm_collapsed"])
+
+
+def test_brox_temporal_cli(synth, tmp_path):
+    """brox_temporal nimages I1..In [...] dir verbose: dir/flowNN.flo byte-identical to the reference vectors"""
+    c, g = CASES["broxt_seq4_64x48"], load("broxt_seq4_64x48")
+    seq = synth.sequence(c["nx"], c["ny"], c["pair"])
+    names = []
+    for f in range(seq.shape[0]):
+        names.append(str(tmp_path / ("f%d.pgm" % f)))
+        write_pgm(names[-1], seq[f])
+    p = c["params"]
+    out = tmp_path / "flows"
+    out.mkdir()
+    r = subprocess.run([os.path.join(BIN, "brox_temporal"), str(seq.shape[0])] + names +
+                       [str(p["alpha"]), str(p["gamma"]), str(p["nscales"]), str(p["nu"]), str(p["TOL"]), str(p["inner"]),
+                        str(p["outer"]), str(out), "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    printed = [int(x.split("Iterations: ")[1]) for x in r.stdout.splitlines() if x.startswith("Iterations:")]
+    assert printed == list(g["iters"]) and "Scale: 1" in r.stdout
+    for f in range(seq.shape[0] - 1):
+        want = np.stack([g["u"][f], g["v"][f]], axis=-1).astype(np.float32)
+        assert np.array_equal(read_flo(out / ("flow%02d.flo" % f)), want)
+    r = subprocess.run([os.path.join(BIN, "brox_temporal"), "2", names[0], names[1]], capture_output=True, text=True)
+    assert r.returncode == 0 and "more than two frames" in r.stderr
+    r = subprocess.run([os.path.join(BIN, "brox_temporal")], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage:" in r.stdout

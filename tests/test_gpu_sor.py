@@ -192,3 +192,49 @@ def test_exact_windowed_extreme_shapes(gpu64, orc, synth, nx, ny):
     ub, vb = gpu64.brox_spatial(I1, I2, **kw)
     assert np.array_equal(gpu64.stats().iterations(), it_r)
     assert np.abs(ub - ur).max() < 1e-11 and np.abs(vb - vr).max() < 1e-11
+
+
+# ---- Brox temporal ----------------------------------------------------------------------------
+@pytest.mark.parametrize("nx,ny,frames,kw", [
+    (48, 40, 3, dict(nscales=2, outer=3)),                           # nz = 2: no interior frame
+    (64, 48, 5, dict(nscales=2, outer=3, inner=2)),
+    (33, 47, 4, dict(nscales=1, outer=2, alpha=30.0, gamma=0.0)),    # runs into the 300-sweep limit
+    (150, 140, 4, dict(nscales=3, outer=4, nu=0.5)),                 # several row blocks per frame (R = 64)
+])
+def test_brox_temporal_exact(gpu64, orc, synth, nx, ny, frames, kw):
+    I = synth.sequence(nx, ny, frames)
+    ur, vr, it_r = orc.brox_temporal(I, **kw)
+    ug, vg = gpu64.brox_temporal(I, **kw)
+    assert np.array_equal(gpu64.stats().iterations(), it_r)
+    assert np.abs(ug - ur).max() < 1e-11 and np.abs(vg - vr).max() < 1e-11
+
+
+@pytest.mark.parametrize("window,rows", [(1, 2), (5, 3), (32, 0), (8, 1000)])
+def test_brox_temporal_any_window(gpu64, orc, synth, window, rows):
+    I = synth.sequence(40, 33, 5, 1)
+    kw = dict(nscales=1, outer=2, inner=1)
+    ur, vr, it_r = orc.brox_temporal(I, **kw)
+    gpu64.set_option("sor_window", window)
+    gpu64.set_option("sor_rows", rows)
+    try:
+        ug, vg = gpu64.brox_temporal(I, **kw)
+        it_g = gpu64.stats().iterations()
+    finally:
+        gpu64.set_option("sor_window", 0)
+        gpu64.set_option("sor_rows", 0)
+    assert np.array_equal(it_g, it_r)
+    assert np.abs(ug - ur).max() < 1e-11 and np.abs(vg - vr).max() < 1e-11
+
+
+def test_brox_temporal_golden_and_errors(gpu64, ofx_mod, synth):
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cases = json.load(open(os.path.join(here, "cases.json")))
+    for name in ("broxt_seq4_64x48", "broxt_seq3_48x40"):
+        c, g = cases[name], np.load(os.path.join(here, name + ".npz"))
+        u, v = gpu64.brox_temporal(synth.sequence(c["nx"], c["ny"], c["pair"]), **c["params"])
+        assert list(gpu64.stats().iterations()[::-1].ravel()) == list(g["iters"])
+        assert np.abs(u - g["u"]).max() < 1e-11 and np.abs(v - g["v"]).max() < 1e-11
+    with pytest.raises(ofx_mod.OfxError):
+        gpu64.brox_temporal(synth.sequence(32, 24, 2))               # "The method needs more than two frames"
