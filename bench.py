@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--pair", default="P1")
     ap.add_argument("--fixed-steps", type=int, default=2, help="fixed-work passes for the roofline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--lockstep", type=int, default=4,
-                    help="pairs per lockstep group (they share every kernel launch of one context)")
+    ap.add_argument("--lockstep", type=int, default=0,
+                    help="pairs per lockstep group (they share every kernel launch of one context); 0 = the library's "
+                         "choice: up to 4, fewer when the batch is small")
     ap.add_argument("--concurrency", type=int, default=0, help="override the library's concurrency hint (0 = streams)")
     ap.add_argument("--variants", type=int, default=8, help="distinct synthetic pairs cycled through by the steps")
     ap.add_argument("--streams", type=int, default=4,
@@ -156,14 +157,15 @@ def main():
     synth = importlib.import_module("optical-flow-1_amd.synth")
     prec = ofx_mod.F64 if a.precision == "f64" else ofx_mod.F32
     tdt = torch.float64 if a.precision == "f64" else torch.float32
-    lockstep = max(1, min(a.lockstep, 16, max(a.steps, 1)))
-    nstreams = max(1, min(a.streams, -(-max(a.steps, 1) // lockstep)))
+    nstreams = max(1, min(a.streams, max(a.steps, 1)))
+    lockstep = a.lockstep if a.lockstep > 0 else max(1, min(4, -(-max(a.steps, 1) // nstreams)))   # the library's rule
+    lockstep = min(lockstep, 16)
     in_flight = nstreams * lockstep
     ctxs = [ofx_mod.Ofx(local, prec) for _ in range(nstreams)]
     ctx = ctxs[0]
     for c_ in ctxs:
         c_.set_option("concurrency", a.concurrency or nstreams)
-        c_.set_option("lockstep", lockstep)
+        c_.set_option("lockstep", a.lockstep if a.lockstep > 0 else 0)
         if a.rows:
             c_.set_option("rows_per_wave", a.rows)
         if a.chunk:

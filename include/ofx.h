@@ -92,7 +92,7 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *   "sor_window"     time steps per launch of sor_exact = 1 (default 8)
  *   "sor_rows"       rows per workgroup (row block of a sweep) of sor_exact = 1 (default 64)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
- *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default 4, at most 16)
+ *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default: up to 4, fewer for small batches; at most 16)
  *   "concurrency"    number of contexts that will be solving on the same device at the same time
  *                         (default 1); a scheduling hint for the strip height of the TV-L1 kernels
  *   "rows_per_wave", "rows_per_wave2", "chunk"   tuning of the TV-L1 kernels / launch batching */
@@ -156,7 +156,7 @@ int ofx_tvl1_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *dI0, const 
                        int nscales, double zfactor, int warps, double epsilon, ofx_stats *stats_out);
 
 /* Batch of independent pairs on ONE device (the unit of parallel work is the image pair).
- * The pairs are cut into lockstep groups of `lockstep` consecutive pairs (option of ctxs[0], default 4);
+ * The pairs are cut into lockstep groups of `lockstep` consecutive pairs (option of ctxs[0]; default: up to 4, fewer when the batch is small);
  * group q is solved on context ctxs[q % n_ctx] with ofx_tvl1_group_dev, one host thread per context, so
  * n_ctx groups are in flight at a time (each context = its own HIP stream and workspace; all contexts
  * must live on the same device and have the same precision).  Arrays dI0/dI1/d_flo hold n_pairs device

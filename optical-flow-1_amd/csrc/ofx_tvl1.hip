@@ -956,7 +956,7 @@ extern "C" int ofx_tvl1_iterations(ofx_ctx *ctx, double *u1, double *u2, double 
 }
 
 // ---- batch of pairs: lockstep groups, one worker thread per context --------------------------------------
-// The pairs are cut into groups of `lockstep` (option of ctxs[0]; default 4) consecutive pairs; group q is
+// The pairs are cut into groups of `lockstep` (option of ctxs[0]; default: up to 4) consecutive pairs; group q is
 // solved by context q % n_ctx with ofx_tvl1_group_dev, i.e. its pairs share every launch.  On the small
 // pyramid levels a launch is a latency chain that leaves most of the GPU idle, so G pairs per launch cost
 // the time of one; and the convergence polls (one host round trip per warp) are paid once per group.
@@ -968,7 +968,13 @@ extern "C" int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *c
     if (!ctxs || n_ctx < 1 || n_pairs < 0 || !dI0 || !dI1 || !d_flo) return OFX_ERR_ARG;
     for (int w = 0; w < n_ctx; w++)
         if (!ctxs[w] || ctxs[w]->device != ctxs[0]->device || ctxs[w]->precision != ctxs[0]->precision) return OFX_ERR_ARG;
-    int G = ctxs[0]->lockstep > 0 ? ctxs[0]->lockstep : 4;
+    // group size: the "lockstep" option, or -- automatic -- 4, shrunk so that a small batch still gives every
+    // context a group (5 pairs on 4 contexts: groups of 2, 2, 1 instead of 4 + 1)
+    int G = ctxs[0]->lockstep;
+    if (G <= 0) {
+        G = (n_pairs + n_ctx - 1) / n_ctx;
+        G = G < 1 ? 1 : (G > 4 ? 4 : G);
+    }
     if (G > OFX_MAX_GROUP) G = OFX_MAX_GROUP;
     const int n_groups = (n_pairs + G - 1) / G;
     std::atomic<int> status(OFX_OK);
