@@ -836,8 +836,8 @@ extern "C" int ofx_tvl1_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *
         if (!dI0[g] || !dI1[g] || !d_flo[g]) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: NULL pointer (pair %d)", g);
     const double t0 = ofx_now_ms();
     const Tvl1Params P = make_params(ctx, tau, lambda, theta, warps, epsilon, 0);
-    ofx_stats local[OFX_MAX_GROUP];
-    ofx_stats *st = stats_out ? stats_out : local;
+    std::vector<ofx_stats> local(stats_out ? 0 : n_pairs);      // ~25 KB per record: not on the stack
+    ofx_stats *st = stats_out ? stats_out : local.data();
     int s = ctx->precision == OFX_F64
                 ? tvl1_group_devapi<double>(ctx, n_pairs, dI0, dI1, d_flo, nx, ny, P, nscales, zfactor, st)
                 : tvl1_group_devapi<float>(ctx, n_pairs, dI0, dI1, d_flo, nx, ny, P, nscales, zfactor, st);
