@@ -109,6 +109,9 @@ int ofx_dxy(ofx_ctx *ctx, const double *I, double *Ixy, int nx, int ny);
  * window 5): src/operators.cpp:506-624 */
 int ofx_gaussian(ofx_ctx *ctx, double *I, int nx, int ny, double sigma);
 
+/* centered_gradient3 (src/operators.h:107-114): f holds nz frames of nx*ny; dx, dy per frame, dz between frames */
+int ofx_centered_gradient3(ofx_ctx *ctx, const double *f, double *dx, double *dy, double *dz, int nx, int ny, int nz);
+
 /* ---- bicubic interpolation (replace src/bicubic_interpolation.h:16-52) -----------------------*/
 /* n samples at (uu[k], vv[k]) -> out[k]; one call of the reference's bicubic_interpolation_at
  * per sample */
@@ -116,15 +119,23 @@ int ofx_bicubic_at(ofx_ctx *ctx, const double *input, const double *uu, const do
                    int n, int nx, int ny, int border_out);
 int ofx_bicubic_warp(ofx_ctx *ctx, const double *input, const double *u, const double *v, double *output,
                      int nx, int ny, int border_out);
+/* bicubic_interpolation_at_color (src/bicubic_interpolation.h:30-43): channel k of nz interleaved channels */
+int ofx_bicubic_at_color(ofx_ctx *ctx, const double *input, const double *uu, const double *vv, double *out,
+                         int n, int nx, int ny, int nz, int k, int border_out);
 
 /* ---- pyramid zoom (replace src/zoom.h:20-63) -------------------------------------------------*/
 void ofx_zoom_size(int nx, int ny, int *nxx, int *nyy, double factor);      /* pure host arithmetic */
 int  ofx_zoom_out(ofx_ctx *ctx, const double *I, double *Iout, int nx, int ny, double factor);
 int  ofx_zoom_in(ofx_ctx *ctx, const double *I, double *Iout, int nx, int ny, int nxx, int nyy);
+/* zoom_out_color (src/zoom.h:44-55).  The reference is only defined for nz = 1 (for nz > 1 it reads beyond its
+ * nx*ny scratch copy, src/zoom.cpp:96-118); nz = 1 is zoom_out, any other nz is OFX_ERR_ARG. */
+int  ofx_zoom_out_color(ofx_ctx *ctx, const double *I, double *Iout, int nx, int ny, int nz, double factor);
 
 /* ---- normalisation (replace src/utils.h:27-32) -----------------------------------------------*/
 int ofx_image_normalization_2(ofx_ctx *ctx, const double *I1, const double *I2, double *I1n, double *I2n,
                               int size);
+int ofx_image_normalization_1(ofx_ctx *ctx, const double *I, double *In, int size);      /* src/utils.h:17-20 */
+int ofx_getminmax(ofx_ctx *ctx, const double *x, int n, double *min, double *max);        /* src/utils.h:119 */
 
 /* ---- TV-L1 (replace src/tvl1flow.h:36-70) ----------------------------------------------------*/
 /* single scale: u1/u2 are read as the initial flow and overwritten with the result */

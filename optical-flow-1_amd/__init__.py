@@ -96,6 +96,11 @@ def lib():
         "ofx_zoom_out": (_i, [_vp, _dp, _dp, _i, _i, _d]),
         "ofx_zoom_in": (_i, [_vp, _dp, _dp, _i, _i, _i, _i]),
         "ofx_image_normalization_2": (_i, [_vp, _dp, _dp, _dp, _dp, _i]),
+        "ofx_image_normalization_1": (_i, [_vp, _dp, _dp, _i]),
+        "ofx_getminmax": (_i, [_vp, _dp, _i, C.POINTER(_d), C.POINTER(_d)]),
+        "ofx_centered_gradient3": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i]),
+        "ofx_bicubic_at_color": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _i, _i]),
+        "ofx_zoom_out_color": (_i, [_vp, _dp, _dp, _i, _i, _i, _d]),
         "ofx_tvl1_single_scale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _d, _i, _d, _i]),
         "ofx_tvl1_multiscale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _d, _i, _d, _i, _d, _i]),
         "ofx_tvl1_multiscale_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _d, _d, _i, _d, _i, _d, _i]),
@@ -322,3 +327,35 @@ class Ofx:
         self._ck(self.L.ofx_brox_temporal(self.h, _f64(I), u, v, nx, ny, frames, alpha, gamma, nscales, nu, TOL, inner,
                                           outer, verbose))
         return u, v
+
+    # ---- colour / sequence variants of the operator surface --------------------------------------------------
+    def centered_gradient3(self, f):
+        nz, ny, nx = f.shape
+        dx, dy, dz = np.empty((nz, ny, nx)), np.empty((nz, ny, nx)), np.empty((nz, ny, nx))
+        self._ck(self.L.ofx_centered_gradient3(self.h, _f64(f), dx, dy, dz, nx, ny, nz))
+        return dx, dy, dz
+
+    def bicubic_at_color(self, I, uu, vv, k, border_out=False):
+        """I: (ny, nx, nz) interleaved channels; uu, vv: arrays of sample coordinates"""
+        ny, nx, nz = I.shape
+        uu, vv = _f64(np.atleast_1d(uu)), _f64(np.atleast_1d(vv))
+        out = np.empty(uu.shape)
+        self._ck(self.L.ofx_bicubic_at_color(self.h, _f64(I), uu, vv, out, uu.size, nx, ny, nz, k, int(border_out)))
+        return out
+
+    def zoom_out_color(self, I, factor):
+        ny, nx, nz = I.shape
+        nxx, nyy = zoom_size(nx, ny, factor)
+        out = np.empty((nyy, nxx, nz))
+        self._ck(self.L.ofx_zoom_out_color(self.h, _f64(I), out, nx, ny, nz, factor))
+        return out
+
+    def image_normalization_1(self, I):
+        out = np.empty(I.shape)
+        self._ck(self.L.ofx_image_normalization_1(self.h, _f64(I), out, I.size))
+        return out
+
+    def getminmax(self, x):
+        a, b = _d(), _d()
+        self._ck(self.L.ofx_getminmax(self.h, _f64(x), x.size, C.byref(a), C.byref(b)))
+        return a.value, b.value

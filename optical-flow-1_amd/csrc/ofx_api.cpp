@@ -174,6 +174,72 @@ template <typename T> int norm_t(ofx_ctx *ctx, const double *I1, const double *I
     return h.sync();
 }
 
+template <typename T>
+int at_color_t(ofx_ctx *ctx, const double *in, const double *uu, const double *vv, double *out, int cnt, int nx, int ny,
+               int nz, int ch, int bo)
+{
+    HostOp<T> h{ctx};
+    const size_t n = (size_t) nx * ny * nz;
+    T *a;
+    double *du, *dv, *o;
+    OFX_TRY(h.in(in, &a, n));
+    OFX_TRY(ofx_alloc(ctx, (size_t) cnt, &du));
+    OFX_TRY(ofx_alloc(ctx, (size_t) cnt, &dv));
+    OFX_TRY(ofx_alloc(ctx, (size_t) cnt, &o));
+    OFX_HIP(ctx, hipMemcpyAsync(du, uu, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    OFX_HIP(ctx, hipMemcpyAsync(dv, vv, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    OFX_TRY(op_bicubic_at_color<T>(ctx, a, du, dv, o, cnt, nx, ny, nz, ch, bo));
+    OFX_HIP(ctx, hipMemcpyAsync(out, o, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return h.sync();
+}
+
+template <typename T>
+int gradient3_t(ofx_ctx *ctx, const double *f, double *gx, double *gy, double *gz, int nx, int ny, int nz)
+{
+    HostOp<T> h{ctx};
+    const size_t df = (size_t) nx * ny, n = df * nz;
+    T *a, *ox, *oy, *oz;
+    OFX_TRY(h.in(f, &a, n));
+    OFX_TRY(h.out_alloc(&ox, n));
+    OFX_TRY(h.out_alloc(&oy, n));
+    OFX_TRY(h.out_alloc(&oz, n));
+    for (int k = 0; k < nz; k++) OFX_TRY(op_centered_gradient<T>(ctx, a + k * df, ox + k * df, oy + k * df, nx, ny));
+    OFX_TRY(op_gradient_dz<T>(ctx, a, oz, nx, ny, nz));
+    OFX_TRY(h.out(ox, gx, n));
+    OFX_TRY(h.out(oy, gy, n));
+    OFX_TRY(h.out(oz, gz, n));
+    return h.sync();
+}
+
+template <typename T> int norm1_t(ofx_ctx *ctx, const double *I, double *o, int size)
+{
+    HostOp<T> h{ctx};
+    T *a, *x, *dummy;
+    double *scr;
+    OFX_TRY(h.in(I, &a, (size_t) size));
+    OFX_TRY(h.out_alloc(&x, (size_t) size));
+    OFX_TRY(h.out_alloc(&dummy, (size_t) size));
+    OFX_TRY(ofx_alloc(ctx, op_pyramid_scratch_doubles(), &scr));
+    OFX_TRY(op_normalize2<T>(ctx, a, a, x, dummy, size, scr));      // joint min / max of (I, I) = min / max of I
+    OFX_TRY(h.out(x, o, (size_t) size));
+    return h.sync();
+}
+
+template <typename T> int minmax_t(ofx_ctx *ctx, const double *x, int size, double *mn, double *mx)
+{
+    HostOp<T> h{ctx};
+    T *a;
+    double *scr, mm[2];
+    OFX_TRY(h.in(x, &a, (size_t) size));
+    OFX_TRY(ofx_alloc(ctx, op_pyramid_scratch_doubles(), &scr));
+    OFX_TRY(op_minmax<T>(ctx, a, size, scr));
+    OFX_HIP(ctx, hipMemcpyAsync(mm, scr + 2 * 1024, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_TRY(h.sync());
+    *mn = mm[0];
+    *mx = mm[1];
+    return OFX_OK;
+}
+
 } // namespace
 
 #define DISPATCH(ctx, fn, ...) ((ctx)->precision == OFX_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
@@ -277,6 +343,49 @@ int ofx_zoom_in(ofx_ctx *ctx, const double *I, double *Iout, int nx, int ny, int
     OFX_TRY(check_dims(ctx, nx, ny));
     if (nxx < 1 || nyy < 1) return ofx_fail(ctx, OFX_ERR_ARG, "zoom_in: bad output size");
     return DISPATCH(ctx, zoom_in_t, ctx, I, Iout, nx, ny, nxx, nyy);
+}
+
+int ofx_bicubic_at_color(ofx_ctx *ctx, const double *input, const double *uu, const double *vv, double *out, int n,
+                         int nx, int ny, int nz, int k, int border_out)
+{
+    OFX_ENTER(ctx);
+    if (!input || !uu || !vv || !out || n < 1) return ofx_fail(ctx, OFX_ERR_ARG, "NULL pointer / n < 1");
+    if (nz < 1 || k < 0 || k >= nz) return ofx_fail(ctx, OFX_ERR_ARG, "bicubic_at_color: channel %d of %d", k, nz);
+    OFX_TRY(check_dims(ctx, nx, ny));
+    return DISPATCH(ctx, at_color_t, ctx, input, uu, vv, out, n, nx, ny, nz, k, border_out);
+}
+
+int ofx_centered_gradient3(ofx_ctx *ctx, const double *f, double *dx, double *dy, double *dz, int nx, int ny, int nz)
+{
+    OFX_ENTER(ctx);
+    if (!f || !dx || !dy || !dz) return ofx_fail(ctx, OFX_ERR_ARG, "NULL pointer");
+    if (nz < 1) return ofx_fail(ctx, OFX_ERR_ARG, "centered_gradient3: nz=%d", nz);
+    OFX_TRY(check_dims(ctx, nx, ny));
+    return DISPATCH(ctx, gradient3_t, ctx, f, dx, dy, dz, nx, ny, nz);
+}
+
+int ofx_zoom_out_color(ofx_ctx *ctx, const double *I, double *Iout, int nx, int ny, int nz, double factor)
+{
+    // src/zoom.cpp:85-125 copies and smooths only nx*ny samples of the nz-channel image and then indexes that
+    // scratch copy with interleaved-channel offsets: for nz > 1 it reads beyond the allocation (undefined
+    // behaviour), for nz == 1 it IS zoom_out.  Only the defined case is provided.
+    if (!ctx) return OFX_ERR_ARG;
+    if (nz != 1) return ofx_fail(ctx, OFX_ERR_ARG, "zoom_out_color: nz=%d (the reference is only defined for nz = 1)", nz);
+    return ofx_zoom_out(ctx, I, Iout, nx, ny, factor);
+}
+
+int ofx_image_normalization_1(ofx_ctx *ctx, const double *I, double *In, int size)
+{
+    OFX_ENTER(ctx);
+    if (!I || !In || size < 1) return ofx_fail(ctx, OFX_ERR_ARG, "NULL pointer / size < 1");
+    return DISPATCH(ctx, norm1_t, ctx, I, In, size);
+}
+
+int ofx_getminmax(ofx_ctx *ctx, const double *x, int n, double *min, double *max)
+{
+    OFX_ENTER(ctx);
+    if (!x || !min || !max || n < 1) return ofx_fail(ctx, OFX_ERR_ARG, "NULL pointer / n < 1");
+    return DISPATCH(ctx, minmax_t, ctx, x, n, min, max);
 }
 
 int ofx_image_normalization_2(ofx_ctx *ctx, const double *I1, const double *I2, double *I1n, double *I2n, int size)

@@ -53,6 +53,13 @@ template <typename T> int op_bicubic_warp(ofx_ctx *ctx, const T *in, const T *u,
 template <typename T> int op_bicubic_at(ofx_ctx *ctx, const T *in, const double *uu, const double *vv,
                                         double *out, int n, int nx, int ny, int border_out);
 
+// colour / sequence variants of the operator surface (bicubic_interpolation.h:30, operators.h:107, utils.h:119)
+template <typename T> int op_bicubic_at_color(ofx_ctx *ctx, const T *in, const double *uu, const double *vv, double *out,
+                                              int n, int nx, int ny, int nz, int ch, int border_out);
+template <typename T> int op_gradient_dz(ofx_ctx *ctx, const T *in, T *dz, int nx, int ny, int nz);
+// scr >= op_pyramid_scratch_doubles(); result: scr[2 * 1024] = min, scr[2 * 1024 + 1] = max
+template <typename T> int op_minmax(ofx_ctx *ctx, const T *x, int size, double *scr);
+
 // pa = (f, centred dx) pairs, pb = centred dy: one pair gather + one scalar gather per bicubic tap serve the
 // three warps of (f, fx, fy) (see bicubic_sample3 in ofx_device.h for why not one padded 4-vector)
 template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v2 *pa, T *pb, int nx, int ny);

@@ -404,6 +404,48 @@ __global__ void k_bicubic_at(const T *__restrict__ in, const double *__restrict_
     out[k] = (t.out && border_out) ? 0.0 : bicubic_sample(in, t, nx);
 }
 
+// bicubic_interpolation_at_color (src/bicubic_interpolation.cpp:253-344): channel k of an image with nz interleaved
+// channels, same tap rule as the scalar version
+template <typename T>
+__global__ void k_bicubic_at_color(const T *__restrict__ in, const double *__restrict__ uu, const double *__restrict__ vv,
+                                   double *__restrict__ out, int n, int nx, int ny, int nz, int ch, int border_out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const BicubicTaps t = bicubic_taps(uu[k], vv[k], nx, ny);
+    double r = 0.0;
+    if (!(t.out && border_out)) {
+        double c[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double v0 = ldw(in + ((size_t) t.row[0] * nx + t.col[q]) * nz + ch);
+            const double v1 = ldw(in + ((size_t) t.row[1] * nx + t.col[q]) * nz + ch);
+            const double v2 = ldw(in + ((size_t) t.row[2] * nx + t.col[q]) * nz + ch);
+            const double v3 = ldw(in + ((size_t) t.row[3] * nx + t.col[q]) * nz + ch);
+            c[q] = cubic_cell(v0, v1, v2, v3, t.fy);
+        }
+        r = cubic_cell(c[0], c[1], c[2], c[3], t.fx);
+    }
+    out[k] = r;
+}
+
+// the temporal part of centered_gradient3 (src/operators.cpp:477-498): centred difference between frames,
+// one-sided (still x 0.5) in the first / last frame, 0 for a single frame
+template <typename T>
+__global__ void k_gradient_dz(const T *__restrict__ in, T *__restrict__ dz, size_t df, int nz)
+{
+    const size_t p = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (p >= df) return;
+    const size_t k = (size_t) f * df + p;
+    double r = 0.0;
+    if (nz > 1) {
+        const double hi = ldw(in + (f < nz - 1 ? k + df : k)), lo = ldw(in + (f > 0 ? k - df : k));
+        r = 0.5 * (hi - lo);
+    }
+    stn(dz + k, r);
+}
+
 template <typename T> int op_divergence(ofx_ctx *ctx, const T *v1, const T *v2, T *div, int nx, int ny)
 {
     hipLaunchKernelGGL(k_divergence<T>, grid2d(nx, ny), block2d(), 0, ctx->stream, v1, v2, div, nx, ny);
@@ -524,6 +566,36 @@ int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nxx, int nyy, i
     return op_build_pyramid_into<T>(ctx, dA, dB, nscales, zfactor, sigma, lv, tmpA, tmpB, scr);
 }
 
+template <typename T>
+int op_bicubic_at_color(ofx_ctx *ctx, const T *in, const double *uu, const double *vv, double *out, int n, int nx, int ny,
+                        int nz, int ch, int border_out)
+{
+    hipLaunchKernelGGL(k_bicubic_at_color<T>, dim3(grid1d((size_t) n)), dim3(256), 0, ctx->stream, in, uu, vv, out, n, nx,
+                       ny, nz, ch, border_out);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+
+template <typename T> int op_gradient_dz(ofx_ctx *ctx, const T *in, T *dz, int nx, int ny, int nz)
+{
+    const size_t df = (size_t) nx * ny;
+    hipLaunchKernelGGL(k_gradient_dz<T>, dim3(grid1d(df), nz), dim3(256), 0, ctx->stream, in, dz, df, nz);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+
+// getminmax (src/utils.cpp:509-525) of one array: mm[0] = min, mm[1] = max on the device
+template <typename T> int op_minmax(ofx_ctx *ctx, const T *x, int size, double *scr)
+{
+    int nb = grid1d((size_t) size);
+    if (nb > MM_BLOCKS) nb = MM_BLOCKS;
+    hipLaunchKernelGGL(k_minmax_partial<T>, dim3(nb), dim3(256), 0, ctx->stream, x, x, size, scr);
+    OFX_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, ctx->stream, scr, nb, scr + 2 * MM_BLOCKS);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+
 // ---- explicit instantiations -----------------------------------------------------------------------
 #define OFX_INSTANTIATE(T)                                                                                           \
     template int op_convert_in<T>(ofx_ctx *, const double *, T *, size_t);                                            \
@@ -544,6 +616,9 @@ int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nxx, int nyy, i
     template int op_bicubic_warp<T>(ofx_ctx *, const T *, const T *, const T *, T *, int, int, int);                  \
     template int op_bicubic_at<T>(ofx_ctx *, const T *, const double *, const double *, double *, int, int, int, int);           \
     template int op_grad_pack<T>(ofx_ctx *, const T *, Pix<T>::v2 *, T *, int, int);                                            \
+    template int op_bicubic_at_color<T>(ofx_ctx *, const T *, const double *, const double *, double *, int, int, int, int, int, int); \
+    template int op_gradient_dz<T>(ofx_ctx *, const T *, T *, int, int, int);                                                   \
+    template int op_minmax<T>(ofx_ctx *, const T *, int, double *);                                                             \
     template int op_build_pyramid<T>(ofx_ctx *, const T *, const T *, int, int, int, double, double,                   \
                                      std::vector<ImgLevel<T>> &);                                                      \
     template int op_build_pyramid_into<T>(ofx_ctx *, const T *, const T *, int, double, double,                        \

@@ -141,6 +141,17 @@ class _Lib:
         self._fn("centered_gradient3", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int)(_f64(f), dx, dy, dz, nx, ny, nz)
         return dx, dy, dz
 
+    def bicubic_at_color(self, I, uu, vv, k, border_out=False):
+        """I: (ny, nx, nz) interleaved channels"""
+        ny, nx, nz = I.shape
+        return self._fn("bicubic_at_color", C.c_double, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                        C.c_int)(_f64(I), uu, vv, nx, ny, nz, k, int(border_out))
+
+    def getminmax(self, x):
+        a, b = C.c_double(), C.c_double()
+        self._fn("getminmax", None, C.POINTER(C.c_double), C.POINTER(C.c_double), _dp, C.c_int)(C.byref(a), C.byref(b), _f64(x), x.size)
+        return a.value, b.value
+
     def image_normalization_1(self, I):
         out = np.empty(I.shape)
         self._fn("image_normalization_1", None, _dp, _dp, C.c_int)(_f64(I), out, I.size)

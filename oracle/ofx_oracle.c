@@ -1410,3 +1410,33 @@ int orc_brox_temporal(const double *I, double *u, double *v, int nxx, int nyy, i
     free(Is); free(us); free(vs); free(nx); free(ny);
     return rc;
 }
+
+/* src/bicubic_interpolation.cpp:253-344: channel k of an image with nz interleaved channels; taps exactly as in
+ * orc_bicubic_at (same truncation, sign and clamping quirks) */
+double orc_bicubic_at_color(const double *in, double uu, double vv, int nx, int ny, int nz, int k, int border_out)
+{
+    const int sx = (uu < 0) ? -1 : 1, sy = (vv < 0) ? -1 : 1;
+    int out = 0;
+    const int x = clamp_flag((int) uu, nx, &out), y = clamp_flag((int) vv, ny, &out);
+    const int mx = clamp_flag((int) uu - sx, nx, &out), my = clamp_flag((int) vv - sx, ny, &out);
+    const int dx = clamp_flag((int) uu + sx, nx, &out), dy = clamp_flag((int) vv + sy, ny, &out);
+    const int ddx = clamp_flag((int) uu + 2 * sx, nx, &out), ddy = clamp_flag((int) vv + 2 * sy, ny, &out);
+    if (out && border_out) return 0.0;
+    const int cols[4] = {mx, x, dx, ddx}, rows[4] = {my, y, dy, ddy};
+    double c[4];
+    for (int q = 0; q < 4; q++)
+        c[q] = cubic_cell(in[((size_t) cols[q] + (size_t) nx * rows[0]) * nz + k], in[((size_t) cols[q] + (size_t) nx * rows[1]) * nz + k],
+                          in[((size_t) cols[q] + (size_t) nx * rows[2]) * nz + k], in[((size_t) cols[q] + (size_t) nx * rows[3]) * nz + k],
+                          vv - y);
+    return cubic_cell(c[0], c[1], c[2], c[3], uu - x);
+}
+
+/* src/utils.cpp:509-525 */
+void orc_getminmax(double *mn, double *mx, const double *x, int n)
+{
+    *mn = *mx = x[0];
+    for (int i = 1; i < n; i++) {
+        if (x[i] < *mn) *mn = x[i];
+        if (x[i] > *mx) *mx = x[i];
+    }
+}

@@ -150,4 +150,9 @@ void ref_centered_gradient3(const double *in, double *dx, double *dy, double *dz
 
 void ref_image_normalization_1(const double *I, double *In, int size) { image_normalization_1(I, In, size); }
 
+double ref_bicubic_at_color(const double *in, double uu, double vv, int nx, int ny, int nz, int k, int border_out)
+{ return bicubic_interpolation_at_color(in, uu, vv, nx, ny, nz, k, border_out != 0); }
+
+void ref_getminmax(double *mn, double *mx, const double *x, int n) { getminmax(mn, mx, x, n); }
+
 } // extern "C"

@@ -79,3 +79,28 @@ def test_ops_f32_storage(gpu32, orc, nx, ny):
     u, v = rnd(5, ny, nx, 3), rnd(6, ny, nx, 3)
     assert np.abs(gpu32.bicubic_warp(a, u, v, True) - orc.bicubic_warp(a, u, v, True)).max() < 5e-3
     assert np.abs(gpu32.zoom_out(a, 0.5) - orc.zoom_out(a, 0.5)).max() < tol
+
+
+def test_colour_sequence_and_minmax_operators(gpu64, orc, ofx_mod):
+    """ofx_bicubic_at_color, ofx_centered_gradient3, ofx_image_normalization_1, ofx_getminmax, ofx_zoom_out_color
+    (the prototypes of SURVEY 8b's header ranges beyond the single-channel ones)"""
+    rng = np.random.default_rng(12)
+    img = rng.standard_normal((13, 17, 3)) * 40
+    uu, vv = rng.uniform(-3, 20, 200), rng.uniform(-3, 16, 200)
+    for k in range(3):
+        for bo in (False, True):
+            want = np.array([orc.bicubic_at_color(img, x, y, k, bo) for x, y in zip(uu, vv)])
+            assert np.array_equal(gpu64.bicubic_at_color(img, uu, vv, k, bo), want)
+    for nz in (1, 2, 5):
+        f = rng.standard_normal((nz, 11, 14))
+        for g, o in zip(gpu64.centered_gradient3(f), orc.centered_gradient3(f)):
+            assert np.array_equal(g, o)
+    seq = np.floor(rng.uniform(3, 200, (4, 9, 12)))
+    assert np.array_equal(gpu64.image_normalization_1(seq), orc.image_normalization_1(seq))
+    const = np.full((3, 4), 7.0)
+    assert np.array_equal(gpu64.image_normalization_1(const), const)          # den = 0: plain copy (utils.cpp:269-274)
+    assert gpu64.getminmax(img) == (img.min(), img.max())
+    one = rng.uniform(0, 255, (20, 24, 1))
+    assert np.array_equal(gpu64.zoom_out_color(one, 0.5)[..., 0], orc.zoom_out(one[..., 0], 0.5))
+    with pytest.raises(ofx_mod.OfxError):
+        gpu64.zoom_out_color(img, 0.5)                                        # nz > 1: undefined in the reference

@@ -95,3 +95,14 @@ def test_known_answer_anchor_p0_640x480(ref, synth):
     I0, I1 = synth.pair("P0", 640, 480)
     u, v = ref.tvl1_multiscale(I0, I1, nscales=5)
     assert abs(u.mean() - 1.594792) < 5e-7 and abs(v.mean() + 0.723327) < 5e-7
+
+
+def test_colour_and_minmax_operators(orc, ref):
+    """the remaining prototypes of SURVEY 8b's header ranges: bicubic_interpolation_at_color, getminmax"""
+    rng = np.random.default_rng(11)
+    img = rng.standard_normal((6, 9, 3)) * 40
+    for uu, vv in [(-3.5, 2.5), (0.0, 0.0), (1.25, 3.5), (7.999, 4.2), (8.0, 5.0), (20.0, -9.0), (4.4, 2.6)]:
+        for k in range(3):
+            for bo in (False, True):
+                assert orc.bicubic_at_color(img, uu, vv, k, bo) == ref.bicubic_at_color(img, uu, vv, k, bo)
+    assert orc.getminmax(img) == ref.getminmax(img) == (img.min(), img.max())
