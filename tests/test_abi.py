@@ -62,3 +62,14 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".c", ".cpp", ".h", ".hip", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "liboracle" not in text and "libofref" not in text, f
+
+
+def test_reference_shim_compiles_against_the_reference_headers():
+    """include/ofx_reference_shim.hpp defines the reference's own prototypes on top of the C ABI; compiling it with the
+    reference's real headers proves every signature matches (a mismatch is a conflicting declaration)."""
+    import subprocess
+    if not os.path.exists("/root/reference/src/tvl1flow.h"):
+        pytest.skip("/root/reference not present on this machine")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I/root/reference/src", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "shim", "shim_driver.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
