@@ -19,6 +19,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libofref.so")
+REF32_SO = os.path.join(HERE, "_ref", "libofref32.so")      # the reference's float build (ofpix_t = float)
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _ip = C.POINTER(C.c_int)
@@ -344,4 +345,41 @@ class Ref(_Lib):
             raise ValueError("GaussianSmooth: sigma too large")
         if rc:
             raise ValueError("The method needs more than two frames")
+        return u, v
+
+
+class Ref32:
+    """The reference's own FLOAT build (src/of.h with OFPIX_DOUBLE off), double planes converted at the boundary:
+    what float storage costs the reference itself (oracle variant 2)."""
+    kind = "reference-f32"
+
+    def __init__(self):
+        if not os.path.exists(REF32_SO):
+            raise FileNotFoundError(REF32_SO + " (run `make -C oracle` where /root/reference is present)")
+        self.lib = C.CDLL(REF32_SO)
+
+    def set_num_threads(self, n):
+        f = self.lib.ref32_set_num_threads
+        f.restype, f.argtypes = None, [C.c_int]
+        f(n)
+
+    def tvl1_multiscale(self, I0, I1, tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5, epsilon=0.01, verbose=0):
+        ny, nx = I0.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        f = self.lib.ref32_tvl1_multiscale
+        f.restype = C.c_int
+        f.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int,
+                      C.c_double, C.c_int]
+        if f(_f64(I0), _f64(I1), u, v, nx, ny, tau, lam, theta, nscales, zfactor, warps, epsilon, verbose):
+            raise ValueError("GaussianSmooth: sigma too large")
+        return u, v
+
+    def hs_pyramidal(self, I1, I2, alpha=7.0, nscales=10, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150, verbose=0):
+        ny, nx = I1.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        f = self.lib.ref32_hs_pyramidal
+        f.restype = C.c_int
+        f.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int]
+        if f(_f64(I1), _f64(I2), u, v, nx, ny, alpha, nscales, zfactor, warps, TOL, maxiter, verbose):
+            raise ValueError("GaussianSmooth: sigma too large")
         return u, v
