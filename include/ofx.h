@@ -194,6 +194,11 @@ int ofx_hs_pyramidal(ofx_ctx *ctx, const double *I1, const double *I2, double *u
                      int nx, int ny, double alpha, int nscales, double zfactor, int warps,
                      double TOL, int maxiter, int verbose);
 
+/* classic Horn-Schunck (replace src/horn_schunck.h:7-8, src/horn_schunck_classic.cpp:125-149): niter Jacobi
+ * iterations from a zero flow; a / b are the two images, w x h */
+int ofx_hs_classic(ofx_ctx *ctx, const double *a, const double *b, double *u, double *v, int w, int h, int niter,
+                   double alpha);
+
 /* ---- Brox spatial (replace src/brox_optic_flow.h:19-33) ---------------------------------------*/
 int ofx_brox_spatial(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v,
                      int nxx, int nyy, double alpha, double gamma, int nscales, double nu,

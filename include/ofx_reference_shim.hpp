@@ -81,6 +81,11 @@ void horn_schunck_pyramidal(const ofpix_t *I1, const ofpix_t *I2, ofpix_t *u, of
     ofx_shim::check(ofx_hs_pyramidal(ofx_shim::ctx(), I1, I2, u, v, nx, ny, alpha, nscales, zfactor, warps, TOL, maxiter, verbose));
 }
 
+void hs(ofpix_t *u, ofpix_t *v, ofpix_t *a, ofpix_t *b, int w, int h, int n, double alpha)      // src/horn_schunck.h:7-8
+{
+    ofx_shim::check(ofx_hs_classic(ofx_shim::ctx(), a, b, u, v, w, h, n, alpha));
+}
+
 // ---- src/brox_optic_flow.h:19-55 --------------------------------------------------------------------------------
 void brox_optic_flow_spatial(const ofpix_t *I1, const ofpix_t *I2, ofpix_t *u, ofpix_t *v, const int nxx, const int nyy,
                              const double alpha, const double gamma, const int nscales, const double nu, const double TOL,

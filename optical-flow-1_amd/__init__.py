@@ -112,6 +112,7 @@ def lib():
         "ofx_hs_single_scale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _i]),
         "ofx_hs_pyramidal": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _d, _i, _i]),
         "ofx_brox_spatial": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
+        "ofx_hs_classic": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _d]),
         "ofx_brox_temporal": (_i, [_vp, _dp, _dp, _dp, _i, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
     }
     L.ofx_missing = []
@@ -359,3 +360,9 @@ class Ofx:
         a, b = _d(), _d()
         self._ck(self.L.ofx_getminmax(self.h, _f64(x), x.size, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def hs_classic(self, a, b, niter, alpha):
+        h, w = a.shape
+        u, v = np.zeros((h, w)), np.zeros((h, w))
+        self._ck(self.L.ofx_hs_classic(self.h, _f64(a), _f64(b), u, v, w, h, niter, alpha))
+        return u, v

@@ -1486,3 +1486,105 @@ extern "C" int ofx_brox_temporal(ofx_ctx *ctx, const double *I, double *u, doubl
     ctx->stats.total_ms = ofx_now_ms() - t0;
     return s;
 }
+
+
+// ============================================================================================
+// Classic Horn-Schunck: src/horn_schunck_classic.cpp -- n Jacobi iterations from a zero flow
+// ============================================================================================
+// Jacobi, so exactly parallel: one launch per iteration on ping-pong (u, v) pairs.  Per pixel and iteration:
+// read (Ex, Ey) + Et (3 T) and the 3x3 neighbourhood of (u, v) (2 T compulsory), write (u, v) (2 T) = 7 T = 56 B
+// in f64 -- HBM-bound.  Sample p(x, i, j) = column i, row j with clamped indices (:22-43).
+template <typename T> OFX_DEV double hsc_p(const T *x, int w, int h, int i, int j)
+{
+    i = i < 0 ? 0 : (i >= w ? w - 1 : i);
+    j = j < 0 ? 0 : (j >= h ? h - 1 : j);
+    return ldw(x + (size_t) j * w + i);
+}
+
+// compute_input_derivatives, :46-73 (every sum in the reference's left-to-right order)
+template <typename T>
+__global__ void k_hsc_derivs(const T *__restrict__ a, const T *__restrict__ b, typename Pix<T>::v2 *__restrict__ E,
+                             T *__restrict__ Et, int w, int h)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= w || j >= h) return;
+    const double a00 = hsc_p(a, w, h, i, j), a10 = hsc_p(a, w, h, i + 1, j), a01 = hsc_p(a, w, h, i, j + 1),
+                 a11 = hsc_p(a, w, h, i + 1, j + 1);
+    const double b00 = hsc_p(b, w, h, i, j), b10 = hsc_p(b, w, h, i + 1, j), b01 = hsc_p(b, w, h, i, j + 1),
+                 b11 = hsc_p(b, w, h, i + 1, j + 1);
+    const double ey = (1.0 / 4) * (a01 - a00 + a11 - a10 + b01 - b00 + b11 - b10);
+    const double ex = (1.0 / 4) * (a10 - a00 + a11 - a01 + b10 - b00 + b11 - b01);
+    const double et = (1.0 / 4) * (b00 - a00 + b10 - a10 + b01 - a01 + b11 - a11);
+    const size_t p = (size_t) j * w + i;
+    stn2(E + p, make_double2(ex, ey));
+    stn(Et + p, et);
+}
+
+// compute_bar + hs_iteration, :76-122
+template <typename T>
+__global__ __launch_bounds__(256) void k_hsc_iter(const typename Pix<T>::v2 *__restrict__ Uin,
+                                                  typename Pix<T>::v2 *__restrict__ Uout,
+                                                  const typename Pix<T>::v2 *__restrict__ E, const T *__restrict__ Et, int w,
+                                                  int h, double alpha)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= w || j >= h) return;
+    const int il = i > 0 ? i - 1 : 0, ir = i < w - 1 ? i + 1 : w - 1;
+    const unsigned rc = (unsigned) j * w, ru = (unsigned) (j > 0 ? j - 1 : 0) * w, rd = (unsigned) (j < h - 1 ? j + 1 : h - 1) * w;
+    const double2 l = ldw2(Uin + rc + il), r = ldw2(Uin + rc + ir), t = ldw2(Uin + ru + i), d = ldw2(Uin + rd + i);
+    const double2 tl = ldw2(Uin + ru + il), tr = ldw2(Uin + ru + ir), dl = ldw2(Uin + rd + il), dr = ldw2(Uin + rd + ir);
+    const double ubar = (1.0 / 6) * (l.x + r.x + t.x + d.x) + (1.0 / 12) * (tl.x + tr.x + dl.x + dr.x);
+    const double vbar = (1.0 / 6) * (l.y + r.y + t.y + d.y) + (1.0 / 12) * (tl.y + tr.y + dl.y + dr.y);
+    const double2 e = ldw2(E + rc + i);
+    const double et = ldw(Et + rc + i);
+    double tt = e.x * ubar + e.y * vbar + et;
+    tt /= alpha * alpha + e.x * e.x + e.y * e.y;
+    stn2(Uout + rc + i, make_double2(rnd_to<T>(ubar - e.x * tt), rnd_to<T>(vbar - e.y * tt)));
+}
+
+template <typename T>
+static int hs_classic_host(ofx_ctx *ctx, const double *a, const double *b, double *u, double *v, int w, int h, int niter,
+                           double alpha)
+{
+    const size_t n = (size_t) w * h;
+    T *da, *db, *Et;
+    typename Pix<T>::v2 *U[2], *E;
+    OFX_TRY(upload_plane<T>(ctx, a, n, &da));
+    OFX_TRY(upload_plane<T>(ctx, b, n, &db));
+    OFX_TRY(ofx_alloc(ctx, n, &U[0]));
+    OFX_TRY(ofx_alloc(ctx, n, &U[1]));
+    OFX_TRY(ofx_alloc(ctx, n, &E));
+    OFX_TRY(ofx_alloc(ctx, n, &Et));
+    hipLaunchKernelGGL(k_hsc_derivs<T>, g2d(w, h), b2d(), 0, ctx->stream, (const T *) da, (const T *) db, E, Et, w, h);
+    OFX_LAUNCH_CHECK(ctx);
+    OFX_TRY(op_fill2<T>(ctx, U[0], n));                                                            // :139-141
+    int cur = 0;
+    for (int it = 0; it < niter; it++) {                                                           // :142-144
+        hipLaunchKernelGGL(k_hsc_iter<T>, g2d(w, h), b2d(), 0, ctx->stream, U[cur], U[cur ^ 1], E, (const T *) Et, w, h,
+                           alpha);
+        cur ^= 1;
+    }
+    OFX_LAUNCH_CHECK(ctx);
+    sor_stats_begin(ctx, 1, 1);
+    ctx->stats.nx[0] = w;
+    ctx->stats.ny[0] = h;
+    ctx->stats.iters[0][0] = niter;
+    ctx->stats.work_pix_iters = (double) niter * n;
+    return download_flow<T>(ctx, U[cur], u, v, n);
+}
+
+extern "C" int ofx_hs_classic(ofx_ctx *ctx, const double *a, const double *b, double *u, double *v, int w, int h, int niter,
+                              double alpha)
+{
+    OFX_ENTER(ctx);
+    if (!a || !b || !u || !v) return ofx_fail(ctx, OFX_ERR_ARG, "hs_classic: NULL pointer");
+    if (w < 1 || h < 1 || (long long) w * h >= (1LL << 28)) return ofx_fail(ctx, OFX_ERR_ARG, "hs_classic: bad size %dx%d", w, h);
+    if (niter < 0) niter = 0;                                   // the reference's loop simply does not run
+    const double t0 = ofx_now_ms();
+    int s = ctx->precision == OFX_F64 ? hs_classic_host<double>(ctx, a, b, u, v, w, h, niter, alpha)
+                                      : hs_classic_host<float>(ctx, a, b, u, v, w, h, niter, alpha);
+    ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}

@@ -153,6 +153,13 @@ class _Lib:
         self._fn("getminmax", None, C.POINTER(C.c_double), C.POINTER(C.c_double), _dp, C.c_int)(C.byref(a), C.byref(b), _f64(x), x.size)
         return a.value, b.value
 
+    def hs_classic(self, a, b, niter, alpha):
+        """src/horn_schunck_classic.cpp hs(): niter Jacobi iterations from a zero flow"""
+        h, w = a.shape
+        u, v = np.zeros((h, w)), np.zeros((h, w))
+        self._fn("hs_classic", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double)(u, v, _f64(a), _f64(b), w, h, niter, alpha)
+        return u, v
+
     def image_normalization_1(self, I):
         out = np.empty(I.shape)
         self._fn("image_normalization_1", None, _dp, _dp, C.c_int)(_f64(I), out, I.size)

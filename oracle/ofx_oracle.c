@@ -1440,3 +1440,53 @@ void orc_getminmax(double *mn, double *mx, const double *x, int n)
         if (x[i] > *mx) *mx = x[i];
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Classic Horn-Schunck, src/horn_schunck_classic.cpp: n Jacobi iterations from a zero flow.  p(x, i, j) is the
+ * sample at column i, row j with clamped (Neumann) indices (:22-43). */
+static inline double hsc_p(const double *x, int w, int h, int i, int j)
+{
+    if (i < 0) i = 0;
+    if (j < 0) j = 0;
+    if (i >= w) i = w - 1;
+    if (j >= h) j = h - 1;
+    return x[j * w + i];
+}
+
+void orc_hs_classic(double *u, double *v, const double *a, const double *b, int w, int h, int n, double alpha)
+{
+    const size_t sz = (size_t) w * h;
+    double *Ex = dalloc(sz), *Ey = dalloc(sz), *Et = dalloc(sz), *ubar = dalloc(sz), *vbar = dalloc(sz);
+    for (int j = 0; j < h; j++)                                                       /* :46-73 */
+        for (int i = 0; i < w; i++) {
+            Ey[j * w + i] = (1.0 / 4) * (hsc_p(a, w, h, i, j + 1) - hsc_p(a, w, h, i, j) + hsc_p(a, w, h, i + 1, j + 1) -
+                                         hsc_p(a, w, h, i + 1, j) + hsc_p(b, w, h, i, j + 1) - hsc_p(b, w, h, i, j) +
+                                         hsc_p(b, w, h, i + 1, j + 1) - hsc_p(b, w, h, i + 1, j));
+            Ex[j * w + i] = (1.0 / 4) * (hsc_p(a, w, h, i + 1, j) - hsc_p(a, w, h, i, j) + hsc_p(a, w, h, i + 1, j + 1) -
+                                         hsc_p(a, w, h, i, j + 1) + hsc_p(b, w, h, i + 1, j) - hsc_p(b, w, h, i, j) +
+                                         hsc_p(b, w, h, i + 1, j + 1) - hsc_p(b, w, h, i, j + 1));
+            Et[j * w + i] = (1.0 / 4) * (hsc_p(b, w, h, i, j) - hsc_p(a, w, h, i, j) + hsc_p(b, w, h, i + 1, j) -
+                                         hsc_p(a, w, h, i + 1, j) + hsc_p(b, w, h, i, j + 1) - hsc_p(a, w, h, i, j + 1) +
+                                         hsc_p(b, w, h, i + 1, j + 1) - hsc_p(a, w, h, i + 1, j + 1));
+        }
+    for (size_t i = 0; i < sz; i++) u[i] = v[i] = 0;                                  /* :139-141 */
+    for (int it = 0; it < n; it++) {                                                  /* hs_iteration :97-122 */
+        for (int pass = 0; pass < 2; pass++) {                                        /* compute_bar :76-94 */
+            const double *x = pass ? v : u;
+            double *bar = pass ? vbar : ubar;
+            for (int j = 0; j < h; j++)
+                for (int i = 0; i < w; i++)
+                    bar[j * w + i] = (1.0 / 6) * (hsc_p(x, w, h, i - 1, j) + hsc_p(x, w, h, i + 1, j) + hsc_p(x, w, h, i, j - 1) +
+                                                  hsc_p(x, w, h, i, j + 1)) +
+                                     (1.0 / 12) * (hsc_p(x, w, h, i - 1, j - 1) + hsc_p(x, w, h, i + 1, j - 1) +
+                                                   hsc_p(x, w, h, i - 1, j + 1) + hsc_p(x, w, h, i + 1, j + 1));
+        }
+        for (size_t i = 0; i < sz; i++) {
+            double t = Ex[i] * ubar[i] + Ey[i] * vbar[i] + Et[i];
+            t /= alpha * alpha + Ex[i] * Ex[i] + Ey[i] * Ey[i];
+            u[i] = ubar[i] - Ex[i] * t;
+            v[i] = vbar[i] - Ey[i] * t;
+        }
+    }
+    free(Ex); free(Ey); free(Et); free(ubar); free(vbar);
+}

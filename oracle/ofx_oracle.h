@@ -87,6 +87,8 @@ void orc_image_normalization_1(const double *I, double *In, int size);
 int  orc_brox_temporal(const double *I, double *u, double *v, int nx, int ny, int frames, double alpha, double gamma,
                        int nscales, double nu, double TOL, int inner_iter, int outer_iter, int verbose, int *iters);
 
+/* horn_schunck_classic.cpp */
+void orc_hs_classic(double *u, double *v, const double *a, const double *b, int w, int h, int n, double alpha);
 double orc_bicubic_at_color(const double *in, double uu, double vv, int nx, int ny, int nz, int k, int border_out);
 void orc_getminmax(double *mn, double *mx, const double *x, int n);
 

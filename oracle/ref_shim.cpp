@@ -155,4 +155,7 @@ double ref_bicubic_at_color(const double *in, double uu, double vv, int nx, int 
 
 void ref_getminmax(double *mn, double *mx, const double *x, int n) { getminmax(mn, mx, x, n); }
 
+void ref_hs_classic(double *u, double *v, const double *a, const double *b, int w, int h, int n, double alpha)
+{ hs(u, v, const_cast<double *>(a), const_cast<double *>(b), w, h, n, alpha); }
+
 } // extern "C"

@@ -59,6 +59,8 @@ int main(int argc, char **argv)
         put(fo, u); put(fo, v);
         brox_optic_flow_spatial(I0, I1, u.data(), v.data(), nx, ny, 50.0, 10.0, 3, 0.5, 1e-4, 1, 4, false);
         put(fo, u); put(fo, v);
+        hs(u.data(), v.data(), I0, I1, nx, ny, 25, 15.0);
+        put(fo, u); put(fo, v);
         std::vector<ofpix_t> us((size_t) n * (frames - 1)), vs((size_t) n * (frames - 1));
         brox_optic_flow_temporal(I.data(), us.data(), vs.data(), nx, ny, frames, 18.0, 7.0, 2, 0.75, 1e-4, 1, 3, false);
         put(fo, us); put(fo, vs);

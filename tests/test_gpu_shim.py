@@ -56,6 +56,8 @@ def test_reference_prototypes_through_the_shim(orc, synth, tmp_path):
     assert np.abs(take(S) - uo).max() < 1e-12 and np.abs(take(S) - vo).max() < 1e-12
     uo, vo, _ = orc.brox_spatial(I0, I1, alpha=50.0, gamma=10.0, nscales=3, nu=0.5, TOL=1e-4, inner=1, outer=4)
     assert np.abs(take(S) - uo).max() < 1e-11 and np.abs(take(S) - vo).max() < 1e-11
+    uo, vo = orc.hs_classic(I0, I1, 25, 15.0)
+    assert np.array_equal(take(S), uo) and np.array_equal(take(S), vo)
     uo, vo, _ = orc.brox_temporal(seq, alpha=18.0, gamma=7.0, nscales=2, nu=0.75, TOL=1e-4, inner=1, outer=3)
     T = (frames - 1, ny, nx)
     assert np.abs(take(T) - uo).max() < 1e-11 and np.abs(take(T) - vo).max() < 1e-11
