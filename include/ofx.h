@@ -92,6 +92,7 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *   "sor_window"     time steps per launch of sor_exact = 1 (default 8)
  *   "sor_rows"       rows per workgroup (row block of a sweep) of sor_exact = 1 (default 64)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
+ *   "warp_lds"       1/0  TV-L1 warp with the bicubic taps staged through LDS (default 1)
  *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default: up to 4, fewer for small batches; at most 16)
  *   "concurrency"    number of contexts that will be solving on the same device at the same time
  *                         (default 1); a scheduling hint for the strip height of the TV-L1 kernels

@@ -63,6 +63,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->fuse2 = 1;             // two TV-L1 iterations per launch
     ctx->concurrency = 1;
     ctx->lockstep = 0;
+    ctx->warp_lds = 1;
     ctx->chunk = 0;             // 0 = pick per level
     ctx->fixed_work = 0;
     ctx->sor_exact = 1;
@@ -136,6 +137,7 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
         ctx->concurrency = (int) value;
         return OFX_OK;
     }
+    if (!strcmp(name, "warp_lds")) { ctx->warp_lds = value != 0; return OFX_OK; }
     if (!strcmp(name, "lockstep")) {
         if (value < 0 || value > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "lockstep out of range");
         ctx->lockstep = (int) value;

@@ -54,6 +54,7 @@ struct ofx_ctx {
     int fuse2;
     int concurrency;    // contexts expected to share the device (tuning hint, default 1)
     int lockstep;       // pairs per lockstep group in ofx_tvl1_batch_dev (0 = default)
+    int warp_lds;       // 1 (default): TV-L1 warp with the taps staged through LDS; 0: gathered from global memory
     int chunk;
     int fixed_work;
     int sor_exact;      // 1: reference sweep order, windowed launches; 2: same, one launch per time step; 0: colour order

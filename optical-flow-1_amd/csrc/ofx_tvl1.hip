@@ -459,6 +459,97 @@ __global__ void k_tvl1_warp(const typename Pix<T>::v2 *__restrict__ pag, const T
     stn(R + p, (I1w - I1wx * u.x - I1wy * u.y - ldw(I0 + p)));       // :107-108
 }
 
+// The same warp with the taps staged through LDS.  k_tvl1_warp's time follows the bytes it gathers through the
+// vector L1 (16 taps x 24 B = 384 B per pixel, 8.5x the unique data of a block).  Here a block of 32 x 8 pixels first
+// finds the bounding box of its taps -- a computed sample has the clean block rows y-1 .. y+2, columns x-1 .. x+2
+// (bicubic_sample3) --, loads that box of the (I1, I1x) and I1y planes ONCE with coalesced row loads into LDS and
+// gathers from there (LDS: 128 B/clk/CU, consecutive lanes -> consecutive columns, conflict-free).  A block whose box
+// does not fit the tile (a motion boundary with a large jump) takes the global-gather path; same arithmetic either
+// way, bit-identical results.
+#define WARP_TW 48          // tile columns
+#define WARP_TH 24          // tile rows
+template <typename T>
+__global__ __launch_bounds__(256) void k_tvl1_warp_lds(
+    const typename Pix<T>::v2 *__restrict__ pag, const T *__restrict__ pbg, const T *__restrict__ I0g,
+    const typename Pix<T>::v2 *__restrict__ U0, const typename Pix<T>::v2 *__restrict__ U1,
+    typename Pix<T>::v2 *__restrict__ Ag, T *__restrict__ Rg, int nx, int ny, unsigned curmask)
+{
+    __shared__ double2 s_a[WARP_TH * WARP_TW];
+    __shared__ double s_b[WARP_TH * WARP_TW];
+    __shared__ int s_box[4][4];                               // per wave: xmin, xmax, ymin, ymax
+    const int tid = threadIdx.y * 32 + threadIdx.x, wave = tid >> 6;
+    const int j = blockIdx.x * 32 + threadIdx.x;
+    const int i = blockIdx.y * 8 + threadIdx.y;
+    const bool inside = (j < nx) && (i < ny);
+    const int g = blockIdx.z;
+    const size_t goff = (size_t) g * nx * ny;
+    const typename Pix<T>::v2 *__restrict__ pa = pag + goff;
+    const T *__restrict__ pb = pbg + goff;
+    const typename Pix<T>::v2 *__restrict__ U = (((curmask >> g) & 1u) ? U1 : U0) + goff;
+    const size_t p = (size_t) (inside ? i : 0) * nx + (inside ? j : 0);
+    double2 u = make_double2(0.0, 0.0);
+    BicubicTaps t;
+    t.out = true;
+    if (inside) {
+        u = ldw2(U + p);
+        t = bicubic_taps(j + u.x, i + u.y, nx, ny);
+    }
+    const bool need = inside && !t.out;
+    // bounding box of the taps of the block
+    int xlo = need ? t.col[0] : 0x7fffffff, xhi = need ? t.col[3] : -1;
+    int ylo = need ? t.row[0] : 0x7fffffff, yhi = need ? t.row[3] : -1;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        xlo = min(xlo, __shfl_xor(xlo, m, 64)); xhi = max(xhi, __shfl_xor(xhi, m, 64));
+        ylo = min(ylo, __shfl_xor(ylo, m, 64)); yhi = max(yhi, __shfl_xor(yhi, m, 64));
+    }
+    if ((tid & 63) == 0) { s_box[wave][0] = xlo; s_box[wave][1] = xhi; s_box[wave][2] = ylo; s_box[wave][3] = yhi; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        xlo = min(xlo, s_box[w][0]); xhi = max(xhi, s_box[w][1]);
+        ylo = min(ylo, s_box[w][2]); yhi = max(yhi, s_box[w][3]);
+    }
+    const int W = xhi - xlo + 1, H = yhi - ylo + 1;
+    const bool any = (xhi >= 0);
+    const bool tile = any && W <= WARP_TW && H <= WARP_TH;    // block-uniform
+    if (tile) {
+        for (int k = tid; k < W * H; k += 256) {
+            const int r = k / W, c = k - r * W;
+            const size_t src = (size_t) (ylo + r) * nx + (xlo + c);
+            s_a[r * WARP_TW + c] = ldw2(pa + src);
+            s_b[r * WARP_TW + c] = ldw(pb + src);
+        }
+        __syncthreads();
+    }
+    if (!inside) return;
+    double I1w = 0.0, I1wx = 0.0, I1wy = 0.0;
+    if (need) {
+        if (tile) {
+            const int cx = t.col[0] - xlo, cy = t.row[0] - ylo;
+            double c0[4], c1[4], c2[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int o = cy * WARP_TW + cx + k;
+                const double2 a0 = s_a[o], a1 = s_a[o + WARP_TW], a2 = s_a[o + 2 * WARP_TW], a3 = s_a[o + 3 * WARP_TW];
+                const double b0 = s_b[o], b1 = s_b[o + WARP_TW], b2 = s_b[o + 2 * WARP_TW], b3 = s_b[o + 3 * WARP_TW];
+                c0[k] = cubic_cell(a0.x, a1.x, a2.x, a3.x, t.fy);
+                c1[k] = cubic_cell(a0.y, a1.y, a2.y, a3.y, t.fy);
+                c2[k] = cubic_cell(b0, b1, b2, b3, t.fy);
+            }
+            I1w = cubic_cell(c0[0], c0[1], c0[2], c0[3], t.fx);
+            I1wx = cubic_cell(c1[0], c1[1], c1[2], c1[3], t.fx);
+            I1wy = cubic_cell(c2[0], c2[1], c2[2], c2[3], t.fx);
+        } else {
+            bicubic_sample3(pa, pb, t, nx, I1w, I1wx, I1wy);
+        }
+        I1wx = rnd_to<T>(I1wx);
+        I1wy = rnd_to<T>(I1wy);
+    }
+    stn2(Ag + goff + p, make_double2(I1wx, I1wy));
+    stn(Rg + goff + p, (I1w - I1wx * u.x - I1wy * u.y - ldw(I0g + goff + p)));       // :107-108
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 // One level of a lockstep group: every array holds G pairs back to back (pair g at element g * nx * ny).
 template <typename T> struct Tvl1Level {
@@ -658,8 +749,12 @@ static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params
     }
 
     for (int w = 0; w < P.warps; w++) {
-        hipLaunchKernelGGL(k_tvl1_warp<T>, g2, b2, 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I0, L.U[0], L.U[1],
-                           L.A, L.R, nx, ny, L.cur);                                                               // :94-109
+        if (ctx->warp_lds)
+            hipLaunchKernelGGL(k_tvl1_warp_lds<T>, dim3(ofx_cdiv(nx, 32), ofx_cdiv(ny, 8), G), dim3(32, 8), 0, ctx->stream, L.pa,
+                               (const T *) L.pb, (const T *) L.I0, L.U[0], L.U[1], L.A, L.R, nx, ny, L.cur);
+        else
+            hipLaunchKernelGGL(k_tvl1_warp<T>, g2, b2, 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I0, L.U[0],
+                               L.U[1], L.A, L.R, nx, ny, L.cur);                                                   // :94-109
         OFX_LAUNCH_CHECK(ctx);
         // p lives in the same ping-pong half as u
         int it[OFX_MAX_GROUP];

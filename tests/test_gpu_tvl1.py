@@ -264,3 +264,25 @@ def test_f32_mode_is_as_accurate_as_the_reference_own_float_build(gpu32, oracle_
         ug, vg = gpu32.hs_pyramidal(I0, I1, alpha=20.0, nscales=4, warps=5)
         ref_drift, gpu_drift = aepe(a, b, u, v), aepe(ug, vg, u, v)
         assert gpu_drift < 1e-3 and gpu_drift < 30 * ref_drift + 1e-5, (pair, gpu_drift, ref_drift)
+
+
+@pytest.mark.parametrize("amp", [0.5, 6.0, 40.0])
+def test_warp_tile_and_gather_paths_agree(gpu64, orc, synth, amp):
+    """the LDS-staged warp (block bounding box of the taps fits the tile) and the global-gather path (it does not:
+    amp = 40 scatters the samples of a block over +-40 pixels) compute the same bits; both against the oracle"""
+    nx, ny = 200, 150
+    I0, I1 = synth.pair("P1", nx, ny)
+    rng = np.random.default_rng(7)
+    u0 = rng.uniform(-amp, amp, (ny, nx))
+    v0 = rng.uniform(-amp, amp, (ny, nx))
+    uo, vo, it_o, _ = orc.tvl1_single_scale(I0, I1, u0, v0, warps=2, **PAR)
+    res = {}
+    for lds in (1, 0):
+        gpu64.set_option("warp_lds", lds)
+        try:
+            res[lds] = gpu64.tvl1_single_scale(I0, I1, u0, v0, warps=2, **PAR)
+            assert list(gpu64.stats().iterations()[0]) == list(it_o)
+        finally:
+            gpu64.set_option("warp_lds", 1)
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1])
+    assert np.abs(res[1][0] - uo).max() < 1e-9 and np.abs(res[1][1] - vo).max() < 1e-9
