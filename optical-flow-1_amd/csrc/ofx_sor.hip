@@ -278,7 +278,7 @@ __global__ __launch_bounds__(1024) void k_hs_window(typename Pix<T>::v2 *U, type
 // lag_f = K steps behind frame o - 1 and the sweeps move lag_f (nz - 1) further apart.
 template <class WindowFn, class TakeFn>
 static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxiter, int qmax, int C, int batch,
-                           WindowFn launch, TakeFn take, int *n_out, double *err_out, int nz = 1)
+                           WindowFn launch, TakeFn take, int *n_out, double *err_out, int nz = 1, int *hint = nullptr)
 {
     int niter = 0;
     double error = 1000;
@@ -299,8 +299,20 @@ static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxit
     LS.chunk = 0;
     LS.fixed = false;
     LS.pairs = false;
+    // Every sweep of a batch costs lag_s steps of pipeline whether it is needed or not, so batches are sized, not
+    // maximal (`batch` is the snapshot capacity): the first one from the sweep count of the previous solve at this level
+    // (*hint; consecutive warps / outer iterations converge in similar, usually decreasing, numbers of sweeps) with
+    // 25 % + 2 of head room, 32 without a hint; a solve that needs more runs further, half-sized batches.
+    int first = batch < 32 ? batch : 32;
+    if (ctx->sor_batch > 0) first = batch;                       // explicit option: fixed batches
+    else if (hint && *hint > 0) {
+        first = *hint + *hint / 4 + 2;
+        first = first < 8 ? 8 : (first > batch ? batch : first);
+    }
+    const int later = ctx->sor_batch > 0 ? batch : (first / 2 < 8 ? (batch < 8 ? batch : 8) : first / 2);
     while (error > TOL && niter < maxiter) {
-        const int ns = (maxiter - niter < batch) ? maxiter - niter : batch;
+        const int want = niter == 0 ? first : later;
+        const int ns = (maxiter - niter < want) ? maxiter - niter : want;
         OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) ns * OFX_NSHARD, ctx->stream));
         OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
         const long tail = (long) w.lag_b * (B - 1) + (long) w.lag_f * (nz - 1);   // the last unit of a sweep ends this much later
@@ -325,6 +337,7 @@ static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxit
         niter += st.n;
         error = st.error;
     }
+    if (hint) *hint = niter;
     *n_out = niter;
     *err_out = error;
     return OFX_OK;
@@ -389,10 +402,11 @@ static int sor_exact_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int q
     return OFX_OK;
 }
 
-// sweeps per batch of the windowed mode: option "sor_batch", else 32, capped by maxiter and by ~4 GiB of snapshots
+// snapshot capacity (= most sweeps in one batch) of the windowed mode: option "sor_batch", else 64, capped by maxiter
+// and by ~4 GiB of snapshots
 static int sor_pick_batch(const ofx_ctx *ctx, size_t npix, size_t elem_bytes, int maxiter)
 {
-    int b = ctx->sor_batch > 0 ? ctx->sor_batch : 32;
+    int b = ctx->sor_batch > 0 ? ctx->sor_batch : 64;
     const size_t cap = (size_t) 4 << 30;
     while (b > 1 && (size_t) b * npix * elem_bytes > cap) b /= 2;
     if (b > maxiter) b = maxiter;
@@ -413,6 +427,7 @@ template <typename T> struct HsLevel {
     T *Dif;
     typename Pix<T>::v2 *Snap;  // windowed exact mode: one snapshot plane per sweep of a batch (allocated on first use)
     int snap_planes;
+    int sweep_hint;             // sweeps of the previous solve at this level (sizes the next first batch)
 };
 
 template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int nx, int ny)
@@ -428,6 +443,7 @@ template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int
     OFX_TRY(ofx_alloc(ctx, n, &L.Dif));
     L.Snap = nullptr;
     L.snap_planes = 0;
+    L.sweep_hint = 0;
     return OFX_OK;
 }
 
@@ -474,7 +490,7 @@ template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L
                 return OFX_OK;
             };
             OFX_TRY(sor_window_loop(ctx, nx * ny, ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, batch, window, take,
-                                    &niter, &error));
+                                    &niter, &error, 1, &L.sweep_hint));
         } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
             // one launch per time step (option sor_exact = 2): the reference implementation of the exact schedule
             const size_t ub = (size_t) nx * ny * sizeof(typename Pix<T>::v2);
@@ -988,6 +1004,7 @@ template <typename T> struct BroxLevel {
     v4 *PA, *WA, *CO;
     v2 *Snap;           // windowed exact mode: one snapshot plane of (du, dv) per sweep of a batch
     int snap_planes;
+    int sweep_hint;
 };
 
 template <typename T> static int brox_level_alloc(ofx_ctx *ctx, BroxLevel<T> &L, int nx, int ny)
@@ -1010,6 +1027,7 @@ template <typename T> static int brox_level_alloc(ofx_ctx *ctx, BroxLevel<T> &L,
     OFX_TRY(ofx_alloc(ctx, n, &L.CO));
     L.Snap = nullptr;
     L.snap_planes = 0;
+    L.sweep_hint = 0;
     return OFX_OK;
 }
 
@@ -1060,7 +1078,7 @@ template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T
                     return OFX_OK;
                 };
                 OFX_TRY(sor_window_loop(ctx, n, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
-                                        take, &nsor, &error));
+                                        take, &nsor, &error, 1, &L.sweep_hint));
             } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
                 const size_t ub = (size_t) n * sizeof(typename Pix<T>::v2);
                 const unsigned gpx = ofx_cdiv(ny + 3, 64);
@@ -1333,7 +1351,7 @@ template <typename T> struct BroxtLevel {
     T *Psis, *Dd, *Dm;          // nz * n each
     v2 *G1, *PB, *WB, *U, *DV, *DU, *Snap;
     v4 *PA, *WA, *CO;
-    int snap_planes;
+    int snap_planes, sweep_hint;
 };
 
 template <typename T> static int broxt_level_alloc(ofx_ctx *ctx, BroxtLevel<T> &L, int nx, int ny, int frames)
@@ -1356,6 +1374,7 @@ template <typename T> static int broxt_level_alloc(ofx_ctx *ctx, BroxtLevel<T> &
     OFX_TRY(ofx_alloc(ctx, n1, &L.CO));
     L.Snap = nullptr;
     L.snap_planes = 0;
+    L.sweep_hint = 0;
     return OFX_OK;
 }
 
@@ -1409,7 +1428,7 @@ static int broxt_single_scale_dev(ofx_ctx *ctx, BroxtLevel<T> &L, const BroxPara
                 return OFX_OK;
             };
             OFX_TRY(sor_window_loop(ctx, (int) n1, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
-                                    take, &nsor, &error, nz));                                       // :430-461
+                                    take, &nsor, &error, nz, &L.sweep_hint));                                       // :430-461
             if (P.verbose) { printf("Iterations: %d\n", nsor); fflush(stdout); }                     // :463-465
             if (scale < OFX_MAX_SCALES) {
                 if (solve < OFX_MAX_SOLVES) { S.iters[scale][solve] = nsor; S.error[scale][solve] = error; }
