@@ -158,11 +158,9 @@ def main():
     prec = ofx_mod.F64 if a.precision == "f64" else ofx_mod.F32
     tdt = torch.float64 if a.precision == "f64" else torch.float32
     nstreams = max(1, min(a.streams, max(a.steps, 1)))
-    lockstep = a.lockstep if a.lockstep > 0 else max(1, min(4, -(-max(a.steps, 1) // nstreams)))   # the library's rule
-    lockstep = min(lockstep, 16)
-    in_flight = nstreams * lockstep
     ctxs = [ofx_mod.Ofx(local, prec) for _ in range(nstreams)]
     ctx = ctxs[0]
+    nx, ny = a.nx, a.ny
     for c_ in ctxs:
         c_.set_option("concurrency", a.concurrency or nstreams)
         c_.set_option("lockstep", a.lockstep if a.lockstep > 0 else 0)
@@ -172,8 +170,13 @@ def main():
             c_.set_option("chunk", a.chunk)
         if a.rows2:
             c_.set_option("rows_per_wave2", a.rows2)
+    # group size: --lockstep, or what the library picks for a batch of `steps` pairs on these contexts; pinned
+    # for the whole run so that warmup, timed region and fixed-work pass all use the same grouping
+    lockstep = ofx_mod.tvl1_batch_group_size(ctxs, max(a.steps, 1), nx, ny, PAR["nscales"], PAR["zfactor"])
+    for c_ in ctxs:
+        c_.set_option("lockstep", lockstep)
+    in_flight = nstreams * lockstep
 
-    nx, ny = a.nx, a.ny
     # a short synthetic sequence: `variants` distinct pairs (SURVEY 8d batch variants), resident in HBM; step i of
     # rank r solves variant (r * steps + i) % variants, so the pairs of a lockstep group converge differently
     nvar = max(1, a.variants)

@@ -93,7 +93,8 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *   "sor_rows"       rows per workgroup (row block of a sweep) of sor_exact = 1 (default 64)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
  *   "warp_lds"       1/0  TV-L1 warp with the bicubic taps staged through LDS (default 1)
- *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default: up to 4, fewer for small batches; at most 16)
+ *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default 0 = ofx_tvl1_batch_group_size's
+ *                         rule: as large as possible, evened out over the contexts; at most 16)
  *   "concurrency"    number of contexts that will be solving on the same device at the same time
  *                         (default 1); a scheduling hint for the strip height of the TV-L1 kernels
  *   "rows_per_wave", "rows_per_wave2", "chunk"   tuning of the TV-L1 kernels / launch batching */
@@ -168,7 +169,7 @@ int ofx_tvl1_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *dI0, const 
                        int nscales, double zfactor, int warps, double epsilon, ofx_stats *stats_out);
 
 /* Batch of independent pairs on ONE device (the unit of parallel work is the image pair).
- * The pairs are cut into lockstep groups of `lockstep` consecutive pairs (option of ctxs[0]; default: up to 4, fewer when the batch is small);
+ * The pairs are cut into lockstep groups of ofx_tvl1_batch_group_size() consecutive pairs;
  * group q is solved on context ctxs[q % n_ctx] with ofx_tvl1_group_dev, one host thread per context, so
  * n_ctx groups are in flight at a time (each context = its own HIP stream and workspace; all contexts
  * must live on the same device and have the same precision).  Arrays dI0/dI1/d_flo hold n_pairs device
@@ -179,6 +180,12 @@ int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI0, 
                        void *const *d_flo, int n_pairs, int nx, int ny, double tau, double lambda,
                        double theta, int nscales, double zfactor, int warps, double epsilon,
                        double *work_pix_iters);
+
+/* Group size ofx_tvl1_batch_dev picks for this batch: the "lockstep" option of ctxs[0] if > 0, else the batch
+ * is spread over the fewest rounds a group of 16 (less if device memory is short) allows, one group per
+ * context and round, with the groups evened out.  Returns the size (>= 1) or a negative status. */
+int ofx_tvl1_batch_group_size(ofx_ctx *const *ctxs, int n_ctx, int n_pairs, int nx, int ny, int nscales,
+                              double zfactor);
 
 /* Fixed-work inner loop only (src/tvl1flow.cpp:113-182 run exactly n_iter times on linearised
  * data, all arrays host double planes; u/p updated in place).  Returns the last error in *error.

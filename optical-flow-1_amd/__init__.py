@@ -108,6 +108,7 @@ def lib():
                                     C.POINTER(Stats)]),
         "ofx_tvl1_batch_dev": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _d, _d, _d,
                                     _i, _d, _i, _d, C.POINTER(_d)]),
+        "ofx_tvl1_batch_group_size": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _d]),
         "ofx_tvl1_iterations": (_i, [_vp] + [_dp] * 9 + [_i, _i, _d, _d, _d, _i, C.POINTER(_d)]),
         "ofx_hs_single_scale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _i]),
         "ofx_hs_pyramidal": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _d, _i, _i]),
@@ -140,8 +141,8 @@ def _f64(a):
 def tvl1_batch_dev(ctxs, dI0, dI1, d_flo, nx, ny, tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5,
                    epsilon=0.01):
     """ofx_tvl1_batch_dev: lists of device pointers (ints), one entry per pair; the pairs are cut into lockstep
-    groups (option "lockstep" of ctxs[0], default 4), group q runs on ctxs[q % len(ctxs)] with len(ctxs) groups in
-    flight.  Returns the per-pair work (pixel-iterations)."""
+    groups of tvl1_batch_group_size() pairs, group q runs on ctxs[q % len(ctxs)] with len(ctxs) groups in flight.
+    Returns the per-pair work (pixel-iterations)."""
     n = len(dI0)
     arr = lambda xs: (_vp * len(xs))(*xs)
     work = (_d * max(n, 1))()
@@ -150,6 +151,15 @@ def tvl1_batch_dev(ctxs, dI0, dI1, d_flo, nx, ny, tau=0.25, lam=0.15, theta=0.3,
     if s:
         raise OfxError(s, "; ".join((c.L.ofx_last_error(c.h) or b"").decode() for c in ctxs))
     return [work[i] for i in range(n)]
+
+
+def tvl1_batch_group_size(ctxs, n_pairs, nx, ny, nscales=5, zfactor=0.5):
+    """ofx_tvl1_batch_group_size: pairs per lockstep group tvl1_batch_dev uses for a batch of n_pairs."""
+    g = lib().ofx_tvl1_batch_group_size((_vp * len(ctxs))(*[c.h.value for c in ctxs]), len(ctxs), n_pairs, nx, ny, nscales,
+                                        zfactor)
+    if g < 1:
+        raise OfxError(g, "; ".join((c.L.ofx_last_error(c.h) or b"").decode() for c in ctxs))
+    return g
 
 
 class Ofx:

@@ -1050,8 +1050,45 @@ extern "C" int ofx_tvl1_iterations(ofx_ctx *ctx, double *u1, double *u2, double 
     return s;
 }
 
+// Pairs per lockstep group that ofx_tvl1_batch_dev uses for this batch.  The "lockstep" option of ctxs[0] if
+// set; otherwise the batch is spread over as few rounds as the largest allowed group permits (every context
+// gets one group per round) and the groups are evened out: 20 pairs on 4 contexts = 4 groups of 5, not
+// 5 groups of 4 with one context working alone at the end.  Measured on MI355X (1080p f64, 4 contexts):
+// bigger groups keep winning up to the cap (32 pairs: groups of 4 / 8 = 48.9k / 50.6k Mpix*it/s; 64 pairs:
+// 4 / 8 / 16 = 49.5k / 50.8k / 51.2k).  The cap is OFX_MAX_GROUP, lowered so that all contexts' level arrays
+// together stay within half of the device memory that is free now.
+extern "C" int ofx_tvl1_batch_group_size(ofx_ctx *const *ctxs, int n_ctx, int n_pairs, int nx, int ny, int nscales,
+                                         double zfactor)
+{
+    if (!ctxs || n_ctx < 1 || !ctxs[0] || n_pairs < 0 || nx < 1 || ny < 1) return OFX_ERR_ARG;
+    int G = ctxs[0]->lockstep;
+    if (G > 0) return G > OFX_MAX_GROUP ? OFX_MAX_GROUP : G;
+    if (n_pairs <= 1) return 1;
+    int nxs[OFX_MAX_SCALES], nys[OFX_MAX_SCALES];
+    const int st = op_pyramid_sizes(ctxs[0], nx, ny, nscales, zfactor, nxs, nys);
+    if (st != OFX_OK) return st;
+    double px = 0;
+    for (int s = 0; s < nscales; s++) px += (double) nxs[s] * nys[s];
+    const double elem = ctxs[0]->precision == OFX_F32 ? 4.0 : 8.0;
+    const double per_pair = 12.0 * px * elem;                 // tvl1_level_alloc: 12 arrays per level
+    size_t mfree = 0, mtotal = 0;
+    int dev_now = 0;
+    (void) hipGetDevice(&dev_now);
+    (void) hipSetDevice(ctxs[0]->device);
+    const hipError_t e = hipMemGetInfo(&mfree, &mtotal);
+    (void) hipSetDevice(dev_now);
+    int cap = OFX_MAX_GROUP;
+    if (e == hipSuccess) {
+        const double fit = 0.5 * (double) mfree / n_ctx / per_pair;
+        if (fit < cap) cap = fit < 1.0 ? 1 : (int) fit;
+    }
+    const int rounds = (n_pairs + n_ctx * cap - 1) / (n_ctx * cap);
+    G = (n_pairs + n_ctx * rounds - 1) / (n_ctx * rounds);
+    return G < 1 ? 1 : G;
+}
+
 // ---- batch of pairs: lockstep groups, one worker thread per context --------------------------------------
-// The pairs are cut into groups of `lockstep` (option of ctxs[0]; default: up to 4) consecutive pairs; group q is
+// The pairs are cut into groups of ofx_tvl1_batch_group_size() consecutive pairs; group q is
 // solved by context q % n_ctx with ofx_tvl1_group_dev, i.e. its pairs share every launch.  On the small
 // pyramid levels a launch is a latency chain that leaves most of the GPU idle, so G pairs per launch cost
 // the time of one; and the convergence polls (one host round trip per warp) are paid once per group.
@@ -1063,14 +1100,8 @@ extern "C" int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *c
     if (!ctxs || n_ctx < 1 || n_pairs < 0 || !dI0 || !dI1 || !d_flo) return OFX_ERR_ARG;
     for (int w = 0; w < n_ctx; w++)
         if (!ctxs[w] || ctxs[w]->device != ctxs[0]->device || ctxs[w]->precision != ctxs[0]->precision) return OFX_ERR_ARG;
-    // group size: the "lockstep" option, or -- automatic -- 4, shrunk so that a small batch still gives every
-    // context a group (5 pairs on 4 contexts: groups of 2, 2, 1 instead of 4 + 1)
-    int G = ctxs[0]->lockstep;
-    if (G <= 0) {
-        G = (n_pairs + n_ctx - 1) / n_ctx;
-        G = G < 1 ? 1 : (G > 4 ? 4 : G);
-    }
-    if (G > OFX_MAX_GROUP) G = OFX_MAX_GROUP;
+    const int G = ofx_tvl1_batch_group_size(ctxs, n_ctx, n_pairs, nx, ny, nscales, zfactor);
+    if (G < 1) return G < 0 ? G : OFX_ERR_ARG;
     const int n_groups = (n_pairs + G - 1) / G;
     std::atomic<int> status(OFX_OK);
     auto worker = [&](int w) {

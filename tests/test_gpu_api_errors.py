@@ -90,5 +90,11 @@ def test_batch_entry_point(ofx_mod, orc, synth):
         assert np.array_equal(got[k], np.stack([uo, vo], axis=-1).astype(np.float32))
         sizes = [(nx, ny), (64, 48), (32, 24)]
         assert work[k] == sum(int(it[s].sum()) * sizes[s][0] * sizes[s][1] for s in range(3))
+    # the automatic grouping: as few rounds as groups of 16 allow, evened out over the contexts
+    size = lambda npairs, k: ofx_mod.tvl1_batch_group_size(ctxs[:k], npairs, nx, ny, 3, 0.5)
+    assert [size(5, 2), size(1, 2), size(20, 2), size(33, 2), size(64, 2), size(65, 2), size(7, 1)] == [3, 1, 10, 9, 16, 11, 7]
+    ctxs[0].set_option("lockstep", 2)
+    assert size(20, 2) == 2
+    ctxs[0].set_option("lockstep", 0)
     for c in ctxs:
         c.close()
