@@ -9,7 +9,7 @@
 
 `pairs.txt` holds one pair per line: "I0 I1 [out.flo]" (PGM / PPM / PFM / PNG, read exactly as the tvl1flow front-end
 reads them).  Pair k is solved by rank k % world (optical-flow-1_amd/batch.py); every rank keeps `--in-flight`
-contexts (HIP stream + host thread each) busy on its GPU, every context solving lockstep groups of up to 4 pairs
+contexts (HIP stream + host thread each) busy on its GPU, every context solving lockstep groups of up to 16 pairs
 (ofx_tvl1_batch_dev); the float32 .flo payloads stay in
 HBM until ONE gather to rank 0 at the end, which writes the files.  Solver parameters are the reference's
 (tvl1flow_main.cpp:24-33), including the automatic number of scales.
