@@ -466,20 +466,35 @@ __global__ void k_tvl1_warp(const typename Pix<T>::v2 *__restrict__ pag, const T
 // gathers from there (LDS: 128 B/clk/CU, consecutive lanes -> consecutive columns, conflict-free).  A block whose box
 // does not fit the tile (a motion boundary with a large jump) takes the global-gather path; same arithmetic either
 // way, bit-identical results.
+// Tile size and register budget are chosen for occupancy: the block has two dependent global-load phases (flow ->
+// bounding box -> tile), so its time follows the number of resident waves.  48 x 16 x 24 B = 18 KB lets 8 blocks =
+// 32 waves share a CU's LDS, and 64 VGPRs (waves_per_eu 8; 10 spilled) lets them share its registers:
+// 1080p 49.0 -> 40.5 us (tile 48 x 24 and 98 VGPRs gave 16 waves per CU; a 16-row block or a 40 x 14 tile: no better).
+#ifndef WARP_TW
 #define WARP_TW 48          // tile columns
-#define WARP_TH 24          // tile rows
+#define WARP_TH 16          // tile rows
+#endif
+#ifndef WARP_BY
+#define WARP_BY 8           // block rows (block = 32 x WARP_BY pixels)
+#endif
+#ifndef WARP_WAVES
+#define WARP_WAVES 8
+#endif
+#define WARP_ATTR __attribute__((amdgpu_waves_per_eu(WARP_WAVES, WARP_WAVES)))
+#define WARP_NT (32 * WARP_BY)
+#define WARP_NW (WARP_NT / 64)
 template <typename T>
-__global__ __launch_bounds__(256) void k_tvl1_warp_lds(
+__global__ __launch_bounds__(WARP_NT) WARP_ATTR void k_tvl1_warp_lds(
     const typename Pix<T>::v2 *__restrict__ pag, const T *__restrict__ pbg, const T *__restrict__ I0g,
     const typename Pix<T>::v2 *__restrict__ U0, const typename Pix<T>::v2 *__restrict__ U1,
     typename Pix<T>::v2 *__restrict__ Ag, T *__restrict__ Rg, int nx, int ny, unsigned curmask)
 {
     __shared__ double2 s_a[WARP_TH * WARP_TW];
     __shared__ double s_b[WARP_TH * WARP_TW];
-    __shared__ int s_box[4][4];                               // per wave: xmin, xmax, ymin, ymax
+    __shared__ int s_box[WARP_NW][4];                         // per wave: xmin, xmax, ymin, ymax
     const int tid = threadIdx.y * 32 + threadIdx.x, wave = tid >> 6;
     const int j = blockIdx.x * 32 + threadIdx.x;
-    const int i = blockIdx.y * 8 + threadIdx.y;
+    const int i = blockIdx.y * WARP_BY + threadIdx.y;
     const bool inside = (j < nx) && (i < ny);
     const int g = blockIdx.z;
     const size_t goff = (size_t) g * nx * ny;
@@ -506,7 +521,7 @@ __global__ __launch_bounds__(256) void k_tvl1_warp_lds(
     if ((tid & 63) == 0) { s_box[wave][0] = xlo; s_box[wave][1] = xhi; s_box[wave][2] = ylo; s_box[wave][3] = yhi; }
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < WARP_NW; w++) {
         xlo = min(xlo, s_box[w][0]); xhi = max(xhi, s_box[w][1]);
         ylo = min(ylo, s_box[w][2]); yhi = max(yhi, s_box[w][3]);
     }
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(256) void k_tvl1_warp_lds(
     const bool any = (xhi >= 0);
     const bool tile = any && W <= WARP_TW && H <= WARP_TH;    // block-uniform
     if (tile) {
-        for (int k = tid; k < W * H; k += 256) {
+        for (int k = tid; k < W * H; k += WARP_NT) {
             const int r = k / W, c = k - r * W;
             const size_t src = (size_t) (ylo + r) * nx + (xlo + c);
             s_a[r * WARP_TW + c] = ldw2(pa + src);
@@ -750,7 +765,7 @@ static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params
 
     for (int w = 0; w < P.warps; w++) {
         if (ctx->warp_lds)
-            hipLaunchKernelGGL(k_tvl1_warp_lds<T>, dim3(ofx_cdiv(nx, 32), ofx_cdiv(ny, 8), G), dim3(32, 8), 0, ctx->stream, L.pa,
+            hipLaunchKernelGGL(k_tvl1_warp_lds<T>, dim3(ofx_cdiv(nx, 32), ofx_cdiv(ny, WARP_BY), G), dim3(32, WARP_BY), 0, ctx->stream, L.pa,
                                (const T *) L.pb, (const T *) L.I0, L.U[0], L.U[1], L.A, L.R, nx, ny, L.cur);
         else
             hipLaunchKernelGGL(k_tvl1_warp<T>, g2, b2, 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I0, L.U[0],
