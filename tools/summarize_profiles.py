@@ -15,8 +15,13 @@ for extra in ("bench_4k", "bench_f32", "bench_4k_f32"):
 bench = json.load(open(os.path.join(SRC, "bench.json")))
 
 # ---- kernel stats of the bench command ----
-stats = list(csv.DictReader(open(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0])))
-trace = list(csv.DictReader(open(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv"))[0])))
+def newest(pattern):
+    """gpurun merges every collection into the same directory: take the files of the latest one"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
+stats = list(csv.DictReader(open(newest(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0])))
+trace = list(csv.DictReader(open(newest(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv"))[0])))
 out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu --streams 1 --lockstep 1   (MI355X, f64, 1920x1080 P1)",
        "# the run contains the reference-semantics steps (eps=0.01) AND the fixed-work passes (300 iterations / warp)",
        "# kernel | calls | total ms | average us | % of GPU time", ""]
@@ -64,7 +69,7 @@ pm = {"note": "rocprofv3 --pmc passes on tools/pmc_iter.py (40 fixed iterations 
 for sz in ("1920x1080", "3840x2160"):
     vals = {}
     for kind in ("fetch", "write", "sq"):
-        f = glob.glob(os.path.join(SRC, "pmc_%s_%s" % (kind, sz), "*", "*_counter_collection.csv"))
+        f = newest(os.path.join(SRC, "pmc_%s_%s" % (kind, sz), "*", "*_counter_collection.csv"))
         if not f:
             continue
         acc = collections.defaultdict(list)
@@ -73,7 +78,7 @@ for sz in ("1920x1080", "3840x2160"):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             vals[k] = sum(v) / len(v)
-        kt = glob.glob(os.path.join(SRC, "pmc_%s_%s" % (kind, sz), "*", "*_kernel_trace.csv"))
+        kt = newest(os.path.join(SRC, "pmc_%s_%s" % (kind, sz), "*", "*_kernel_trace.csv"))
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt[0])) if "k_tvl1_iter2" in r["Kernel_Name"]]
         vals["launch_us_" + kind] = sum(d) / len(d)
     nx, ny = map(int, sz.split("x"))
