@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--nx", type=int, default=NX)
