@@ -173,8 +173,13 @@ OFX_DEV PairHalves<V> pick_halves(V *h0, V *h1, unsigned inmask, int g, size_t n
 // `slot` is where the error of this iteration is accumulated; `check` = index of this iteration in the
 // loop (0 = no stopping test, used for the unconditional redo of a single iteration).  g0 = first pair of
 // the launch (the redo runs on one pair: gridDim.y = 1, g0 = that pair).
+#ifdef OFX_ITER1_WAVES
+#define OFX_ITER1_ATTR __attribute__((amdgpu_waves_per_eu(OFX_ITER1_WAVES, OFX_ITER1_WAVES)))
+#else
+#define OFX_ITER1_ATTR
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void k_tvl1_iter(
+__global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
     typename Pix<T>::v2 *__restrict__ U0, typename Pix<T>::v2 *__restrict__ U1,
     typename Pix<T>::v2 *__restrict__ P10, typename Pix<T>::v2 *__restrict__ P11,
     typename Pix<T>::v2 *__restrict__ P20, typename Pix<T>::v2 *__restrict__ P21,

@@ -189,7 +189,7 @@ def test_fused_kernel_equals_single_kernel(gpu64, orc, synth, nx, ny):
 
 
 # ---- lockstep groups (several pairs share every launch) -----------------------------------------------------
-@pytest.mark.parametrize("G", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("G", [1, 2, 3, 5, 8, 16])
 def test_lockstep_group_equals_pairs_solved_alone(ofx_mod, gpu64, orc, synth, G):
     """ofx_tvl1_group_dev: G different pairs through the same launches.  Every pair keeps its own stopping
     test / iteration counts / ping-pong phase: iteration tables equal the oracle's pair by pair and the .flo
