@@ -70,9 +70,9 @@ static inline int ofx_loop_finalize(ofx_ctx *ctx, const LoopSpec &L, int start, 
 //   launch(k, count, thr) must enqueue every kernel of sweeps k .. k+count-1 of ALL problems on ctx->stream
 // (count is 2 only when L.pairs and at least two sweeps remain; pairs always start at an even k); kernels
 // take (ctx->d_err, k, thr) and use the helpers above.  With L.pairs the second sweep of a pair runs even
-// when the first one ended the loop; if that happens for problem g (n odd), redo(g, n-1) must recompute
-// sweep n-1 of that problem alone from the pair's untouched input buffers.  Returns the reference's n and
-// error per problem.
+// when the first one ended the loop; if that happens for any problem (n odd), redo(k_of) is called ONCE with
+// k_of[g] = n_g - 1 for those problems and -1 for the others, and must recompute sweep k_of[g] of each such
+// problem alone from the pair's untouched input buffers.  Returns the reference's n and error per problem.
 template <class LaunchFn, class RedoFn>
 static int ofx_run_loop_group(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn launch, RedoFn redo, int *n_out,
                               double *err_out, float *ms_out)
@@ -129,8 +129,14 @@ static int ofx_run_loop_group(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn l
         }
     }
     if (!stop) return ofx_fail(ctx, OFX_ERR_HIP, "iteration loop ended without a final state");
-    for (int g = 0; g < G; g++)
-        if (S.pairs && (fin[g].n & 1) && fin[g].n != S.max_iter) OFX_TRY(redo(g, fin[g].n - 1));
+    int redo_k[OFX_MAX_GROUP];
+    bool any_redo = false;
+    for (int g = 0; g < G; g++) {
+        const bool r = S.pairs && (fin[g].n & 1) && fin[g].n != S.max_iter;
+        redo_k[g] = r ? fin[g].n - 1 : -1;
+        any_redo = any_redo || r;
+    }
+    if (any_redo) OFX_TRY(redo(redo_k));
     if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
     for (int g = 0; g < G; g++) {
         n_out[g] = fin[g].n;
@@ -143,10 +149,10 @@ static int ofx_run_loop_group(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn l
     return OFX_OK;
 }
 
-// single problem (the SOR solvers); redo(k) as above without the problem index
+// single problem (the SOR solvers); redo(k) as above for the one problem
 template <class LaunchFn, class RedoFn>
 static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, RedoFn redo, int *n_out, double *err_out,
                         float *ms_out)
 {
-    return ofx_run_loop_group(ctx, L, 1, launch, [&](int, int k) { return redo(k); }, n_out, err_out, ms_out);
+    return ofx_run_loop_group(ctx, L, 1, launch, [&](const int *k_of) { return redo(k_of[0]); }, n_out, err_out, ms_out);
 }

@@ -171,8 +171,8 @@ OFX_DEV PairHalves<V> pick_halves(V *h0, V *h1, unsigned inmask, int g, size_t n
 
 // ---- one iteration per launch ------------------------------------------------------------------------
 // `slot` is where the error of this iteration is accumulated; `check` = index of this iteration in the
-// loop (0 = no stopping test, used for the unconditional redo of a single iteration).  g0 = first pair of
-// the launch (the redo runs on one pair: gridDim.y = 1, g0 = that pair).
+// loop (0 = no stopping test, used for the unconditional redo of a single iteration).  Pairs whose bit in
+// `runmask` is clear are skipped (the redo runs only on the pairs whose loop ended on an odd count).
 #ifdef OFX_ITER1_WAVES
 #define OFX_ITER1_ATTR __attribute__((amdgpu_waves_per_eu(OFX_ITER1_WAVES, OFX_ITER1_WAVES)))
 #else
@@ -185,12 +185,13 @@ __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
     typename Pix<T>::v2 *__restrict__ P20, typename Pix<T>::v2 *__restrict__ P21,
     const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int check, int slot,
     int nx, int ny, int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2,
-    unsigned inmask, int g0, int err_stride)
+    unsigned inmask, unsigned runmask, int err_stride)
 {
     using v2 = typename Pix<T>::v2;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int g = g0 + blockIdx.y;
+    const int g = blockIdx.y;
+    if (!((runmask >> g) & 1u)) return;
     const size_t npix = (size_t) nx * ny;
     const PairHalves<v2> hu = pick_halves(U0, U1, inmask, g, npix), h1 = pick_halves(P10, P11, inmask, g, npix),
                          h2 = pick_halves(P20, P21, inmask, g, npix);
@@ -713,17 +714,17 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
     const bool nt_stores = (double) nx * ny * G * 15.0 * sizeof(T) > 300e6;
     // launch unit u (a pair of iterations, or a single one) reads half (base_g + u) & 1 of pair g and writes
     // the other one
-    auto single = [&](int unit, int check, int slot, double thr, int g0, int gy) -> int {
-        const unsigned inmask = (unit & 1) ? (base ^ all) : base;
-        hipLaunchKernelGGL(k_tvl1_iter<T>, dim3(gx1, gy), block, 0, ctx->stream, L.U[0], L.U[1], L.P1[0], L.P1[1], L.P2[0],
+    auto single = [&](unsigned inmask, unsigned runmask, int check, int slot, double thr) -> int {
+        hipLaunchKernelGGL(k_tvl1_iter<T>, dim3(gx1, G), block, 0, ctx->stream, L.U[0], L.U[1], L.P1[0], L.P1[1], L.P2[0],
                            L.P2[1], L.A, (const T *) L.R, ctx->d_err, check, slot, nx, ny, rows, strips_x, strips_pad,
-                           l_t, theta, taut, thr, inmask, g0, err_stride);
+                           l_t, theta, taut, thr, inmask, runmask, err_stride);
         OFX_LAUNCH_CHECK(ctx);
         return OFX_OK;
     };
     auto launch = [&](int k, int cnt, double thr) -> int {
-        if (cnt == 1) return single(pairs ? k / 2 : k, k, k, thr, 0, G);
-        const unsigned inmask = ((k / 2) & 1) ? (base ^ all) : base;
+        const int unit = (pairs ? k / 2 : k);
+        const unsigned inmask = (unit & 1) ? (base ^ all) : base;
+        if (cnt == 1) return single(inmask, all, k, k, thr);
         if (nt_stores)
             hipLaunchKernelGGL((k_tvl1_iter2<T, true>), grid2, block, 0, ctx->stream, L.U[0], L.U[1], L.P1[0], L.P1[1],
                                L.P2[0], L.P2[1], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
@@ -735,9 +736,18 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
         OFX_LAUNCH_CHECK(ctx);
         return OFX_OK;
     };
-    // the loop of pair g ended on the first iteration of a fused pair: recompute that iteration alone (no
-    // stopping test, error into the scratch slot) from the pair's input half, overwriting the pair's output
-    auto redo = [&](int g, int k) -> int { return single(k / 2, 0, S.max_iter, -1.0, g, 1); };
+    // pairs whose loop ended on the first iteration of a fused pair: recompute that iteration alone (no stopping
+    // test, error into the scratch slot) from each pair's input half, overwriting its output half -- one launch
+    // for all of them (runmask), every pair reading the half its own unit k / 2 started from
+    auto redo = [&](const int *k_of) -> int {
+        unsigned inmask = 0, runmask = 0;
+        for (int g = 0; g < G; g++) {
+            if (k_of[g] < 0) continue;
+            runmask |= 1u << g;
+            inmask |= ((((base >> g) & 1u) + (unsigned) (k_of[g] / 2)) & 1u) << g;
+        }
+        return single(inmask, runmask, 0, S.max_iter, -1.0);
+    };
     OFX_TRY(ofx_run_loop_group(ctx, S, G, launch, redo, n_out, err_out, ms_out));
     unsigned cur = 0;
     for (int g = 0; g < G; g++) {
