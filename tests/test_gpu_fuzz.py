@@ -1,9 +1,16 @@
 """Randomised sizes and parameters (seeded): the C-ABI TV-L1 path against the oracle, and the operators on
 ragged sizes.  Everything stays small enough for the oracle to finish in a fraction of a second."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+# a longer soak with other draws: OFX_FUZZ_SEED=7 OFX_FUZZ_N=300 OFX_FUZZ_SOR=40 python -m pytest tests/test_gpu_fuzz.py -m gpu
+FUZZ_SEED = int(os.environ.get("OFX_FUZZ_SEED", "2026"))
+FUZZ_N = int(os.environ.get("OFX_FUZZ_N", "24"))
+FUZZ_SOR = int(os.environ.get("OFX_FUZZ_SOR", "4"))
 
 
 def cases(seed, n):
@@ -26,7 +33,7 @@ def cases(seed, n):
     return out
 
 
-@pytest.mark.parametrize("c", cases(2026, 24), ids=lambda c: "%dx%d-%s-ns%d-w%d-z%g-e%g" % (
+@pytest.mark.parametrize("c", cases(FUZZ_SEED, FUZZ_N), ids=lambda c: "%dx%d-%s-ns%d-w%d-z%g-e%g" % (
     c["nx"], c["ny"], c["pair"], c["kw"]["nscales"], c["kw"]["warps"], c["kw"]["zfactor"], c["kw"]["epsilon"]))
 def test_tvl1_random_configurations(gpu64, orc, synth, c):
     I0, I1 = synth.pair(c["pair"], c["nx"], c["ny"], c["k"])
@@ -59,9 +66,9 @@ def test_operators_ragged_sizes(gpu64, orc, seed):
         assert np.array_equal(gpu64.zoom_in(a, nx + 3, ny + 5), orc.zoom_in(a, nx + 3, ny + 5))
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(FUZZ_SOR))
 def test_sor_random_configurations(gpu64, orc, synth, seed):
-    rng = np.random.default_rng(300 + seed)
+    rng = np.random.default_rng((300 if FUZZ_SEED == 2026 else 1000 * FUZZ_SEED) + seed)
     nx, ny = int(rng.integers(20, 90)), int(rng.integers(16, 70))
     I1, I2 = synth.pair("P1", nx, ny, seed)
     z = np.zeros((ny, nx))
@@ -77,3 +84,30 @@ def test_sor_random_configurations(gpu64, orc, synth, seed):
     ug, vg = gpu64.brox_spatial(I1, I2, **kw)
     assert np.array_equal(gpu64.stats().iterations(), it_o)
     assert np.abs(ug - uo).max() < 1e-10 and np.abs(vg - vo).max() < 1e-10
+
+
+FUZZ_GROUPS = int(os.environ.get("OFX_FUZZ_GROUPS", "3"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_GROUPS))
+def test_tvl1_random_lockstep_groups(gpu64, orc, synth, seed):
+    """a lockstep group of random size with random parameters: every pair equals the oracle's solve of that pair"""
+    import torch
+    rng = np.random.default_rng((500 if FUZZ_SEED == 2026 else 2000 * FUZZ_SEED) + seed)
+    c = cases(int(rng.integers(0, 1 << 30)), 1)[0]
+    G = int(rng.integers(2, 17))
+    nx, ny, kw = c["nx"], c["ny"], dict(c["kw"])
+    kw["warps"] = min(kw["warps"], 3)
+    pairs = [synth.pair("P0" if k % 4 == 3 else "P1", nx, ny, k) for k in range(G)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in pairs]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in pairs]
+    flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    st = gpu64.tvl1_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1],
+                              [flo[k].data_ptr() for k in range(G)], nx, ny, **kw)
+    gpu64.synchronize()
+    got = flo.cpu().numpy()
+    for k in range(G):
+        uo, vo, it, _ = orc.tvl1_multiscale(pairs[k][0], pairs[k][1], **kw)
+        assert np.array_equal(st[k].iterations(), it), (k, G, nx, ny, kw)
+        assert np.array_equal(got[k], np.stack([uo, vo], axis=-1).astype(np.float32)), (k, G, nx, ny, kw)
