@@ -111,3 +111,21 @@ def test_tvl1_random_lockstep_groups(gpu64, orc, synth, seed):
         uo, vo, it, _ = orc.tvl1_multiscale(pairs[k][0], pairs[k][1], **kw)
         assert np.array_equal(st[k].iterations(), it), (k, G, nx, ny, kw)
         assert np.array_equal(got[k], np.stack([uo, vo], axis=-1).astype(np.float32)), (k, G, nx, ny, kw)
+
+
+FUZZ_TEMPORAL = int(os.environ.get("OFX_FUZZ_TEMPORAL", "2"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_TEMPORAL))
+def test_brox_temporal_random_configurations(gpu64, orc, synth, seed):
+    """temporal Brox on random small sequences: sweep counts and flows equal the oracle's (reference sweep order)"""
+    rng = np.random.default_rng((700 if FUZZ_SEED == 2026 else 3000 * FUZZ_SEED) + seed)
+    nx, ny, frames = int(rng.integers(16, 80)), int(rng.integers(16, 60)), int(rng.integers(3, 7))
+    I = synth.sequence(nx, ny, frames, int(rng.integers(0, 4)))
+    kw = dict(alpha=float(rng.choice([18.0, 30.0])), gamma=float(rng.choice([7.0, 0.0, 3.0])), nscales=int(rng.integers(1, 3)),
+              nu=float(rng.choice([0.75, 0.5])), TOL=float(rng.choice([1e-4, 1e-3])), inner=int(rng.integers(1, 3)),
+              outer=int(rng.integers(1, 4)))
+    ur, vr, it_r = orc.brox_temporal(I, **kw)
+    ug, vg = gpu64.brox_temporal(I, **kw)
+    assert np.array_equal(gpu64.stats().iterations(), it_r), (nx, ny, frames, kw)
+    assert np.abs(ug - ur).max() < 1e-10 and np.abs(vg - vr).max() < 1e-10, (nx, ny, frames, kw)
