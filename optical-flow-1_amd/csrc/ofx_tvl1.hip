@@ -326,7 +326,12 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
     double *__restrict__ err = errg + (size_t) g * err_stride;
     const double prev1 = loop_fetch_prev(err, k), prev2 = loop_fetch_prev(err, k - 1);
 
-    const int strip = gw % strips_pad, band = gw / strips_pad;
+    const int band = gw / strips_pad;
+#ifdef OFX_XCD_ROT   // A/B knob: rotate the tile columns from band to band, so vertical neighbours sit on different XCDs
+    const int strip = (gw % strips_pad + 4 * OFX_XCD_ROT * band) % strips_pad;
+#else
+    const int strip = gw % strips_pad;
+#endif
     const int y0 = band * rows;
     const bool idle = (strip >= strips_x) || (y0 >= ny);
     const int yend = (y0 + rows < ny) ? y0 + rows : ny;     // rows [y0, yend) are written by this wave
