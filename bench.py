@@ -1,31 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- TV-L1 multiscale throughput on MI355X, BASELINE.json metric.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one synthetic 1920x1080 image pair (P1 of SURVEY.md §8d, rank r uses batch variant k=r)
-through ofx_tvl1_multiscale_dev with the reference's default parameters (nscales=5 warps=5 tau=0.25
-lambda=0.15 theta=0.3 zfactor=0.5 epsilon=0.01) in f64 storage, inputs already resident in HBM, result
-= the .flo payload in HBM.  Work is counted exactly like the reference prints it:
-    work = sum_scales sum_warps n_iter * nx_s * ny_s      [pixel-iterations]
-and `value` = whole-job Mpix*warp-iters/s = (work of all ranks over the K timed steps) / (max over ranks
-of the wall time of those K steps, barrier + device sync on both sides) / 1e6.  For N > 1 every rank
-processes its own K pairs (weak scaling, no data-path collective) and the timed region ends with ONE RCCL
-gather of the float32 .flo payloads to rank 0.
+Workloads (--workload):
+  1080p     (default, BASELINE configs[1], the configuration the metric is quoted on)  One "step" = one synthetic
+            1920x1080 image pair (P1 of SURVEY.md 8d) through the TV-L1 multiscale solve with the reference's default
+            parameters (nscales=5 warps=5 tau=0.25 lambda=0.15 theta=0.3 zfactor=0.5 epsilon=0.01) in f64 storage,
+            inputs resident in HBM, result = the .flo payload in HBM.  Every rank solves its own K pairs: weak scaling.
+  4k-batch  (BASELINE configs[4])  ONE batch of K (default 64) distinct synthetic 3840x2160 pairs, pair k on rank
+            k mod N (8 pairs per GPU at N = 8, all 64 on one GPU at N = 1): strong scaling.
+Work is counted exactly like the reference prints it:  work = sum_scales sum_warps n_iter * nx_s * ny_s  [pixel-
+iterations], and `value` = whole-job Mpix*warp-iters/s = (work of all ranks over the timed steps) / (max over ranks of
+the wall time of those steps, barrier + device sync on both sides) / 1e6.
 
-Because P1 converges in a few dozen iterations per warp, the line also carries a `fixed_work` object
-(option "fixed_work": every warp runs exactly 300 iterations) and the `roofline` object, which
-is measured on that pass: HIP events on the library's own stream bracket the full-resolution iteration
-launches, achieved = 120 B/px/iter * 1920*1080 px / average launch duration.  `cpu_baseline` times the
-compiled reference (oracle/_ref, kind "reference"; falls back to the C port) on the host cores, rank 0 and
-N=1 only.
+N > 1: no data-path collective (pairs are independent); the timed region ends with the RCCL gather of the float32 .flo
+payloads to rank 0.  The pairs of a rank are solved in ROUNDS and the gather of round r runs (asynchronously, RCCL's
+own stream) while round r + 1 computes, so only the last round's transfer is exposed (`gather_ms`).
+
+The line also carries: `fixed_work` (option "fixed_work": every warp runs exactly 300 iterations);
+`roofline` / `roofline_4k` for the dominant kernel k_tvl1_iter2, measured on a fixed-work pass with HIP events on the
+library's own stream; `sor` (BASELINE configs 3 / 4: exact Horn-Schunck and Brox solves); `cpu_baseline` (the compiled
+reference, oracle/_ref, on the host cores; rank 0 at N = 1 only).
 """
 import argparse
-import ctypes
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,30 +38,37 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NX, NY = 1920, 1080
 PAR = dict(tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5, epsilon=0.01)
-BYTES_PER_PIX_ITER = {0: 120.0, 1: 60.0}      # 15 storage elements / px / iteration
+ELEM = {"f64": 8.0, "f32": 4.0}
 HBM_PEAK_GBS = 8000.0
+WORKLOADS = {"1080p": (1920, 1080), "4k-batch": (3840, 2160)}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=0, help="pairs per rank (1080p, default 64) / pairs of the batch (4k-batch, default 64)")
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
-    ap.add_argument("--nx", type=int, default=NX)
-    ap.add_argument("--ny", type=int, default=NY)
+    ap.add_argument("--nx", type=int, default=0, help="override the workload's image width (tests / rehearsals)")
+    ap.add_argument("--ny", type=int, default=0)
     ap.add_argument("--pair", default="P1")
     ap.add_argument("--fixed-steps", type=int, default=2, help="fixed-work passes for the roofline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-4k", action="store_true", help="skip the roofline_4k leg")
+    ap.add_argument("--no-sor", action="store_true", help="skip the sor leg (BASELINE configs 3 / 4)")
     ap.add_argument("--lockstep", type=int, default=0,
-                    help="pairs per lockstep group (they share every kernel launch of one context); 0 = the library's "
-                         "choice: up to 4, fewer when the batch is small")
+                    help="pairs per lockstep group (they share every kernel launch of one context); 0 = the library's choice")
     ap.add_argument("--concurrency", type=int, default=0, help="override the library's concurrency hint (0 = streams)")
-    ap.add_argument("--variants", type=int, default=8, help="distinct synthetic pairs cycled through by the steps")
+    ap.add_argument("--variants", type=int, default=8, help="1080p: distinct synthetic pairs cycled through by the steps")
     ap.add_argument("--streams", type=int, default=4,
-                    help="image pairs in flight per GPU, each on its own context / HIP stream (SURVEY 8e: >= 2)")
+                    help="lockstep groups in flight per GPU, each on its own context / HIP stream (SURVEY 8e: >= 2)")
+    ap.add_argument("--rounds", type=int, default=0,
+                    help="rounds per rank (the gather of a round overlaps the next round's compute); 0 = automatic: "
+                         "1 on one GPU, 2 (3/4 + 1/4 of the pairs) on several when a rank has >= 32 pairs")
+    ap.add_argument("--check", action="store_true",
+                    help="N > 1: rank 0 re-solves every pair of every rank and compares the gathered payloads byte for byte")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
@@ -73,8 +84,47 @@ def log(msg):
     sys.stderr.flush()
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process has not touched the GPU (not even
+    imported torch) -- it starts the N ranks as fresh child processes through torch.distributed.run, relays rank 0's
+    JSON line (the children inherit stdout) and returns their exit code.  Nothing is re-exec'ed."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting %d ranks: %s" % (a.gpus, " ".join(cmd)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def split_rounds(n, rounds, nstreams):
+    """[(first, count)] slices of a rank's n pairs.  Two rounds: the last one ~1/4 of the pairs, a multiple of the
+    number of contexts where possible (every context then gets one lockstep group per round)."""
+    rounds = min(rounds, n)
+    if rounds <= 1:
+        return [(0, n)]
+    out, first = [], 0
+    for r in range(rounds):
+        left = rounds - r
+        if left == 1:
+            cnt = n - first
+        else:
+            cnt = (n - first) * (2 ** (left - 1) + 1) // (2 ** left)     # 2 rounds: 3/4 + 1/4
+            if cnt >= nstreams:
+                cnt -= cnt % nstreams
+            cnt = max(1, min(cnt, n - first - (left - 1)))
+        out.append((first, cnt))
+        first += cnt
+    return out
+
+
 def cpu_baseline(synth, nx, ny, pair):
-    """Reference (oracle/_ref) on the host cores: one multiscale call on the same pair + the inner loop only."""
+    """Reference (oracle/_ref) on the host cores: a bounded sample of the 1080p workload (4 pairs through the multiscale
+    call) + the inner loop alone."""
     import oracle
     if oracle.have_ref():
         cpu = oracle.Ref()
@@ -86,7 +136,6 @@ def cpu_baseline(synth, nx, ny, pair):
     cores = min(oracle.host_cores(), 32)
     cpu.set_num_threads(cores)
     log("cpu_baseline: %s on %d threads (affinity %d)" % (cpu.kind, cores, len(os.sched_getaffinity(0))))
-    # a bounded sample (~10 s of CPU work): NPAIR batch variants of the bench pair through the multiscale call
     NPAIR = 4
     pairs = [synth.pair(pair, nx, ny, k) for k in range(NPAIR)]
     t0 = time.perf_counter()
@@ -99,7 +148,6 @@ def cpu_baseline(synth, nx, ny, pair):
                      % (NPAIR, pair, nx, ny, NPAIR - 1, t_ms), "seconds": round(t_ms, 3),
            "build": "-O3 -fopenmp, generic x86-64"}
     # work of those calls: iteration counts from the port (bit-identical loop, OMP_NUM_THREADS=1 parity-tested)
-    work = None
     if port is not None:
         port.set_num_threads(cores)
         sizes = [(nx, ny)]
@@ -111,7 +159,7 @@ def cpu_baseline(synth, nx, ny, pair):
             work += float(sum(int(iters[s].sum()) * sizes[s][0] * sizes[s][1] for s in range(PAR["nscales"])))
         out["value"] = round(work / t_ms / 1e6, 3)
     I0, I1 = pairs[0]
-    # fixed-work inner loop: Dual_TVL1_optic_flow, 1 warp, eps=0 -> 300 iterations at full resolution
+    # fixed-work inner loop: Dual_TVL1_optic_flow, 2 warps, eps=0 -> 300 iterations each at full resolution
     z = np.zeros((ny, nx))
     t0 = time.perf_counter()
     if cpu.kind == "reference":
@@ -125,11 +173,108 @@ def cpu_baseline(synth, nx, ny, pair):
     log("cpu_baseline: fixed-work inner loop %.2f s" % t_fx)
     out["fixed_work"] = {"value": round(n_it * nx * ny / t_fx / 1e6, 3), "unit": "Mpix*iters/s",
                          "sample": "Dual_TVL1_optic_flow %dx%d, 2 warps, eps=0 (%d iterations, %.2f s)" % (nx, ny, n_it, t_fx)}
-    return out, work
+    return out
+
+
+def load_pmc():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return {}
+
+
+def roofline_of(ctx, solve_one, precision, nx, ny, passes):
+    """Fixed-work passes of ONE pair alone with HIP events (on the library's stream) around the iteration launches of
+    every level.  Returns (roofline dict for the full-resolution k_tvl1_iter2 launches, per-level list, work, seconds).
+
+    Bytes: the kernel fuses TWO iterations per launch and touches every stream once per launch, so its compulsory
+    HBM traffic is 15 storage elements per pixel PER LAUNCH (read U,P1,P2,A,R = 9, write U,P1,P2 = 6): `achieved` and
+    `frac` use that figure and cannot exceed 1.  SURVEY 8(d)'s accounting unit (15 elements per pixel per ITERATION,
+    what an unfused kernel has to move) is kept next to it as `algorithmic_equivalent_*`: it says how fast a
+    one-iteration-per-launch kernel would have to stream to keep up, and may exceed the HBM peak."""
+    elem = ELEM[precision]
+    ctx.set_option("concurrency", 1)
+    ctx.set_option("profile", 1)
+    ctx.set_option("fixed_work", 1)
+    solve_one()                                          # warm
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    work, ns = 0.0, PAR["nscales"]
+    lv_ms, lv_n = [0.0] * ns, [0] * ns
+    st = None
+    for _ in range(passes):
+        work += solve_one()
+        st = ctx.stats()
+        for s_ in range(ns):
+            lv_ms[s_] += st.iter_ms[s_]
+            lv_n[s_] += st.iter_launches[s_]
+    ctx.synchronize()
+    secs = time.perf_counter() - t0
+    ctx.set_option("profile", 0)
+    ctx.set_option("fixed_work", 0)
+    us_iter = lv_ms[0] * 1e3 / max(lv_n[0], 1)            # per ITERATION (stats count iterations)
+    us_launch = 2.0 * us_iter
+    fused = 15.0 * elem * nx * ny                         # bytes per launch, compulsory for the fused kernel
+    ach = fused / (us_launch * 1e-6) / 1e9
+    equiv = 2.0 * fused / (us_launch * 1e-6) / 1e9
+    roof = {"bound": "hbm",
+            "kernel": "k_tvl1_iter2<%s> @ %dx%d (2 fused iterations per launch)" % ("double" if precision == "f64" else "float", nx, ny),
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": None, "avg_launch_us": round(us_launch, 3), "launches": int(lv_n[0] // 2),
+            "fused_algorithmic_bytes_per_launch": fused,
+            "bytes_model": "15 storage elements/px per LAUNCH (2 fused iterations): read U,P1,P2,A,R + write U,P1,P2",
+            "algorithmic_equivalent_bytes_per_launch": 2.0 * fused,
+            "algorithmic_equivalent_gbs": round(equiv, 1),
+            "algorithmic_equivalent_frac": round(equiv / HBM_PEAK_GBS, 4),
+            "algorithmic_equivalent_note": "SURVEY 8(d): 15 elements/px per ITERATION x 2 iterations per launch; the rate an "
+                                           "unfused kernel would need -- may exceed the HBM peak, not a bandwidth",
+            "mpix_iters_per_s": round(nx * ny / us_iter, 1)}
+    pmc = load_pmc()
+    key = "%s_%dx%d" % (precision, nx, ny)
+    tr = pmc.get("bytes_per_launch_" + key)
+    if tr:
+        det = pmc.get("detail_%dx%d" % (nx, ny), {}) if precision == "f64" else {}
+        roof["traffic"] = tr
+        roof["traffic_source"] = "profiles/pmc_traffic.json (builder-run rocprofv3 --pmc passes, not measured by this run)"
+        roof["hbm_frac_counter"] = round(tr / (us_launch * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        if "valu_active_fraction" in det:
+            roof["valu_active"] = round(det["valu_active_fraction"], 3)
+    lim = pmc.get("limiter_" + key) or pmc.get("limiter")
+    if lim:
+        roof["limiter"] = lim
+    levels = [{"size": "%dx%d" % (st.nx[s_], st.ny[s_]), "iter_us": round(lv_ms[s_] * 1e3 / max(lv_n[s_], 1), 2),
+               "ms_per_step": round(lv_ms[s_] / passes, 2)} for s_ in range(ns)]
+    return roof, levels, work, secs
+
+
+def sor_leg(ofx_mod, synth, local):
+    """BASELINE configs 3 and 4 (parity-test cases, not the headline): exact-order Horn-Schunck 1920x1080 and Brox
+    1280x720 solves, host arrays in / out, one pair per call.  Algorithmic bytes per sweep: 56 B/px (HS), 80 B/px
+    (Brox) -- SURVEY 8(d)."""
+    ctx = ofx_mod.Ofx(local, ofx_mod.F64)
+    out = {}
+    for name, fn, size, bpp, kw in (
+            ("hs_cfg3", ctx.hs_pyramidal, (1920, 1080), 56.0, dict(alpha=20.0, nscales=5, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150)),
+            ("brox_cfg4", ctx.brox_spatial, (1280, 720), 80.0, dict(alpha=50.0, gamma=10.0, nscales=6, nu=0.5, TOL=1e-4, inner=1, outer=15))):
+        I1, I2 = synth.pair("P0", size[0], size[1])
+        fn(I1, I2, **kw)                                 # warm (arena, clocks)
+        t0 = time.perf_counter()
+        fn(I1, I2, **kw)
+        dt = time.perf_counter() - t0
+        st = ctx.stats()
+        mps = st.work_pix_iters / dt / 1e6
+        out[name] = {"size": "%dx%d" % size, "seconds": round(dt, 4), "sweeps": int(st.iterations().sum()),
+                     "mpix_sweeps_per_s": round(mps, 1), "algorithmic_gbs": round(mps * bpp / 1e3, 1),
+                     "frac_of_hbm_peak": round(mps * bpp / 1e3 / HBM_PEAK_GBS, 5), "bytes_per_pixel_sweep": bpp,
+                     "mode": "exact (reference sweep order, bit-identical), one pair per call, host arrays in/out"}
+    ctx.close()
+    return out
 
 
 def main():
     a = parse()
+    if "RANK" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
 
@@ -137,13 +282,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (a.gpus, a.gpus))
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
-    local = local % torch.cuda.device_count()      # rehearsal of N ranks on a 1-GPU box (gloo); identity on a real node
+    ndev = torch.cuda.device_count()
+    if world > ndev and a.backend == "nccl":
+        raise SystemExit("bench.py --gpus %d: only %d device(s) visible (RCCL needs one GPU per rank; "
+                         "--backend gloo rehearses several ranks on one GPU)" % (world, ndev))
+    local = local % ndev                                 # rehearsal of N ranks on a 1-GPU box (gloo); identity on a real node
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -155,12 +301,24 @@ def main():
 
     ofx_mod = importlib.import_module("optical-flow-1_amd")
     synth = importlib.import_module("optical-flow-1_amd.synth")
+    batch = importlib.import_module("optical-flow-1_amd.batch")
     prec = ofx_mod.F64 if a.precision == "f64" else ofx_mod.F32
     tdt = torch.float64 if a.precision == "f64" else torch.float32
-    nstreams = max(1, min(a.streams, max(a.steps, 1)))
+    nx, ny = WORKLOADS[a.workload]
+    nx, ny = a.nx or nx, a.ny or ny
+    strong = a.workload == "4k-batch"
+    total_steps = a.steps if a.steps > 0 else 64
+    if strong:
+        mine = batch.pairs_of_rank(total_steps, world, rank)          # pair k of the batch -> rank k mod N
+        nsteps = len(mine)
+    else:
+        nsteps = total_steps
+        mine = list(range(rank * nsteps, (rank + 1) * nsteps))
+    slots = batch.pairs_per_rank(total_steps, world) if strong else nsteps
+
+    nstreams = max(1, min(a.streams, max(nsteps, 1)))
     ctxs = [ofx_mod.Ofx(local, prec) for _ in range(nstreams)]
     ctx = ctxs[0]
-    nx, ny = a.nx, a.ny
     for c_ in ctxs:
         c_.set_option("concurrency", a.concurrency or nstreams)
         c_.set_option("lockstep", a.lockstep if a.lockstep > 0 else 0)
@@ -170,39 +328,46 @@ def main():
             c_.set_option("chunk", a.chunk)
         if a.rows2:
             c_.set_option("rows_per_wave2", a.rows2)
-    # group size: --lockstep, or what the library picks for a batch of `steps` pairs on these contexts; pinned
-    # for the whole run so that warmup, timed region and fixed-work pass all use the same grouping
-    lockstep = ofx_mod.tvl1_batch_group_size(ctxs, max(a.steps, 1), nx, ny, PAR["nscales"], PAR["zfactor"])
+    nrounds = a.rounds if a.rounds > 0 else (2 if (world > 1 and nsteps >= 32) else 1)
+    rounds = split_rounds(slots, nrounds, nstreams)          # by slot count: identical on every rank (gather sizes must agree)
+    # group size: --lockstep, or what the library picks for the largest round on these contexts; pinned for the whole
+    # run so that warmup, timed region and fixed-work pass all use the same grouping
+    lockstep = ofx_mod.tvl1_batch_group_size(ctxs, max(max(c for _, c in rounds), 1), nx, ny, PAR["nscales"], PAR["zfactor"])
     for c_ in ctxs:
         c_.set_option("lockstep", lockstep)
     in_flight = nstreams * lockstep
 
-    # a short synthetic sequence: `variants` distinct pairs (SURVEY 8d batch variants), resident in HBM; step i of
-    # rank r solves variant (r * steps + i) % variants, so the pairs of a lockstep group converge differently
-    nvar = max(1, a.variants)
-    host_pairs = [synth.pair(a.pair, nx, ny, k) for k in range(nvar)]
-    dI0s = [torch.from_numpy(p[0]).to(dev, tdt).contiguous() for p in host_pairs]
-    dI1s = [torch.from_numpy(p[1]).to(dev, tdt).contiguous() for p in host_pairs]
-    var_of = lambda i: (rank * max(a.steps, 1) + i) % nvar
-    flo = torch.empty((max(a.steps, in_flight, 1), ny, nx, 2), dtype=torch.float32, device=dev)
+    # ---- inputs, resident in HBM --------------------------------------------------------------------------------
+    if strong:
+        # every pair of the batch is distinct (P1 with phase 0.3 + 0.1 k, foreground motion (4 + k mod 3, -3)),
+        # generated on the device
+        nvar = len(mine)
+        dI0s, dI1s = [], []
+        for k in mine:
+            i0, i1 = synth.pair_device(a.pair, nx, ny, k, dev, tdt)
+            dI0s.append(i0)
+            dI1s.append(i1)
+        var_of = lambda i: i
+    else:
+        # a short synthetic sequence: `variants` distinct pairs cycled, so the pairs of a lockstep group converge differently
+        nvar = max(1, a.variants)
+        host_pairs = [synth.pair(a.pair, nx, ny, k) for k in range(nvar)]
+        dI0s = [torch.from_numpy(p[0]).to(dev, tdt).contiguous() for p in host_pairs]
+        dI1s = [torch.from_numpy(p[1]).to(dev, tdt).contiguous() for p in host_pairs]
+        var_of = lambda i: (rank * nsteps + i) % nvar
+    flo = torch.empty((max(slots, in_flight, 1), ny, nx, 2), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
-    def step(i, c_=None):
-        c_ = c_ or ctx
-        v = var_of(i)
-        c_.tvl1_multiscale_dev(dI0s[v].data_ptr(), dI1s[v].data_ptr(), flo[i % flo.shape[0]].data_ptr(), nx, ny, **PAR)
-        return c_.stats().work_pix_iters
-
-    def run_steps(n):
-        """n steps (pairs) through the library's batch entry point: the pairs are cut into lockstep groups of
-        `lockstep` pairs that share every kernel launch; group q runs on context q % nstreams (one host thread +
-        one HIP stream each, inside libofx), so while one group waits for a convergence poll another one fills
-        the GPU."""
-        if in_flight == 1:
-            return sum(step(i) for i in range(n))
-        work = ofx_mod.tvl1_batch_dev(ctxs, [dI0s[var_of(i)].data_ptr() for i in range(n)],
-                                      [dI1s[var_of(i)].data_ptr() for i in range(n)],
-                                      [flo[i % flo.shape[0]].data_ptr() for i in range(n)], nx, ny, **PAR)
+    def run_pairs(first, cnt):
+        """pairs [first, first + cnt) of this rank through the library's batch entry point: cut into lockstep groups of
+        `lockstep` pairs that share every kernel launch; group q runs on context q % nstreams (one host thread + one
+        HIP stream each, inside libofx).  Blocking: returns when every flow is in `flo`."""
+        if cnt <= 0:
+            return 0.0
+        idx = range(first, first + cnt)
+        work = ofx_mod.tvl1_batch_dev(ctxs, [dI0s[var_of(i)].data_ptr() for i in idx],
+                                      [dI1s[var_of(i)].data_ptr() for i in idx],
+                                      [flo[i % flo.shape[0]].data_ptr() for i in idx], nx, ny, **PAR)
         return sum(work)
 
     def fence():
@@ -213,122 +378,161 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    log("rank %d/%d: inputs resident, warmup" % (rank, world))
+    log("rank %d/%d: %d pairs %dx%d resident, rounds %s, lockstep %d x %d contexts; warmup"
+        % (rank, world, nsteps, nx, ny, [c for _, c in rounds], lockstep, nstreams))
     for i in range(a.warmup):
-        run_steps(in_flight)
+        run_pairs(0, min(in_flight, max(nsteps, 1)))
     log("warmup done")
     gathered = None
     if world > 1 and rank == 0:
-        gathered = [torch.empty_like(flo) for _ in range(world)]
+        gathered = [[torch.empty((cnt, ny, nx, 2), dtype=torch.float32, device=dev) for _ in range(world)] for _, cnt in rounds]
+    if world > 1:
+        # one throw-away gather: RCCL sets up its channels on first use, which is not part of the steady state
+        w_ = dist.gather(flo[:1], [torch.empty_like(flo[:1]) for _ in range(world)] if rank == 0 else None, dst=0)
     fence()
     t0 = time.perf_counter()
-    work = run_steps(a.steps)
-    for c_ in ctxs:
-        c_.synchronize()
-    if world > 1:
-        dist.gather(flo, gathered, dst=0)       # the one collective: .flo payloads to rank 0 over xGMI (RCCL)
+    work, pending = 0.0, []
+    for r, (first, cnt) in enumerate(rounds):
+        work += run_pairs(first, min(cnt, nsteps - first))   # returns with the round's flows complete in HBM
+        if world > 1:
+            # strong scaling: a rank may own one pair fewer than `slots`; the gather buffers have the same size on
+            # every rank (rounds are cut from the slot count), rank 0 ignores the unused tail slots
+            pending.append(dist.gather(flo[first:first + cnt], gathered[r] if rank == 0 else None, dst=0, async_op=True))
+    t_compute = time.perf_counter() - t0
+    for w_ in pending:
+        w_.wait()
     fence()
     elapsed = time.perf_counter() - t0
-    log("timed region: %d steps in %.3f s" % (a.steps, elapsed))
+    gather_ms = (elapsed - t_compute) * 1e3
+    log("timed region: %d pairs in %.3f s (exposed gather %.2f ms)" % (nsteps, elapsed, gather_ms))
 
+    gather_check = None
+    if a.check and world > 1 and rank == 0:
+        # every flow is a deterministic function of its pair (lockstep groups are bit-identical to solo solves), so
+        # rank 0 can recompute what each rank must have sent
+        tmp = torch.empty((ny, nx, 2), dtype=torch.float32, device=dev)
+        n_checked = 0
+        for q in range(world):
+            q_pairs = batch.pairs_of_rank(total_steps, world, q) if strong else list(range(q * nsteps, (q + 1) * nsteps))
+            for i, k in enumerate(q_pairs):
+                if strong:
+                    i0, i1 = synth.pair_device(a.pair, nx, ny, k, dev, tdt)
+                else:
+                    i0, i1 = dI0s[k % nvar], dI1s[k % nvar]
+                ctx.tvl1_multiscale_dev(i0.data_ptr(), i1.data_ptr(), tmp.data_ptr(), nx, ny, **PAR)
+                ctx.synchronize()
+                r = max(j for j, (f_, _) in enumerate(rounds) if f_ <= i)
+                got = gathered[r][q][i - rounds[r][0]]
+                if not torch.equal(got.view(torch.int32), tmp.view(torch.int32)):
+                    raise SystemExit("gather check FAILED: rank %d slot %d (pair %d)" % (q, i, k))
+                n_checked += 1
+        gather_check = "ok: %d payloads from %d ranks byte-identical to rank 0's own solves" % (n_checked, world)
+        log("gather check " + gather_check)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, gather_ms], dtype=torch.float64, device=dev)
         w = torch.tensor([work], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
-        elapsed, work = float(t.item()), float(w.item())
+        elapsed, gather_ms, work = float(t[0].item()), float(t[1].item()), float(w.item())
 
     # ---- fixed-work pass + roofline (rank 0's numbers are reported; every rank runs it to stay in step) ----
-    fixed, roof = None, None
-    if a.fixed_steps > 0:
+    fixed, roof, roof4k = None, None, None
+    if a.fixed_steps > 0 and nsteps > 0:
         # (a) throughput of the fixed-work job with the same number of pairs in flight as the headline
         for c_ in ctxs:
             c_.set_option("fixed_work", 1)
-        run_steps(in_flight)                                 # warm
+        nfw = min(in_flight, nsteps)
+        run_pairs(0, nfw)                                # warm
         fence()
         tq0 = time.perf_counter()
-        fw_par = run_steps(a.fixed_steps * in_flight)
+        fw_par = sum(run_pairs(0, nfw) for _ in range(a.fixed_steps))
         fence()
         tq = time.perf_counter() - tq0
-        # (b) one pair alone with HIP events around the iteration launches: per-kernel times for the roofline
-        ctx.set_option("concurrency", 1)
-        ctx.set_option("profile", 1)
-        step(0)                                              # warm
-        ctx.synchronize()
-        tf0 = time.perf_counter()
-        fw, it_ms, it_n = 0.0, 0.0, 0
-        lv_ms, lv_n = [0.0] * PAR["nscales"], [0] * PAR["nscales"]
-        for i in range(a.fixed_steps):
-            fw += step(0)
-            st = ctx.stats()
-            it_ms += st.iter_ms[0]
-            it_n += st.iter_launches[0]
-            for s_ in range(PAR["nscales"]):
-                lv_ms[s_] += st.iter_ms[s_]
-                lv_n[s_] += st.iter_launches[s_]
-        ctx.synchronize()
-        tf = time.perf_counter() - tf0
         for c_ in ctxs:
             c_.set_option("fixed_work", 0)
-        ctx.set_option("profile", 0)
+
+        # (b) one pair alone with HIP events around the iteration launches: per-kernel times for the roofline
+        def one():
+            ctx.tvl1_multiscale_dev(dI0s[0].data_ptr(), dI1s[0].data_ptr(), flo[0].data_ptr(), nx, ny, **PAR)
+            return ctx.stats().work_pix_iters
+        roof, levels, fw, tf = roofline_of(ctx, one, a.precision, nx, ny, a.fixed_steps)
         ctx.set_option("concurrency", a.concurrency or nstreams)
         log("fixed-work pass: %d steps in %.3f s" % (a.fixed_steps, tf))
         fixed = {"value": round(fw_par / tq / 1e6, 1), "unit": "Mpix*warp-iters/s",
-                 "ms_per_step": round(tq / (a.fixed_steps * in_flight) * 1e3, 3), "steps": a.fixed_steps * in_flight,
-                 "pairs_in_flight": in_flight, "iterations_per_warp": 300,
+                 "ms_per_step": round(tq / (a.fixed_steps * nfw) * 1e3, 3), "steps": a.fixed_steps * nfw,
+                 "pairs_in_flight": nfw, "iterations_per_warp": 300,
                  "single_pair": {"value": round(fw / tf / 1e6, 1), "ms_per_step": round(tf / a.fixed_steps * 1e3, 3)},
-                 "levels": [{"size": "%dx%d" % (st.nx[s_], st.ny[s_]), "iter_us": round(lv_ms[s_] * 1e3 / max(lv_n[s_], 1), 2),
-                             "ms_per_step": round(lv_ms[s_] / a.fixed_steps, 2)} for s_ in range(PAR["nscales"])]}
-        us = it_ms * 1e3 / max(it_n, 1)                       # per ITERATION (stats count iterations)
-        ach = BYTES_PER_PIX_ITER[prec] * nx * ny / (us * 1e-6) / 1e9
-        # the dominant kernel is k_tvl1_iter2: TWO iterations per launch
-        roof = {"bound": "hbm", "kernel": "k_tvl1_iter2<%s> @ %dx%d (2 fused iterations per launch)"
-                                          % ("double" if prec == 0 else "float", nx, ny),
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "avg_launch_us": round(2 * us, 3), "launches": int(it_n // 2),
-                "algorithmic_bytes_per_launch": 2 * BYTES_PER_PIX_ITER[prec] * nx * ny,
-                "algorithmic_bytes_per_pixel_iteration": BYTES_PER_PIX_ITER[prec],
-                "mpix_iters_per_s": round(nx * ny / us, 1)}
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
-            try:
-                roof["traffic"] = json.load(open(prof)).get("bytes_per_launch_%s_%dx%d" % (a.precision, nx, ny))
-            except Exception:
-                pass
+                 "levels": levels}
+        # (c) the same measurement at 3840x2160 (north_star: ">= 60 % of peak HBM at 4K"), one pair, one pass
+        if rank == 0 and world == 1 and not a.no_4k and (nx, ny) != (3840, 2160):
+            j0, j1 = synth.pair_device(a.pair, 3840, 2160, 1, dev, tdt)
+            f4 = torch.empty((2160, 3840, 2), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
 
-    cpu, _ = (None, None)
+            def one4k():
+                ctx.tvl1_multiscale_dev(j0.data_ptr(), j1.data_ptr(), f4.data_ptr(), 3840, 2160, **PAR)
+                return ctx.stats().work_pix_iters
+            roof4k, lv4, fw4, tf4 = roofline_of(ctx, one4k, a.precision, 3840, 2160, 1)
+            roof4k["single_pair_fixed_work"] = {"value": round(fw4 / tf4 / 1e6, 1), "unit": "Mpix*warp-iters/s", "levels": lv4}
+            ctx.set_option("concurrency", a.concurrency or nstreams)
+            del j0, j1, f4
+            log("4K fixed-work pass: %.3f s" % tf4)
+        elif (nx, ny) == (3840, 2160):
+            roof4k = None
+
+    sor = None
+    if rank == 0 and world == 1 and not a.no_sor:
+        sor = sor_leg(ofx_mod, synth, local)
+        log("sor leg done")
+    cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
-        cpu, _ = cpu_baseline(synth, nx, ny, a.pair)
+        cnx, cny = WORKLOADS["1080p"] if strong else (nx, ny)
+        cpu = cpu_baseline(synth, cnx, cny, a.pair)
 
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
         return
+    npairs_job = total_steps if strong else nsteps * world
+    if strong:
+        wl = ("tvl1flow batch of %d distinct synthetic %dx%d pairs (%s, batch variants k = 0..%d), pair k on rank k mod %d, "
+              "nscales=5 warps=5 tau=0.25 lambda=0.15 theta=0.3 zfactor=0.5 epsilon=0.01" % (total_steps, nx, ny, a.pair, total_steps - 1, world))
+    else:
+        wl = ("tvl1flow %dx%d pair (synthetic %s), nscales=5 warps=5 tau=0.25 lambda=0.15 theta=0.3 zfactor=0.5 epsilon=0.01; "
+              "one pair per step per GPU" % (nx, ny, a.pair))
     line = {
         "metric": "Mpix*warp-iters/s, TV-L1 %dx%d 5-scale" % (nx, ny),
         "value": round(work / elapsed / 1e6, 1),
         "unit": "Mpix*warp-iters/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(elapsed / max(a.steps, 1) * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "n_gpus": world, "steps": total_steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / max(nsteps if not strong else total_steps, 1) * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": a.precision, "data": "synthetic",
-        "config": {"workload": "tvl1flow %dx%d pair (synthetic %s), nscales=5 warps=5 tau=0.25 lambda=0.15 theta=0.3 "
-                               "zfactor=0.5 epsilon=0.01; one pair per step per GPU" % (nx, ny, a.pair),
-                   "pairs_per_gpu": a.steps, "pairs_in_flight_per_gpu": in_flight, "lockstep_group": lockstep,
-                   "streams_per_gpu": nstreams, "distinct_pairs": nvar,
-                   "parallelism": "%d GPU(s) x %d HIP stream(s) x lockstep groups of %d pairs, RCCL gather of .flo at end"
-                                  % (world, nstreams, lockstep),
-                   "pix_iters_per_step": work / max(a.steps, 1) / world},
-        "pairs_per_s": round(a.steps * world / elapsed, 3),
+        "config": {"workload": wl, "workload_name": a.workload,
+                   "pairs_per_gpu": slots, "pairs_in_flight_per_gpu": min(in_flight, max(nsteps, 1)), "lockstep_group": lockstep,
+                   "streams_per_gpu": nstreams, "distinct_pairs": total_steps if strong else nvar,
+                   "rounds_per_gpu": [c for _, c in rounds],
+                   "parallelism": "%d GPU(s) x %d HIP stream(s) x lockstep groups of %d pairs; RCCL gather of the .flo payloads "
+                                  "per round, overlapped with the next round" % (world, nstreams, lockstep),
+                   "pix_iters_per_step": work / max(npairs_job, 1)},
+        "pairs_per_s": round(npairs_job / elapsed, 3),
+        "gather_ms": round(gather_ms, 3) if world > 1 else 0.0,
     }
+    if gather_check:
+        line["gather_check"] = gather_check
     if fixed:
         line["fixed_work"] = fixed
     if roof:
         line["roofline"] = roof
+    if roof4k:
+        line["roofline_4k"] = roof4k
+    if sor:
+        line["sor"] = sor
     if cpu:
         line["cpu_baseline"] = cpu
     print(json.dumps(line))
+    sys.stdout.flush()
 
 
 if __name__ == "__main__":

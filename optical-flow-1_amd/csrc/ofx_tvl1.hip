@@ -85,6 +85,9 @@ template <typename T>
 OFX_DEV double2 tvl1_primal(double2 u, double2 a, double r, double2 p1, double2 p2, double l11, double l21, double up12,
                             double up22, bool lef, bool rig, bool top, bool bot, double l_t, double theta)
 {
+#ifdef OFX_CEIL_MEM   // ceiling experiment (tools/ceilings.sh): memory traffic and lane shifts kept, arithmetic replaced by a copy
+    return make_double2(u.x + 1e-300 * (a.x + r + p1.x + l11 + up12), u.y + 1e-300 * (a.y + p2.x + p1.y + p2.y + l21 + up22));
+#endif
     const double div1 = div_backward(p1.x, l11, p1.y, up12, lef, rig, top, bot);
     const double div2 = div_backward(p2.x, l21, p2.y, up22, lef, rig, top, bot);
     const double ix = a.x, iy = a.y;
@@ -113,6 +116,11 @@ template <typename T>
 OFX_DEV void tvl1_dual(double2 p1, double2 p2, double2 un, double r1, double r2, double2 dn, bool rig, bool lastrow,
                        double taut, double2 &q1, double2 &q2)
 {
+#ifdef OFX_CEIL_MEM
+    q1 = make_double2(p1.x + 1e-300 * (un.x + r1), p1.y + 1e-300 * dn.x);
+    q2 = make_double2(p2.x + 1e-300 * (un.y + r2), p2.y + 1e-300 * dn.y);
+    return;
+#endif
     const double u1x = rig ? 0.0 : r1 - un.x;
     const double u2x = rig ? 0.0 : r2 - un.y;
     const double u1y = lastrow ? 0.0 : dn.x - un.x;
@@ -346,6 +354,9 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
     const unsigned E2 = 2 * sizeof(T);                      // bytes per pixel of the pair arrays
     const unsigned row2 = (unsigned) nx * E2;
     unsigned off = ((unsigned) ys * nx + cc) * E2;          // byte offset of (y, cc): loads
+#ifdef OFX_CEIL_ALU
+    const unsigned off0 = off;
+#endif
     unsigned so = ((unsigned) ys * nx + (c < 0 ? 0 : c)) * E2;   // ... of (y, c): stores (owner lanes only)
 
     double up12 = 0.0, up22 = 0.0;                           // p12 / p22 (iteration k-1) of row y-1
@@ -373,7 +384,11 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
 
     for (int y = ys; y <= yend + 2; y++) {
         RowIn<T> nxt = cur;
+#ifdef OFX_CEIL_ALU   // ceiling experiment (tools/ceilings.sh): arithmetic kept, loads alternate between the strip's first two rows
+        if (y + 1 <= yl) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off0 + (((unsigned) (y + 1 - ys)) & 1u) * row2);
+#else
         if (y + 1 <= yl) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + row2);
+#endif
 
         // S1: u_A(y)
         const bool have1 = (y <= yl);
@@ -414,6 +429,9 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
             tvl1_dual<T>(pA2a, pA2b, uB1, n1, n2, uB0, rig, y - 3 == ny - 1, taut, q1, q2);
             if (owner) st4 = so - 3 * row2;
         }
+#ifdef OFX_CEIL_ALU   // ceiling experiment: every store dropped (still issued, out of range), loads stay on the first row
+        st3 = OFX_OOB; st4 = OFX_OOB;
+#endif
         // the three stores of this step: always issued, lanes / steps with nothing to write are out of range
         bst2<NT>(rU, st3, uB0, Uout);
         bst2<NT>(rP1, st4, q1, P1out);

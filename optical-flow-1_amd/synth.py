@@ -78,3 +78,40 @@ def sequence(nx, ny, frames, k=0):
         out[t] = np.floor(np.where(fg(j - t * mx, i - t * my), tex_f(j - t * mx, i - t * my),
                                    tex_b(j - 0.6 * t * fx, i - 0.6 * t * fy)))
     return out
+
+
+def pair_device(name, nx, ny, k, device, dtype=None):
+    """pair(name, nx, ny, k) evaluated with torch on `device` (float64 arithmetic, same formulas): the 64 distinct
+    3840x2160 pairs of BASELINE config 5 take minutes in numpy and a moment on the GPU.  The device's sin / cos may
+    differ from libm's in the last bit, which can move floor() at isolated pixels -- fine for benchmark inputs;
+    parity tests use pair()."""
+    import torch
+    f64 = torch.float64
+    i, j = torch.meshgrid(torch.arange(ny, dtype=f64, device=device), torch.arange(nx, dtype=f64, device=device), indexing="ij")
+    fx, fy = 1.5 + 0.5 * torch.sin(0.01 * i), -0.75 + 0.25 * torch.cos(0.013 * j)
+
+    def tex(x, y, phase=0.3):
+        return (127.5 + 40 * torch.sin(0.11 * x + phase) * torch.cos(0.07 * y) + 30 * torch.sin(0.031 * x + 0.043 * y)
+                + 25 * torch.cos(0.19 * y - 0.05 * x) + 20 * torch.sin(0.37 * x) * torch.sin(0.29 * y))
+
+    if name == "P0":
+        I0, I1 = torch.floor(tex(j, i)), torch.floor(tex(j - fx, i - fy))
+    elif name == "P1":
+        phase = 0.3 + 0.1 * k
+        mx, my = 4 + (k % 3), -3
+
+        def tex_b(x, y):
+            return tex(x, y, phase) + 15 * torch.sin(1.3 * x) * torch.cos(1.1 * y)
+
+        def tex_f(x, y):
+            return 127.5 + 60 * torch.sin(0.9 * x + 0.4 * y) + 50 * torch.cos(0.7 * y - 0.3 * x)
+
+        def fg(x, y):
+            return (x >= nx // 4) & (x < nx // 2) & (y >= ny // 4) & (y < ny // 2)
+
+        I0 = torch.floor(torch.where(fg(j, i), tex_f(j, i), tex_b(j, i)))
+        I1 = torch.floor(torch.where(fg(j - mx, i - my), tex_f(j - mx, i - my), tex_b(j - fx, i - fy)))
+    else:
+        raise ValueError(name)
+    dtype = dtype or f64
+    return I0.to(dtype).contiguous(), I1.to(dtype).contiguous()

@@ -75,6 +75,37 @@ def test_brox_exact(gpu64, orc, synth, pair, nx, ny, ns):
     assert np.abs(ug - ur).max() < 1e-11 and np.abs(vg - vr).max() < 1e-11
 
 
+# ---- BASELINE.json configs 3 and 4 at full size, against the single-thread oracle (its only deterministic mode) ------
+@pytest.mark.timeout(600)
+def test_cfg3_hs_1080p_full_size_matches_oracle(gpu64, orc, synth):
+    """BASELINE configs[2]: horn_schunck_pyramidal 1920x1080, alpha=20 nscales=5 warps=10 (~4-9 s of CPU).
+    SURVEY 8c anchor: 1004 sweeps, mean(u, v) = (1.556167, -0.751293) on P0."""
+    I1, I2 = synth.pair("P0", 1920, 1080)
+    kw = dict(alpha=20.0, nscales=5, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150)
+    ur, vr, it_r = orc.hs_pyramidal(I1, I2, **kw)
+    ug, vg = gpu64.hs_pyramidal(I1, I2, **kw)
+    assert np.array_equal(gpu64.stats().iterations(), it_r)
+    assert int(np.asarray(it_r).sum()) == 1004
+    assert abs(ug.mean() - 1.556167) < 1e-6 and abs(vg.mean() + 0.751293) < 1e-6
+    assert aepe(ug, vg, ur, vr) < 1e-4
+    assert np.abs(ug - ur).max() < 1e-12 and np.abs(vg - vr).max() < 1e-12
+
+
+@pytest.mark.timeout(600)
+def test_cfg4_brox_720p_full_size_matches_oracle(gpu64, orc, synth):
+    """BASELINE configs[3]: brox_optic_flow_spatial 1280x720, default alpha / gamma -> 6 scales, inner 1, outer 15
+    (~3-8 s of CPU).  SURVEY 8c anchor: 1764 sweeps, mean(u, v) = (1.526222, -0.762388) on P0."""
+    I1, I2 = synth.pair("P0", 1280, 720)
+    kw = dict(alpha=50.0, gamma=10.0, nscales=6, nu=0.5, TOL=1e-4, inner=1, outer=15)
+    ur, vr, it_r = orc.brox_spatial(I1, I2, **kw)
+    ug, vg = gpu64.brox_spatial(I1, I2, **kw)
+    assert np.array_equal(gpu64.stats().iterations(), it_r)
+    assert int(np.asarray(it_r).sum()) == 1764
+    assert abs(ug.mean() - 1.526222) < 1e-6 and abs(vg.mean() + 0.762388) < 1e-6
+    assert aepe(ug, vg, ur, vr) < 1e-4
+    assert np.abs(ug - ur).max() < 1e-12 and np.abs(vg - vr).max() < 1e-12
+
+
 @pytest.mark.parametrize("pair,nx,ny", [("P0", 64, 48), ("P1", 135, 68), ("P1", 33, 47)])
 def test_hs_single_scale_same_order(gpu64, colour_orc, synth, pair, nx, ny):
     I1, I2 = synth.pair(pair, nx, ny)

@@ -145,6 +145,23 @@ def test_full_size_1080p_matches_oracle(gpu64, oracle_mod, synth):
     assert np.abs(ug - uo).max() < 1e-9 and np.abs(vg - vo).max() < 1e-9
 
 
+@pytest.mark.timeout(900)
+def test_full_size_4k_warps5_matches_oracle(gpu64, oracle_mod, synth):
+    """BASELINE configs[4] size, the reference's parameters (warps=5): one 3840x2160 pair against the oracle on every
+    host core (TV-L1 has no racy loop; ~30 s of CPU)."""
+    o = oracle_mod.Oracle()
+    o.set_num_threads(min(oracle_mod.host_cores(), 32))
+    I0, I1 = synth.pair("P1", 3840, 2160, 1)
+    try:
+        uo, vo, it_o, _ = o.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+    finally:
+        o.set_num_threads(1)
+    ug, vg = gpu64.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+    assert np.array_equal(gpu64.stats().iterations(), it_o)
+    assert aepe(ug, vg, uo, vo) < 1e-4
+    assert np.abs(ug - uo).max() < 1e-9 and np.abs(vg - vo).max() < 1e-9
+
+
 def test_4k_size_independent_properties(gpu64, synth):
     """config 5 size (3840x2160), where the oracle is too slow for the suite: (i) the fused two-iteration
     kernel and the one-iteration kernel give bit-identical flows and iteration counts, for any strip

@@ -222,3 +222,35 @@ def test_png_input_follows_iio_semantics(io, tmp_path):
     assert not io.ofx_read_image_double(str(tmp_path / "rgba.png").encode(), C.byref(wv), C.byref(hv))
     (tmp_path / "broken.png").write_bytes(open(tmp_path / "g8.png", "rb").read()[:40])
     assert not io.ofx_read_image_double(str(tmp_path / "broken.png").encode(), C.byref(wv), C.byref(hv))
+
+
+def test_bench_round_split_and_self_launch_command(monkeypatch):
+    """bench.py: rounds are a partition with the last round ~1/4 (multiple of the contexts); N > 1 without a launcher
+    starts torch.distributed.run as a child BEFORE torch is imported."""
+    import bench
+    for n in (1, 2, 3, 5, 8, 20, 64):
+        for r in (1, 2, 3):
+            sl = bench.split_rounds(n, r, 4)
+            assert sl[0][0] == 0 and sum(c for _, c in sl) == n and all(c >= 1 for _, c in sl)
+            assert all(sl[i][0] + sl[i][1] == sl[i + 1][0] for i in range(len(sl) - 1))
+    assert bench.split_rounds(64, 2, 4) == [(0, 48), (48, 16)]
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20"])
+
+    class A:
+        gpus = 4
+
+    assert bench.self_launch(A()) == 7
+    c = seen["cmd"]
+    assert c[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in c and c[c.index("--nproc-per-node") + 1] == "4"
+    assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-4:] == ["--gpus", "4", "--steps", "20"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
