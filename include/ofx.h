@@ -51,7 +51,9 @@ extern "C" {
 #define OFX_TVL1_MAX_ITERATIONS 300   /* src/tvl1flow.cpp:22  */
 #define OFX_BROX_MAX_ITERATIONS 300   /* src/brox_optic_flow_spatial.cpp:24 */
 #define OFX_HS_MAX_MAXITER 65536      /* largest Horn-Schunck `maxiter` accepted (reference: unbounded) */
-#define OFX_MAX_SCALES 32
+#define OFX_MAX_SCALES 32             /* pyramid levels ofx_stats RECORDS; the solvers accept any number of levels
+                                         (e.g. tvl1flow with zfactor = 0.9 at 1080p uses 47), levels >= 32 are solved
+                                         but not itemised in the record (work_pix_iters still counts them)       */
 #define OFX_MAX_SOLVES 64             /* warps (TV-L1, HS) or outer*inner solves (Brox) per scale */
 
 typedef struct ofx_ctx ofx_ctx;
@@ -95,6 +97,8 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *   "warp_lds"       1/0  TV-L1 warp with the bicubic taps staged through LDS (default 1)
  *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default 0 = ofx_tvl1_batch_group_size's
  *                         rule: as large as possible, evened out over the contexts; at most 16)
+ *   "mem_budget"     bytes the level arrays of all contexts of a batch may occupy when the group size is chosen
+ *                         (default 0 = half of the device memory that is free at the time of the call)
  *   "concurrency"    number of contexts that will be solving on the same device at the same time
  *                         (default 1); a scheduling hint for the strip height of the TV-L1 kernels
  *   "rows_per_wave", "rows_per_wave2", "chunk"   tuning of the TV-L1 kernels / launch batching */
@@ -183,7 +187,8 @@ int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI0, 
 
 /* Group size ofx_tvl1_batch_dev picks for this batch: the "lockstep" option of ctxs[0] if > 0, else the batch
  * is spread over the fewest rounds a group of 16 (less if device memory is short) allows, one group per
- * context and round, with the groups evened out.  Returns the size (>= 1) or a negative status. */
+ * context and round, with the groups evened out.  Returns the size (>= 1), or -status (e.g. -OFX_ERR_ARG,
+ * -OFX_ERR_SIGMA for a pyramid that cannot be built) on error. */
 int ofx_tvl1_batch_group_size(ofx_ctx *const *ctxs, int n_ctx, int n_pairs, int nx, int ny, int nscales,
                               double zfactor);
 
@@ -202,6 +207,21 @@ int ofx_hs_pyramidal(ofx_ctx *ctx, const double *I1, const double *I2, double *u
                      int nx, int ny, double alpha, int nscales, double zfactor, int warps,
                      double TOL, int maxiter, int verbose);
 
+/* Device-resident lockstep groups / batches of the SOR solvers, the counterparts of ofx_tvl1_group_dev and
+ * ofx_tvl1_batch_dev (same pointer layout: n_pairs device images of the context's storage precision in, n_pairs
+ * .flo payloads of nx*ny interleaved (u,v) float32 out).  The pairs of a group share every launch of the windowed
+ * exact sweeps (blockIdx.z = pair) -- a lone solve is a latency chain of thousands of dependent steps with little
+ * work each -- while every pair keeps its own error slots, snapshots, sweep counts and stopping test: each flow is
+ * bit-identical to the one ofx_hs_pyramidal / ofx_brox_spatial compute for that pair alone.  Groups need the
+ * default option sor_exact = 1.  The group size of the batch calls is option "lockstep" of ctxs[0] if > 0, else
+ * as large as possible (<= 16), evened out over the contexts. */
+int ofx_hs_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *dI1, const void *const *dI2, void *const *d_flo,
+                     int nx, int ny, double alpha, int nscales, double zfactor, int warps, double TOL, int maxiter,
+                     ofx_stats *stats_out);
+int ofx_hs_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI1, const void *const *dI2,
+                     void *const *d_flo, int n_pairs, int nx, int ny, double alpha, int nscales, double zfactor,
+                     int warps, double TOL, int maxiter, double *work_pix_iters);
+
 /* classic Horn-Schunck (replace src/horn_schunck.h:7-8, src/horn_schunck_classic.cpp:125-149): niter Jacobi
  * iterations from a zero flow; a / b are the two images, w x h */
 int ofx_hs_classic(ofx_ctx *ctx, const double *a, const double *b, double *u, double *v, int w, int h, int niter,
@@ -211,6 +231,13 @@ int ofx_hs_classic(ofx_ctx *ctx, const double *a, const double *b, double *u, do
 int ofx_brox_spatial(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v,
                      int nxx, int nyy, double alpha, double gamma, int nscales, double nu,
                      double TOL, int inner_iter, int outer_iter, int verbose);
+
+int ofx_brox_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *dI1, const void *const *dI2, void *const *d_flo,
+                       int nxx, int nyy, double alpha, double gamma, int nscales, double nu, double TOL,
+                       int inner_iter, int outer_iter, ofx_stats *stats_out);
+int ofx_brox_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI1, const void *const *dI2,
+                       void *const *d_flo, int n_pairs, int nxx, int nyy, double alpha, double gamma, int nscales,
+                       double nu, double TOL, int inner_iter, int outer_iter, double *work_pix_iters);
 
 /* ---- Brox temporal (replace src/brox_optic_flow.h:41-55) ---------------------------*/
 /* I: `frames` images of nx*ny, frame-major; u, v: frames - 1 flow fields (u[f] takes frame f to frame f + 1).

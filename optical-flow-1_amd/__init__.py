@@ -113,6 +113,14 @@ def lib():
         "ofx_hs_single_scale": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _i]),
         "ofx_hs_pyramidal": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _i, _d, _i, _d, _i, _i]),
         "ofx_brox_spatial": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
+        "ofx_hs_group_dev": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _d, _i, _d, _i, _d, _i,
+                                  C.POINTER(Stats)]),
+        "ofx_hs_batch_dev": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _d, _i, _d,
+                                  _i, _d, _i, C.POINTER(_d)]),
+        "ofx_brox_group_dev": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _d, _d, _i, _d, _d, _i,
+                                    _i, C.POINTER(Stats)]),
+        "ofx_brox_batch_dev": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _d, _d, _i,
+                                    _d, _d, _i, _i, C.POINTER(_d)]),
         "ofx_hs_classic": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _d]),
         "ofx_brox_temporal": (_i, [_vp, _dp, _dp, _dp, _i, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
     }
@@ -151,6 +159,27 @@ def tvl1_batch_dev(ctxs, dI0, dI1, d_flo, nx, ny, tau=0.25, lam=0.15, theta=0.3,
     if s:
         raise OfxError(s, "; ".join((c.L.ofx_last_error(c.h) or b"").decode() for c in ctxs))
     return [work[i] for i in range(n)]
+
+
+def _batch_call(fn, ctxs, dA, dB, d_flo, *args):
+    n = len(dA)
+    arr = lambda xs: (_vp * max(len(xs), 1))(*xs)
+    work = (_d * max(n, 1))()
+    s = fn(arr([c.h.value for c in ctxs]), len(ctxs), arr(dA), arr(dB), arr(d_flo), n, *args, work)
+    if s:
+        raise OfxError(s, "; ".join((c.L.ofx_last_error(c.h) or b"").decode() for c in ctxs))
+    return [work[i] for i in range(n)]
+
+
+def hs_batch_dev(ctxs, dI1, dI2, d_flo, nx, ny, alpha=7.0, nscales=10, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150):
+    """ofx_hs_batch_dev: lists of device pointers (ints), one entry per pair; lockstep groups on ctxs[q % len(ctxs)].
+    Returns the per-pair work (pixel-sweeps)."""
+    return _batch_call(lib().ofx_hs_batch_dev, ctxs, dI1, dI2, d_flo, nx, ny, alpha, nscales, zfactor, warps, TOL, maxiter)
+
+
+def brox_batch_dev(ctxs, dI1, dI2, d_flo, nx, ny, alpha=50.0, gamma=10.0, nscales=10, nu=0.5, TOL=1e-4, inner=1, outer=15):
+    """ofx_brox_batch_dev (see hs_batch_dev)"""
+    return _batch_call(lib().ofx_brox_batch_dev, ctxs, dI1, dI2, d_flo, nx, ny, alpha, gamma, nscales, nu, TOL, inner, outer)
 
 
 def tvl1_batch_group_size(ctxs, n_pairs, nx, ny, nscales=5, zfactor=0.5):
@@ -301,6 +330,21 @@ class Ofx:
         self._ck(self.L.ofx_tvl1_group_dev(self.h, n, arr(dI0), arr(dI1), arr(d_flo), nx, ny, tau, lam, theta, nscales,
                                            zfactor, warps, epsilon, st))
         return [st[i] for i in range(n)]
+
+    def _group_call(self, fn, dA, dB, d_flo, *args):
+        n = len(dA)
+        arr = lambda xs: (_vp * max(len(xs), 1))(*xs)
+        st = (Stats * max(n, 1))()
+        self._ck(fn(self.h, n, arr(dA), arr(dB), arr(d_flo), *args, st))
+        return [st[i] for i in range(n)]
+
+    def hs_group_dev(self, dI1, dI2, d_flo, nx, ny, alpha=7.0, nscales=10, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150):
+        """ofx_hs_group_dev: all pairs solved in lockstep on this context; returns the per-pair Stats records"""
+        return self._group_call(self.L.ofx_hs_group_dev, dI1, dI2, d_flo, nx, ny, alpha, nscales, zfactor, warps, TOL, maxiter)
+
+    def brox_group_dev(self, dI1, dI2, d_flo, nx, ny, alpha=50.0, gamma=10.0, nscales=10, nu=0.5, TOL=1e-4, inner=1, outer=15):
+        """ofx_brox_group_dev (see hs_group_dev)"""
+        return self._group_call(self.L.ofx_brox_group_dev, dI1, dI2, d_flo, nx, ny, alpha, gamma, nscales, nu, TOL, inner, outer)
 
     def tvl1_iterations(self, u1, u2, p11, p12, p21, p22, I1wx, I1wy, rho_c, tau, lam, theta, n_iter):
         """In place on the six state arrays (float64, C-contiguous); returns the last error."""

@@ -42,6 +42,8 @@ extern "C" int ofx_device_count(void)
     return n;
 }
 
+extern "C" void ofx_ctx_destroy(ofx_ctx *ctx);
+
 extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
 {
     if (!out) return OFX_ERR_ARG;
@@ -71,10 +73,17 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->sor_batch = 0;
     ctx->sor_window = 0;
     ctx->sor_rows = 0;
+    ctx->mem_budget = 0;
     ctx->poll_seq = 0;
     ctx->errmsg[0] = 0;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
 
+    ctx->stream = nullptr;
+    ctx->d_err = nullptr;
+    ctx->d_state = nullptr;
+    ctx->h_state = nullptr;
+    ctx->ev_t0 = ctx->ev_t1 = nullptr;
+    for (int i = 0; i < OFX_NPOLL; i++) ctx->ev_poll[i] = nullptr;
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc((void **) &ctx->d_err, sizeof(double) * OFX_TVL1_MAX_ITERATIONS * OFX_NSHARD) == hipSuccess;
     ctx->d_err_cap = OFX_TVL1_MAX_ITERATIONS;
@@ -85,7 +94,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ok = ok && hipEventCreate(&ctx->ev_t0) == hipSuccess && hipEventCreate(&ctx->ev_t1) == hipSuccess;
     if (!ok) {
         (void) hipGetLastError();
-        delete ctx;          // leaks the partial HIP objects of a failed init; the process is about to give up anyway
+        ofx_ctx_destroy(ctx);        // every handle is either valid or still null
         return OFX_ERR_HIP;
     }
     *out = ctx;
@@ -96,15 +105,17 @@ extern "C" void ofx_ctx_destroy(ofx_ctx *ctx)
 {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
-    (void) hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->slabs) (void) hipFree(s.base);
-    (void) hipFree(ctx->d_err);
-    (void) hipFree(ctx->d_state);
-    (void) hipHostFree(ctx->h_state);
-    for (int i = 0; i < OFX_NPOLL; i++) (void) hipEventDestroy(ctx->ev_poll[i]);
-    (void) hipEventDestroy(ctx->ev_t0);
-    (void) hipEventDestroy(ctx->ev_t1);
-    (void) hipStreamDestroy(ctx->stream);
+    if (ctx->d_err) (void) hipFree(ctx->d_err);
+    if (ctx->d_state) (void) hipFree(ctx->d_state);
+    if (ctx->h_state) (void) hipHostFree(ctx->h_state);
+    for (int i = 0; i < OFX_NPOLL; i++)
+        if (ctx->ev_poll[i]) (void) hipEventDestroy(ctx->ev_poll[i]);
+    if (ctx->ev_t0) (void) hipEventDestroy(ctx->ev_t0);
+    if (ctx->ev_t1) (void) hipEventDestroy(ctx->ev_t1);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    (void) hipGetLastError();
     delete ctx;
 }
 
@@ -162,6 +173,11 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "sor_batch")) {
         if (value < 0 || value > 4096) return ofx_fail(ctx, OFX_ERR_ARG, "sor_batch out of range");
         ctx->sor_batch = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "mem_budget")) {
+        if (value < 0) return ofx_fail(ctx, OFX_ERR_ARG, "mem_budget out of range");
+        ctx->mem_budget = value;
         return OFX_OK;
     }
     if (!strcmp(name, "fuse2")) { ctx->fuse2 = value != 0; return OFX_OK; }

@@ -61,6 +61,7 @@ struct ofx_ctx {
     int sor_batch;      // sweeps in flight per batch in exact mode (0 = default)
     int sor_window;     // time steps per launch of the windowed exact mode (0 = 8)
     int sor_rows;       // rows per block (workgroup) of a sweep in the windowed exact mode (0 = 64)
+    double mem_budget;  // bytes all contexts of a batch may use for level arrays (0 = half of the free device memory)
     unsigned long long poll_seq;
 
     ofx_stats stats;

@@ -128,7 +128,10 @@ static int ofx_run_loop_group(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn l
             break;
         }
     }
-    if (!stop) return ofx_fail(ctx, OFX_ERR_HIP, "iteration loop ended without a final state");
+    if (!stop) {
+        (void) hipStreamSynchronize(ctx->stream);       // nothing of this loop may still be in flight when the arena is reused
+        return ofx_fail(ctx, OFX_ERR_HIP, "iteration loop ended without a final state");
+    }
     int redo_k[OFX_MAX_GROUP];
     bool any_redo = false;
     for (int g = 0; g < G; g++) {

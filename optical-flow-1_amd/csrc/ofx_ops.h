@@ -75,7 +75,7 @@ int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nx, int ny, int
                      double presmooth_sigma, std::vector<ImgLevel<T>> &lv);
 
 // the same in pieces, for callers that lay several pyramids out in their own arrays (TV-L1 lockstep groups)
-int op_pyramid_sizes(ofx_ctx *ctx, int nxx, int nyy, int nscales, double zfactor, int *nxs, int *nys);
+int op_pyramid_sizes(ofx_ctx *ctx, int nxx, int nyy, int nscales, double zfactor, std::vector<int> &nxs, std::vector<int> &nys);
 size_t op_pyramid_scratch_doubles();
 template <typename T>
 int op_build_pyramid_into(ofx_ctx *ctx, const T *dA, const T *dB, int nscales, double zfactor, double presmooth_sigma,

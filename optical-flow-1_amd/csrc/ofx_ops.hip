@@ -511,9 +511,13 @@ template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>
     return OFX_OK;
 }
 
-int op_pyramid_sizes(ofx_ctx *ctx, int nxx, int nyy, int nscales, double zfactor, int *nxs, int *nys)
+int op_pyramid_sizes(ofx_ctx *ctx, int nxx, int nyy, int nscales, double zfactor, std::vector<int> &nxs, std::vector<int> &nys)
 {
-    if (nscales < 1 || nscales > OFX_MAX_SCALES) return ofx_fail(ctx, OFX_ERR_ARG, "nscales=%d", nscales);
+    // no fixed limit on the number of levels (the reference allocates its pyramid dynamically; tvl1flow with
+    // zfactor = 0.9 at 1080p uses 47): OFX_MAX_SCALES only bounds what ofx_stats RECORDS.  1024 is a sanity bound.
+    if (nscales < 1 || nscales > 1024) return ofx_fail(ctx, OFX_ERR_ARG, "nscales=%d", nscales);
+    nxs.assign(nscales, 0);
+    nys.assign(nscales, 0);
     if (nxx < 2 || nyy < 2) return ofx_fail(ctx, OFX_ERR_ARG, "image %dx%d too small", nxx, nyy);
     if (!(zfactor > 0.0) || !(zfactor < 1.0)) return ofx_fail(ctx, OFX_ERR_ARG, "zoom factor %g", zfactor);
     int nx = nxx, ny = nyy;
@@ -549,7 +553,7 @@ template <typename T>
 int op_build_pyramid(ofx_ctx *ctx, const T *dA, const T *dB, int nxx, int nyy, int nscales, double zfactor,
                      double sigma, std::vector<ImgLevel<T>> &lv)
 {
-    int nxs[OFX_MAX_SCALES], nys[OFX_MAX_SCALES];
+    std::vector<int> nxs, nys;
     OFX_TRY(op_pyramid_sizes(ctx, nxx, nyy, nscales, zfactor, nxs, nys));
     lv.resize(nscales);
     for (int s = 0; s < nscales; s++) {

@@ -21,7 +21,9 @@
 #include "ofx_device.h"
 #include "ofx_loop.h"
 
+#include <atomic>
 #include <cmath>
+#include <thread>
 
 #define HS_SOR_W 1.9                 // src/horn_schunck_pyramidal.cpp:21
 #define HS_PRESMOOTH_SIGMA 0.8       // src/horn_schunck_pyramidal.cpp:22
@@ -57,6 +59,8 @@ __global__ void k_hs_warp(const typename Pix<T>::v2 *__restrict__ pa, const T *_
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= ny) return;
+    const size_t go = (size_t) blockIdx.z * nx * ny;             // pair of a lockstep group
+    pa += go; pb += go; I1 += go; U += go; A += go; Dif += go;
     const size_t p = (size_t) i * nx + j;
     const double2 u = ldw2(U + p);
     const BicubicTaps t = bicubic_taps(j + u.x, i + u.y, nx, ny);
@@ -221,6 +225,16 @@ __global__ __launch_bounds__(64) void k_hs_plane(typename Pix<T>::v2 *__restrict
 struct SorWin {
     int tau0, K, lag_s, lag_b, lag_f, s_first, R;      // lag_f: spacing of the frames of a sequence (temporal Brox)
 };
+// Lockstep group: G image pairs solved by the same launches (blockIdx.z = pair), every array of a level holding the
+// pairs back to back.  A lone solve is a latency chain of qmax + lag_s * sweeps dependent steps with a few hundred
+// waves of work each; the pairs of a group share that chain.  Each pair keeps its own error slots, snapshots and
+// stopping test (bit g of runmask: pair g still sweeps in this solve), so its flow is the one it gets alone.
+struct SorGrp {
+    unsigned runmask;
+    int      err_stride;     // doubles between the error slots of consecutive pairs
+    size_t   npix;           // elements between consecutive pairs in the level arrays
+    size_t   snap_stride;    // elements between the snapshot planes of consecutive pairs
+};
 // which plane item thread t of block b plays: its R rows, then the three shared items (first column, last
 // column, corners) of which a block accepts only the pixels assigned to it (sor_border_block)
 OFX_DEV int sor_window_item(const SorWin &w, int b, int t, int ny)
@@ -240,15 +254,21 @@ OFX_DEV int sor_border_block(int i, int ny, int R)
 }
 
 template <typename T>
-__global__ __launch_bounds__(1024) void k_hs_window(typename Pix<T>::v2 *U, typename Pix<T>::v2 *snap,
-                                                    const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif,
-                                                    double *__restrict__ err, SorWin w, int nx, int ny, double alpha2)
+__global__ __launch_bounds__(1024) void k_hs_window(typename Pix<T>::v2 *Ug, typename Pix<T>::v2 *snap,
+                                                    const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Difg,
+                                                    double *__restrict__ errg, SorWin w, SorGrp grp, int nx, int ny,
+                                                    double alpha2)
 {
-    const int b = blockIdx.x, s = w.s_first + blockIdx.y;
+    const int b = blockIdx.x, s = w.s_first + blockIdx.y, g = blockIdx.z;
+    if (!((grp.runmask >> g) & 1u)) return;                      // this pair's solve has already stopped
     const int qmax = 2 * ny + nx - 2;
     const int q_first = w.tau0 - w.lag_s * s - w.lag_b * b;
     if (q_first > qmax || q_first + w.K - 1 < 0) return;         // this (sweep, block) has no step in the window
-    typename Pix<T>::v2 *mysnap = snap + (size_t) s * nx * ny;
+    typename Pix<T>::v2 *U = Ug + g * grp.npix;
+    const typename Pix<T>::v2 *__restrict__ A = Ag + g * grp.npix;
+    const T *__restrict__ Dif = Difg + g * grp.npix;
+    double *__restrict__ err = errg + (size_t) g * grp.err_stride;
+    typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) s * nx * ny;
     const int r = sor_window_item(w, b, threadIdx.x, ny);
     double e = 0.0;
     for (int q = q_first; q < q_first + w.K; q++) {
@@ -277,11 +297,13 @@ __global__ __launch_bounds__(1024) void k_hs_window(typename Pix<T>::v2 *U, type
 // nz > 1 (temporal Brox): a sweep visits nz frames one after the other; frame number o (in visiting order) runs
 // lag_f = K steps behind frame o - 1 and the sweeps move lag_f (nz - 1) further apart.
 template <class WindowFn, class TakeFn>
-static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxiter, int qmax, int C, int batch,
+static int sor_window_loop(ofx_ctx *ctx, int G, int size, int ny, double TOL, int maxiter, int qmax, int C, int batch,
                            WindowFn launch, TakeFn take, int *n_out, double *err_out, int nz = 1, int *hint = nullptr)
 {
-    int niter = 0;
-    double error = 1000;
+    // G problems in lockstep (SorGrp): launch(w, blocks, sweeps, runmask, err_stride) serves every problem whose bit
+    // is set; take(g, n) makes snapshot n - 1 of problem g its current state.  All problems start together, so the
+    // ones still sweeping have all run the same number of full batches.
+    if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "sor group of %d problems", G);
     SorWin w;
     w.K = ctx->sor_window > 0 ? ctx->sor_window : 8;
     w.R = ctx->sor_rows > 0 ? ctx->sor_rows : 64;
@@ -291,7 +313,8 @@ static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxit
     w.lag_b = w.K;
     w.lag_f = nz > 1 ? w.K : 0;
     w.lag_s = (B > 1 ? 2 * w.K : w.K) + C + w.lag_f * (nz - 1);
-    OFX_TRY(ofx_loop_reserve(ctx, batch + 1));
+    const int per = batch + 1;                                   // error slots per problem
+    OFX_TRY(ofx_loop_reserve(ctx, G * per));
     LoopSpec LS;
     LS.size = size;
     LS.thr = TOL;
@@ -301,8 +324,9 @@ static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxit
     LS.pairs = false;
     // Every sweep of a batch costs lag_s steps of pipeline whether it is needed or not, so batches are sized, not
     // maximal (`batch` is the snapshot capacity): the first one from the sweep count of the previous solve at this level
-    // (*hint; consecutive warps / outer iterations converge in similar, usually decreasing, numbers of sweeps) with
-    // 25 % + 2 of head room, 32 without a hint; a solve that needs more runs further, half-sized batches.
+    // (*hint = the largest of the group; consecutive warps / outer iterations converge in similar, usually decreasing,
+    // numbers of sweeps) with 25 % + 2 of head room, 32 without a hint; a solve that needs more runs further,
+    // half-sized batches.
     int first = batch < 32 ? batch : 32;
     if (ctx->sor_batch > 0) first = batch;                       // explicit option: fixed batches
     else if (hint && *hint > 0) {
@@ -310,11 +334,14 @@ static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxit
         first = first < 8 ? 8 : (first > batch ? batch : first);
     }
     const int later = ctx->sor_batch > 0 ? batch : (first / 2 < 8 ? (batch < 8 ? batch : 8) : first / 2);
-    while (error > TOL && niter < maxiter) {
+    int niter = 0;                                               // sweeps of the problems that are still active
+    unsigned active = (1000 > TOL && maxiter > 0) ? ((G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u)) : 0u;
+    for (int g = 0; g < G; g++) { n_out[g] = 0; err_out[g] = 1000; }                       // :140 / :312
+    while (active) {
         const int want = niter == 0 ? first : later;
         const int ns = (maxiter - niter < want) ? maxiter - niter : want;
-        OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) ns * OFX_NSHARD, ctx->stream));
-        OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState), ctx->stream));
+        OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) G * per * OFX_NSHARD, ctx->stream));
+        OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState) * G, ctx->stream));
         const long tail = (long) w.lag_b * (B - 1) + (long) w.lag_f * (nz - 1);   // the last unit of a sweep ends this much later
         const long total = (long) qmax + 1 + tail + (long) w.lag_s * (ns - 1);
         for (long tau0 = 0; tau0 < total; tau0 += w.K) {
@@ -325,21 +352,28 @@ static int sor_window_loop(ofx_ctx *ctx, int size, int ny, double TOL, int maxit
             if (s_hi < s_lo) continue;
             w.tau0 = (int) tau0;
             w.s_first = (int) s_lo;
-            OFX_TRY(launch(w, B, (int) (s_hi - s_lo + 1)));
+            OFX_TRY(launch(w, B, (int) (s_hi - s_lo + 1), active, per * OFX_NSHARD));
         }
         LS.max_iter = ns;
         const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
-        OFX_TRY(ofx_loop_finalize(ctx, LS, 0, ns, &ctx->h_state[slot * OFX_MAX_GROUP]));
+        OFX_TRY(ofx_loop_finalize_group(ctx, LS, G, per, 0, ns, &ctx->h_state[slot * OFX_MAX_GROUP]));
         OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
         OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
-        const OfxIterState st = ctx->h_state[slot * OFX_MAX_GROUP];
-        if (st.n < ns) OFX_TRY(take(st.n));                     // stopped inside the batch: the state is snapshot n - 1
-        niter += st.n;
-        error = st.error;
+        for (int g = 0; g < G; g++) {
+            if (!((active >> g) & 1u)) continue;
+            const OfxIterState st = ctx->h_state[slot * OFX_MAX_GROUP + g];
+            if (st.n < ns) OFX_TRY(take(g, st.n));              // stopped inside the batch: the state is snapshot n - 1
+            n_out[g] = niter + st.n;
+            err_out[g] = st.error;
+            if (!(st.error > TOL && n_out[g] < maxiter)) active &= ~(1u << g);
+        }
+        niter += ns;
     }
-    if (hint) *hint = niter;
-    *n_out = niter;
-    *err_out = error;
+    if (hint) {
+        int h = 0;
+        for (int g = 0; g < G; g++) h = n_out[g] > h ? n_out[g] : h;
+        *hint = h;
+    }
     return OFX_OK;
 }
 
@@ -403,12 +437,12 @@ static int sor_exact_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int q
 }
 
 // snapshot capacity (= most sweeps in one batch) of the windowed mode: option "sor_batch", else 64, capped by maxiter
-// and by ~4 GiB of snapshots
-static int sor_pick_batch(const ofx_ctx *ctx, size_t npix, size_t elem_bytes, int maxiter)
+// and by ~4 GiB of snapshots per pair (40 GiB per lockstep group)
+static int sor_pick_batch(const ofx_ctx *ctx, size_t npix, size_t elem_bytes, int maxiter, int G = 1)
 {
     int b = ctx->sor_batch > 0 ? ctx->sor_batch : 64;
-    const size_t cap = (size_t) 4 << 30;
-    while (b > 1 && (size_t) b * npix * elem_bytes > cap) b /= 2;
+    const size_t cap = (size_t) 4 << 30, cap_group = (size_t) 40 << 30;      // per pair / for all pairs of a group
+    while (b > 1 && ((size_t) b * npix * elem_bytes > cap || (size_t) b * npix * elem_bytes * G > cap_group)) b /= 2;
     if (b > maxiter) b = maxiter;
     return b < 1 ? 1 : b;
 }
@@ -418,23 +452,31 @@ static int sor_window_threads(int n_items)
     return t > 1024 ? 1024 : t;
 }
 
+// One level of a lockstep group: every array holds G pairs back to back (pair g at element g * nx * ny).
 template <typename T> struct HsLevel {
-    int nx, ny;
+    int nx, ny, G;
     T *I1, *I2;
     typename Pix<T>::v2 *pa;    // (I2, I2x)
     T *pb;                      // I2y
     typename Pix<T>::v2 *U, *A, *Uck;
     T *Dif;
-    typename Pix<T>::v2 *Snap;  // windowed exact mode: one snapshot plane per sweep of a batch (allocated on first use)
+    typename Pix<T>::v2 *Snap;  // windowed exact mode: snap_planes snapshot planes per pair (allocated on first use)
     int snap_planes;
     int sweep_hint;             // sweeps of the previous solve at this level (sizes the next first batch)
+    size_t n() const { return (size_t) nx * ny; }
 };
 
-template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int nx, int ny)
+template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int nx, int ny, int G, bool images)
 {
-    const size_t n = (size_t) nx * ny;
+    const size_t n = (size_t) nx * ny * G;
     L.nx = nx;
     L.ny = ny;
+    L.G = G;
+    L.I1 = L.I2 = nullptr;
+    if (images) {
+        OFX_TRY(ofx_alloc(ctx, n, &L.I1));
+        OFX_TRY(ofx_alloc(ctx, n, &L.I2));
+    }
     OFX_TRY(ofx_alloc(ctx, n, &L.pa));
     OFX_TRY(ofx_alloc(ctx, n, &L.pb));
     OFX_TRY(ofx_alloc(ctx, n, &L.U));
@@ -452,45 +494,56 @@ struct HsParams {
     int warps, maxiter, verbose;
 };
 
-// src/horn_schunck_pyramidal.cpp:78-249 on device data; L.U holds the incoming flow
-template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L, const HsParams &P, int scale)
+// src/horn_schunck_pyramidal.cpp:78-249 on device data for the G pairs of a lockstep group; L.U holds the incoming
+// flows; stats[g] = work record of pair g.
+template <typename T>
+static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L, const HsParams &P, int scale, ofx_stats *stats)
 {
-    const int nx = L.nx, ny = L.ny;
+    const int nx = L.nx, ny = L.ny, G = L.G;
+    const size_t npix = L.n();
     const double alpha2 = P.alpha * P.alpha;
-    if (P.verbose)
+    if (P.verbose && G == 1)
         fprintf(stderr, "Single-scale Horn-Schunck of a %dx%d image\n\ta=%g nw=%d eps=%g mi=%d v=%d\n", nx, ny, P.alpha,
                 P.warps, P.TOL, P.maxiter, P.verbose);
-    OFX_TRY(op_grad_pack<T>(ctx, L.I2, L.pa, L.pb, nx, ny));                                // :114
-    ofx_stats &S = ctx->stats;
+    const bool windowed = ctx->sor_exact == 1 && nx >= 3 && ny >= 3;
+    if (G > 1 && !windowed)
+        return ofx_fail(ctx, OFX_ERR_ARG, "hs: lockstep groups need sor_exact = 1 and levels of at least 3x3 (%dx%d)", nx, ny);
+    for (int g = 0; g < G; g++)
+        OFX_TRY(op_grad_pack<T>(ctx, L.I2 + g * npix, L.pa + g * npix, L.pb + g * npix, nx, ny));      // :114
+    const dim3 gw(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), G);
     const dim3 gc(ofx_cdiv(ofx_cdiv(nx, 2), 64), ofx_cdiv(ofx_cdiv(ny, 2), 4));
     for (int w = 0; w < P.warps; w++) {
-        if (P.verbose) fprintf(stderr, "Warping %d:", w);
-        hipLaunchKernelGGL(k_hs_warp<T>, g2d(nx, ny), b2d(), 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I1, L.U, L.A, L.Dif,
+        if (P.verbose && G == 1) fprintf(stderr, "Warping %d:", w);
+        hipLaunchKernelGGL(k_hs_warp<T>, gw, b2d(), 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I1, L.U, L.A, L.Dif,
                            nx, ny);                                                           // :123-137
         OFX_LAUNCH_CHECK(ctx);
-        int niter = 0;
-        double error = 1000;                                                                  // :140
+        int niter[OFX_MAX_GROUP] = {0};
+        double error[OFX_MAX_GROUP];
+        for (int g = 0; g < G; g++) error[g] = 1000;                                          // :140
         float ms = 0.f;
-        if (ctx->sor_exact == 1 && nx >= 3 && ny >= 3) {
+        if (windowed) {
             // windowed exact mode (default)
-            const size_t ub = (size_t) nx * ny * sizeof(typename Pix<T>::v2);
-            const int batch = sor_pick_batch(ctx, (size_t) nx * ny, sizeof(typename Pix<T>::v2), P.maxiter);
+            const size_t ub = npix * sizeof(typename Pix<T>::v2);
+            const int batch = sor_pick_batch(ctx, npix, sizeof(typename Pix<T>::v2), P.maxiter, G);
             if (L.snap_planes < batch) {
-                OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny * batch, &L.Snap));
+                OFX_TRY(ofx_alloc(ctx, npix * batch * G, &L.Snap));
                 L.snap_planes = batch;
             }
-            auto window = [&](const SorWin &w, int blocks, int sweeps) -> int {
-                hipLaunchKernelGGL(k_hs_window<T>, dim3(blocks, sweeps), dim3(sor_window_threads(w.R + 3)), 0, ctx->stream,
-                                   L.U, L.Snap, L.A, (const T *) L.Dif, ctx->d_err, w, nx, ny, alpha2);
+            const size_t snap_stride = npix * L.snap_planes;
+            auto window = [&](const SorWin &w, int blocks, int sweeps, unsigned runmask, int err_stride) -> int {
+                const SorGrp grp = {runmask, err_stride, npix, snap_stride};
+                hipLaunchKernelGGL(k_hs_window<T>, dim3(blocks, sweeps, G), dim3(sor_window_threads(w.R + 3)), 0, ctx->stream,
+                                   L.U, L.Snap, L.A, (const T *) L.Dif, ctx->d_err, w, grp, nx, ny, alpha2);
                 OFX_LAUNCH_CHECK(ctx);
                 return OFX_OK;
             };
-            auto take = [&](int n) -> int {
-                OFX_HIP(ctx, hipMemcpyAsync(L.U, L.Snap + (size_t) (n - 1) * nx * ny, ub, hipMemcpyDeviceToDevice, ctx->stream));
+            auto take = [&](int g, int n) -> int {
+                OFX_HIP(ctx, hipMemcpyAsync(L.U + g * npix, L.Snap + g * snap_stride + (size_t) (n - 1) * npix, ub,
+                                            hipMemcpyDeviceToDevice, ctx->stream));
                 return OFX_OK;
             };
-            OFX_TRY(sor_window_loop(ctx, nx * ny, ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, batch, window, take,
-                                    &niter, &error, 1, &L.sweep_hint));
+            OFX_TRY(sor_window_loop(ctx, G, nx * ny, ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, batch, window, take,
+                                    niter, error, 1, &L.sweep_hint));
         } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
             // one launch per time step (option sor_exact = 2): the reference implementation of the exact schedule
             const size_t ub = (size_t) nx * ny * sizeof(typename Pix<T>::v2);
@@ -510,8 +563,8 @@ template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L
                 return OFX_OK;
             };
             OFX_TRY(sor_exact_loop(ctx, nx * ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, plane, save, restore,
-                                   &niter, &error));
-        } else if (P.maxiter > 0 && error > P.TOL) {
+                                   &niter[0], &error[0]));
+        } else if (P.maxiter > 0 && error[0] > P.TOL) {
             LoopSpec LS;
             LS.max_iter = P.maxiter;
             LS.size = nx * ny;
@@ -527,15 +580,18 @@ template <typename T> static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L
                 OFX_LAUNCH_CHECK(ctx);
                 return OFX_OK;
             };
-            OFX_TRY(ofx_run_loop(ctx, LS, launch, [](int) { return OFX_OK; }, &niter, &error, ctx->profile ? &ms : nullptr));
+            OFX_TRY(ofx_run_loop(ctx, LS, launch, [](int) { return OFX_OK; }, &niter[0], &error[0], ctx->profile ? &ms : nullptr));
         }
-        if (P.verbose) fprintf(stderr, "Iterations %d (%g)\n", niter, error);                // :233-235
-        if (scale < OFX_MAX_SCALES) {
-            if (w < OFX_MAX_SOLVES) { S.iters[scale][w] = niter; S.error[scale][w] = error; }
-            S.iter_ms[scale] += ms;
-            S.iter_launches[scale] += niter;
+        if (P.verbose && G == 1) fprintf(stderr, "Iterations %d (%g)\n", niter[0], error[0]);   // :233-235
+        for (int g = 0; g < G; g++) {
+            ofx_stats &S = stats[g];
+            if (scale < OFX_MAX_SCALES) {
+                if (w < OFX_MAX_SOLVES) { S.iters[scale][w] = niter[g]; S.error[scale][w] = error[g]; }
+                S.iter_ms[scale] += ms;
+                S.iter_launches[scale] += niter[g];
+            }
+            S.work_pix_iters += (double) niter[g] * nx * ny;
         }
-        S.work_pix_iters += (double) niter * nx * ny;
     }
     return OFX_OK;
 }
@@ -563,12 +619,13 @@ static int download_flow(ofx_ctx *ctx, const typename Pix<T>::v2 *U, double *u, 
     return OFX_OK;
 }
 
-static void sor_stats_begin(ofx_ctx *ctx, int nscales, int nsolves)
+static void sor_stats_begin(ofx_stats *st, int nscales, int nsolves)
 {
-    memset(&ctx->stats, 0, sizeof(ctx->stats));
-    ctx->stats.nscales = nscales;
-    ctx->stats.nsolves = nsolves;
+    memset(st, 0, sizeof(*st));
+    st->nscales = nscales;
+    st->nsolves = nsolves;
 }
+static void sor_stats_begin(ofx_ctx *ctx, int nscales, int nsolves) { sor_stats_begin(&ctx->stats, nscales, nsolves); }
 
 template <typename T>
 static int hs_single_scale_host(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nx, int ny,
@@ -579,7 +636,7 @@ static int hs_single_scale_host(ofx_ctx *ctx, const double *I1, const double *I2
     ctx->stats.nx[0] = nx;
     ctx->stats.ny[0] = ny;
     HsLevel<T> L;
-    OFX_TRY(hs_level_alloc<T>(ctx, L, nx, ny));
+    OFX_TRY(hs_level_alloc<T>(ctx, L, nx, ny, 1, false));
     OFX_TRY(upload_plane<T>(ctx, I1, n, &L.I1));
     OFX_TRY(upload_plane<T>(ctx, I2, n, &L.I2));
     double *d1, *d2;
@@ -588,43 +645,81 @@ static int hs_single_scale_host(ofx_ctx *ctx, const double *I1, const double *I2
     OFX_HIP(ctx, hipMemcpyAsync(d1, u, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     OFX_HIP(ctx, hipMemcpyAsync(d2, v, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     OFX_TRY(op_interleave2<T>(ctx, d1, d2, L.U, n));
-    OFX_TRY(hs_single_scale_dev<T>(ctx, L, P, 0));
+    OFX_TRY(hs_single_scale_dev<T>(ctx, L, P, 0, &ctx->stats));
     return download_flow<T>(ctx, L.U, u, v, n);
 }
 
-// src/horn_schunck_pyramidal.cpp:258-370
+// src/horn_schunck_pyramidal.cpp:258-370 for G pairs in lockstep.  dI1[g] / dI2[g]: device images of storage type T.
+// On success lv[0].U holds the flows (pair g at element g * nx * ny).
+template <typename T>
+static int hs_pyramidal_dev(ofx_ctx *ctx, int G, const T *const *dI1, const T *const *dI2, int nx, int ny, const HsParams &P,
+                            int nscales, double zfactor, std::vector<HsLevel<T>> &lv, ofx_stats *stats)
+{
+    if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "hs: group of %d pairs", G);
+    if (P.verbose && G == 1)
+        fprintf(stderr, "Multiscale Horn-Schunck of a %dx%d pair\n\ta=%g ns=%d zf=%g nw=%d eps=%g mi=%d\n", nx, ny,
+                P.alpha, nscales, zfactor, P.warps, P.TOL, P.maxiter);
+    std::vector<int> nxs, nys;
+    OFX_TRY(op_pyramid_sizes(ctx, nx, ny, nscales, zfactor, nxs, nys));
+    for (int g = 0; g < G; g++) {
+        sor_stats_begin(&stats[g], nscales, P.warps);
+        for (int s = 0; s < nscales && s < OFX_MAX_SCALES; s++) { stats[g].nx[s] = nxs[s]; stats[g].ny[s] = nys[s]; }
+    }
+    lv.resize(nscales);
+    for (int s = 0; s < nscales; s++) OFX_TRY(hs_level_alloc<T>(ctx, lv[s], nxs[s], nys[s], G, true));
+    {                                                                                                  // :279-317
+        T *tmpA, *tmpB;
+        double *scr;
+        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &tmpA));
+        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &tmpB));
+        OFX_TRY(ofx_alloc(ctx, op_pyramid_scratch_doubles(), &scr));
+        std::vector<ImgLevel<T>> img(nscales);
+        for (int g = 0; g < G; g++) {
+            for (int s = 0; s < nscales; s++) {
+                img[s].nx = nxs[s];
+                img[s].ny = nys[s];
+                img[s].A = lv[s].I1 + g * lv[s].n();
+                img[s].B = lv[s].I2 + g * lv[s].n();
+            }
+            OFX_TRY(op_build_pyramid_into<T>(ctx, dI1[g], dI2[g], nscales, zfactor, HS_PRESMOOTH_SIGMA, img, tmpA, tmpB, scr));
+        }
+    }
+    HsLevel<T> &C = lv[nscales - 1];
+    OFX_TRY(op_fill2<T>(ctx, C.U, C.n() * G));                                                          // :320-323
+    for (int s = nscales - 1; s >= 0; s--) {                                                           // :326
+        if (P.verbose && G == 1) fprintf(stderr, "Scale: %d %dx%d\n", s, lv[s].nx, lv[s].ny);
+        OFX_TRY(hs_single_scale_dev<T>(ctx, lv[s], P, s, stats));
+        if (!s) break;
+        for (int g = 0; g < G; g++)
+            OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U + g * lv[s].n(), lv[s - 1].U + g * lv[s - 1].n(), lv[s].nx, lv[s].ny,
+                                       lv[s - 1].nx, lv[s - 1].ny, 1.0 / zfactor));                    // :345-352
+    }
+    return OFX_OK;
+}
+
 template <typename T>
 static int hs_pyramidal_host(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nx, int ny,
                              const HsParams &P, int nscales, double zfactor)
 {
     const size_t n = (size_t) nx * ny;
-    if (P.verbose)
-        fprintf(stderr, "Multiscale Horn-Schunck of a %dx%d pair\n\ta=%g ns=%d zf=%g nw=%d eps=%g mi=%d\n", nx, ny,
-                P.alpha, nscales, zfactor, P.warps, P.TOL, P.maxiter);
     T *dI1, *dI2;
     OFX_TRY(upload_plane<T>(ctx, I1, n, &dI1));
     OFX_TRY(upload_plane<T>(ctx, I2, n, &dI2));
-    sor_stats_begin(ctx, nscales, P.warps);
-    std::vector<ImgLevel<T>> img;
-    OFX_TRY(op_build_pyramid<T>(ctx, dI1, dI2, nx, ny, nscales, zfactor, HS_PRESMOOTH_SIGMA, img));     // :279-317
-    std::vector<HsLevel<T>> lv(nscales);
-    for (int s = 0; s < nscales; s++) {
-        OFX_TRY(hs_level_alloc<T>(ctx, lv[s], img[s].nx, img[s].ny));
-        lv[s].I1 = img[s].A;
-        lv[s].I2 = img[s].B;
-        ctx->stats.nx[s] = img[s].nx;
-        ctx->stats.ny[s] = img[s].ny;
-    }
-    HsLevel<T> &C = lv[nscales - 1];
-    OFX_TRY(op_fill2<T>(ctx, C.U, (size_t) C.nx * C.ny));                                               // :320-323
-    for (int s = nscales - 1; s >= 0; s--) {                                                           // :326
-        if (P.verbose) fprintf(stderr, "Scale: %d %dx%d\n", s, lv[s].nx, lv[s].ny);
-        OFX_TRY(hs_single_scale_dev<T>(ctx, lv[s], P, s));
-        if (!s) break;
-        OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U, lv[s - 1].U, lv[s].nx, lv[s].ny, lv[s - 1].nx, lv[s - 1].ny,
-                                   1.0 / zfactor));                                                    // :345-352
-    }
+    std::vector<HsLevel<T>> lv;
+    const T *a = dI1, *b = dI2;
+    OFX_TRY(hs_pyramidal_dev<T>(ctx, 1, &a, &b, nx, ny, P, nscales, zfactor, lv, &ctx->stats));
     return download_flow<T>(ctx, lv[0].U, u, v, n);
+}
+
+template <typename T>
+static int hs_group_devapi(ofx_ctx *ctx, int G, const void *const *dI1, const void *const *dI2, void *const *d_flo, int nx,
+                           int ny, const HsParams &P, int nscales, double zfactor, ofx_stats *stats)
+{
+    std::vector<HsLevel<T>> lv;
+    OFX_TRY(hs_pyramidal_dev<T>(ctx, G, (const T *const *) dI1, (const T *const *) dI2, nx, ny, P, nscales, zfactor, lv, stats));
+    const size_t n = (size_t) nx * ny;
+    for (int g = 0; g < G; g++) OFX_TRY(op_to_flo<T>(ctx, lv[0].U + g * n, (float2 *) d_flo[g], n));
+    return OFX_OK;
 }
 
 extern "C" int ofx_hs_single_scale(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nx,
@@ -655,6 +750,30 @@ extern "C" int ofx_hs_pyramidal(ofx_ctx *ctx, const double *I1, const double *I2
     int s = ctx->precision == OFX_F64 ? hs_pyramidal_host<double>(ctx, I1, I2, u, v, nx, ny, P, nscales, zfactor)
                                       : hs_pyramidal_host<float>(ctx, I1, I2, u, v, nx, ny, P, nscales, zfactor);
     ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}
+
+extern "C" int ofx_hs_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *dI1, const void *const *dI2,
+                                void *const *d_flo, int nx, int ny, double alpha, int nscales, double zfactor, int warps,
+                                double TOL, int maxiter, ofx_stats *stats_out)
+{
+    OFX_ENTER(ctx);
+    if (!dI1 || !dI2 || !d_flo) return ofx_fail(ctx, OFX_ERR_ARG, "hs: NULL pointer");
+    if (n_pairs < 1 || n_pairs > OFX_MAX_GROUP)
+        return ofx_fail(ctx, OFX_ERR_ARG, "hs: a lockstep group holds 1..%d pairs (got %d)", OFX_MAX_GROUP, n_pairs);
+    for (int g = 0; g < n_pairs; g++)
+        if (!dI1[g] || !dI2[g] || !d_flo[g]) return ofx_fail(ctx, OFX_ERR_ARG, "hs: NULL pointer (pair %d)", g);
+    if (warps < 1) return ofx_fail(ctx, OFX_ERR_ARG, "hs: warps=%d", warps);
+    if (maxiter > OFX_HS_MAX_MAXITER) return ofx_fail(ctx, OFX_ERR_ARG, "hs: maxiter > %d", OFX_HS_MAX_MAXITER);
+    const double t0 = ofx_now_ms();
+    const HsParams P = {alpha, TOL, warps, maxiter, 0};
+    std::vector<ofx_stats> local(stats_out ? 0 : n_pairs);
+    ofx_stats *st = stats_out ? stats_out : local.data();
+    int s = ctx->precision == OFX_F64 ? hs_group_devapi<double>(ctx, n_pairs, dI1, dI2, d_flo, nx, ny, P, nscales, zfactor, st)
+                                      : hs_group_devapi<float>(ctx, n_pairs, dI1, dI2, d_flo, nx, ny, P, nscales, zfactor, st);
+    const double ms = ofx_now_ms() - t0;
+    for (int g = 0; g < n_pairs; g++) st[g].total_ms = ms;
+    ctx->stats = st[0];
     return s;
 }
 
@@ -703,6 +822,8 @@ __global__ void k_brox_prepare(const T *__restrict__ I1, const T *__restrict__ I
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= ny) return;
+    const size_t go = (size_t) blockIdx.z * nx * ny;             // pair of a lockstep group
+    I1 += go; I2 += go; G1 += go; PA += go; PB += go;
     const size_t p = (size_t) i * nx + j;
     stn2(G1 + p, make_double2(cdx(I1, i, j, nx, ny), cdy(I1, i, j, nx, ny)));
     stn4(PA + p, make_double4(ldw(I2 + p), cdx(I2, i, j, nx, ny), cdy(I2, i, j, nx, ny), d2xx(I2, i, j, nx, ny)));
@@ -718,6 +839,8 @@ __global__ void k_brox_warp(const typename Pix<T>::v4 *__restrict__ PA, const ty
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= ny) return;
+    const size_t go = (size_t) blockIdx.z * nx * ny;             // pair of a lockstep group
+    PA += go; PB += go; U += go; WA += go; WB += go;
     const size_t p = (size_t) i * nx + j;
     const double2 u = ldw2(U + p);
     const BicubicTaps t = bicubic_taps(j + u.x, i + u.y, nx, ny);
@@ -759,6 +882,8 @@ __global__ void k_brox_psis(const typename Pix<T>::v2 *__restrict__ U, T *__rest
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= ny) return;
+    const size_t go = (size_t) blockIdx.z * nx * ny;             // pair of a lockstep group
+    U += go; Psis += go;
     const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
     const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
     const double2 r = ldw2(U + (size_t) i * nx + jr), l = ldw2(U + (size_t) i * nx + jl);
@@ -794,6 +919,8 @@ __global__ void k_brox_div(const typename Pix<T>::v2 *__restrict__ U, const T *_
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= ny) return;
+    const size_t go = (size_t) blockIdx.z * nx * ny;             // pair of a lockstep group
+    U += go; Psis += go; DV += go; Dd += go; DU += go;
     const size_t k = (size_t) i * nx + j;
     const Psi4 s = brox_psi4(Psis, i, j, nx, ny);
     const double2 c = ldw2(U + k);
@@ -956,16 +1083,22 @@ __global__ __launch_bounds__(64) void k_brox_plane(typename Pix<T>::v2 *__restri
 
 // windowed exact mode (see k_hs_window): K steps per launch, one workgroup per (sweep, row block)
 template <typename T>
-__global__ __launch_bounds__(1024) void k_brox_window(typename Pix<T>::v2 *DU, typename Pix<T>::v2 *snap,
-                                                      const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
-                                                      const T *__restrict__ Psis, double *__restrict__ err, SorWin w,
-                                                      int nx, int ny, double alpha)
+__global__ __launch_bounds__(1024) void k_brox_window(typename Pix<T>::v2 *DUg, typename Pix<T>::v2 *snap,
+                                                      const typename Pix<T>::v4 *__restrict__ COg, const T *__restrict__ Dmg,
+                                                      const T *__restrict__ Psisg, double *__restrict__ errg, SorWin w,
+                                                      SorGrp grp, int nx, int ny, double alpha)
 {
-    const int b = blockIdx.x, s = w.s_first + blockIdx.y;
+    const int b = blockIdx.x, s = w.s_first + blockIdx.y, g = blockIdx.z;
+    if (!((grp.runmask >> g) & 1u)) return;
     const int qmax = ny + nx - 2;
     const int q_first = w.tau0 - w.lag_s * s - w.lag_b * b;
     if (q_first > qmax || q_first + w.K - 1 < 0) return;
-    typename Pix<T>::v2 *mysnap = snap + (size_t) s * nx * ny;
+    typename Pix<T>::v2 *DU = DUg + g * grp.npix;
+    const typename Pix<T>::v4 *__restrict__ CO = COg + g * grp.npix;
+    const T *__restrict__ Dm = Dmg + g * grp.npix;
+    const T *__restrict__ Psis = Psisg + g * grp.npix;
+    double *__restrict__ err = errg + (size_t) g * grp.err_stride;
+    typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) s * nx * ny;
     const int r = sor_window_item(w, b, threadIdx.x, ny);
     double e = 0.0;
     for (int q = q_first; q < q_first + w.K; q++) {
@@ -995,23 +1128,28 @@ __global__ void k_brox_add(typename Pix<T>::v2 *__restrict__ U, const typename P
     stn2(U + i, make_double2(u.x + d.x, u.y + d.y));
 }
 
+// One level of a lockstep group: every array holds G pairs back to back (pair g at element g * nx * ny).
 template <typename T> struct BroxLevel {
     using v2 = typename Pix<T>::v2;
     using v4 = typename Pix<T>::v4;
-    int nx, ny;
+    int nx, ny, G;
     T *I1, *I2, *Psis, *Dd, *Dm;
     v2 *G1, *PB, *WB, *U, *DV, *DU, *DUck;
     v4 *PA, *WA, *CO;
-    v2 *Snap;           // windowed exact mode: one snapshot plane of (du, dv) per sweep of a batch
+    v2 *Snap;           // windowed exact mode: snap_planes snapshot planes of (du, dv) per pair
     int snap_planes;
     int sweep_hint;
+    size_t n() const { return (size_t) nx * ny; }
 };
 
-template <typename T> static int brox_level_alloc(ofx_ctx *ctx, BroxLevel<T> &L, int nx, int ny)
+template <typename T> static int brox_level_alloc(ofx_ctx *ctx, BroxLevel<T> &L, int nx, int ny, int G)
 {
-    const size_t n = (size_t) nx * ny;
+    const size_t n = (size_t) nx * ny * G;
     L.nx = nx;
     L.ny = ny;
+    L.G = G;
+    OFX_TRY(ofx_alloc(ctx, n, &L.I1));
+    OFX_TRY(ofx_alloc(ctx, n, &L.I2));
     OFX_TRY(ofx_alloc(ctx, n, &L.Psis));
     OFX_TRY(ofx_alloc(ctx, n, &L.Dd));
     OFX_TRY(ofx_alloc(ctx, n, &L.Dm));
@@ -1036,14 +1174,19 @@ struct BroxParams {
     int inner_iter, outer_iter, verbose;
 };
 
-// src/brox_optic_flow_spatial.cpp:179-444 on device data
-template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams &P, int scale)
+// src/brox_optic_flow_spatial.cpp:179-444 on device data for the G pairs of a lockstep group; stats[g] = record of pair g
+template <typename T>
+static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams &P, int scale, ofx_stats *stats)
 {
-    const int nx = L.nx, ny = L.ny, n = nx * ny;
-    const dim3 g = g2d(nx, ny), b = b2d();
-    const dim3 g1((n + 255) / 256), b1(256);
+    const int nx = L.nx, ny = L.ny, n = nx * ny, G = L.G;
+    const size_t npix = L.n();
+    const dim3 g(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), G), b = b2d();
+    const dim3 g1((unsigned) ((npix * G + 255) / 256)), b1(256);
     const dim3 gc(ofx_cdiv(ofx_cdiv(nx, 2) + 1, 64), ofx_cdiv(ny, 4));
-    ofx_stats &S = ctx->stats;
+    if ((long long) npix * G >= (1LL << 31)) return ofx_fail(ctx, OFX_ERR_ARG, "brox: group larger than 2^31 pixels");
+    const bool windowed = ctx->sor_exact == 1 && nx >= 3 && ny >= 3;
+    if (G > 1 && !windowed)
+        return ofx_fail(ctx, OFX_ERR_ARG, "brox: lockstep groups need sor_exact = 1 and levels of at least 3x3 (%dx%d)", nx, ny);
     int solve = 0;
     hipLaunchKernelGGL(k_brox_prepare<T>, g, b, 0, ctx->stream, (const T *) L.I1, (const T *) L.I2, L.G1, L.PA, L.PB, nx, ny);
     OFX_LAUNCH_CHECK(ctx);
@@ -1054,31 +1197,35 @@ template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T
         OFX_LAUNCH_CHECK(ctx);
         for (int ni = 0; ni < P.inner_iter; ni++) {                                               // :277
             hipLaunchKernelGGL(k_brox_coeff<T>, g1, b1, 0, ctx->stream, (const T *) L.I1, L.G1, L.WA, L.WB, L.DU, L.DV,
-                               (const T *) L.Dd, L.CO, L.Dm, n, P.alpha, P.gamma);
+                               (const T *) L.Dd, L.CO, L.Dm, (int) (npix * G), P.alpha, P.gamma);
             OFX_LAUNCH_CHECK(ctx);
-            int nsor = 0;
-            double error = 1000;                                                                  // :312
+            int nsor[OFX_MAX_GROUP] = {0};
+            double error[OFX_MAX_GROUP];
+            for (int q = 0; q < G; q++) error[q] = 1000;                                          // :312
             float ms = 0.f;
-            if (ctx->sor_exact == 1 && nx >= 3 && ny >= 3) {
-                const size_t ub = (size_t) n * sizeof(typename Pix<T>::v2);
-                const int batch = sor_pick_batch(ctx, (size_t) n, sizeof(typename Pix<T>::v2), OFX_BROX_MAX_ITERATIONS);
+            if (windowed) {
+                const size_t ub = npix * sizeof(typename Pix<T>::v2);
+                const int batch = sor_pick_batch(ctx, npix, sizeof(typename Pix<T>::v2), OFX_BROX_MAX_ITERATIONS, G);
                 if (L.snap_planes < batch) {
-                    OFX_TRY(ofx_alloc(ctx, (size_t) n * batch, &L.Snap));
+                    OFX_TRY(ofx_alloc(ctx, npix * batch * G, &L.Snap));
                     L.snap_planes = batch;
                 }
-                auto window = [&](const SorWin &w, int blocks, int sweeps) -> int {
-                    hipLaunchKernelGGL(k_brox_window<T>, dim3(blocks, sweeps), dim3(sor_window_threads(w.R + 3)), 0,
+                const size_t snap_stride = npix * L.snap_planes;
+                auto window = [&](const SorWin &w, int blocks, int sweeps, unsigned runmask, int err_stride) -> int {
+                    const SorGrp grp = {runmask, err_stride, npix, snap_stride};
+                    hipLaunchKernelGGL(k_brox_window<T>, dim3(blocks, sweeps, G), dim3(sor_window_threads(w.R + 3)), 0,
                                        ctx->stream, L.DU, L.Snap, L.CO, (const T *) L.Dm, (const T *) L.Psis, ctx->d_err, w,
-                                       nx, ny, P.alpha);
+                                       grp, nx, ny, P.alpha);
                     OFX_LAUNCH_CHECK(ctx);
                     return OFX_OK;
                 };
-                auto take = [&](int k) -> int {
-                    OFX_HIP(ctx, hipMemcpyAsync(L.DU, L.Snap + (size_t) (k - 1) * n, ub, hipMemcpyDeviceToDevice, ctx->stream));
+                auto take = [&](int q, int k) -> int {
+                    OFX_HIP(ctx, hipMemcpyAsync(L.DU + q * npix, L.Snap + q * snap_stride + (size_t) (k - 1) * npix, ub,
+                                                hipMemcpyDeviceToDevice, ctx->stream));
                     return OFX_OK;
                 };
-                OFX_TRY(sor_window_loop(ctx, n, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
-                                        take, &nsor, &error, 1, &L.sweep_hint));
+                OFX_TRY(sor_window_loop(ctx, G, n, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
+                                        take, nsor, error, 1, &L.sweep_hint));
             } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
                 const size_t ub = (size_t) n * sizeof(typename Pix<T>::v2);
                 const unsigned gpx = ofx_cdiv(ny + 3, 64);
@@ -1097,8 +1244,8 @@ template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T
                     return OFX_OK;
                 };
                 OFX_TRY(sor_exact_loop(ctx, n, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, plane, save,
-                                       restore, &nsor, &error));
-            } else if (error > P.TOL) {
+                                       restore, &nsor[0], &error[0]));
+            } else if (error[0] > P.TOL) {
                 LoopSpec LS;
                 LS.max_iter = OFX_BROX_MAX_ITERATIONS;
                 LS.size = n;
@@ -1114,24 +1261,70 @@ template <typename T> static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T
                     OFX_LAUNCH_CHECK(ctx);
                     return OFX_OK;
                 };
-                OFX_TRY(ofx_run_loop(ctx, LS, launch, [](int) { return OFX_OK; }, &nsor, &error, ctx->profile ? &ms : nullptr));
+                OFX_TRY(ofx_run_loop(ctx, LS, launch, [](int) { return OFX_OK; }, &nsor[0], &error[0], ctx->profile ? &ms : nullptr));
             }
-            if (P.verbose) { printf("Iterations: %d\n", nsor); fflush(stdout); }                  // :392-394
-            if (scale < OFX_MAX_SCALES) {
-                if (solve < OFX_MAX_SOLVES) { S.iters[scale][solve] = nsor; S.error[scale][solve] = error; }
-                S.iter_ms[scale] += ms;
-                S.iter_launches[scale] += nsor;
+            if (P.verbose && G == 1) { printf("Iterations: %d\n", nsor[0]); fflush(stdout); }     // :392-394
+            for (int q = 0; q < G; q++) {
+                ofx_stats &S = stats[q];
+                if (scale < OFX_MAX_SCALES) {
+                    if (solve < OFX_MAX_SOLVES) { S.iters[scale][solve] = nsor[q]; S.error[scale][solve] = error[q]; }
+                    S.iter_ms[scale] += ms;
+                    S.iter_launches[scale] += nsor[q];
+                }
+                S.work_pix_iters += (double) nsor[q] * n;
             }
-            S.work_pix_iters += (double) nsor * n;
             solve++;
         }
-        hipLaunchKernelGGL(k_brox_add<T>, g1, b1, 0, ctx->stream, L.U, L.DU, n);                  // :398-401
+        hipLaunchKernelGGL(k_brox_add<T>, g1, b1, 0, ctx->stream, L.U, L.DU, (int) (npix * G));   // :398-401
         OFX_LAUNCH_CHECK(ctx);
     }
     return OFX_OK;
 }
 
-// src/brox_optic_flow_spatial.cpp:451-549
+// src/brox_optic_flow_spatial.cpp:451-549 for G pairs in lockstep; on success lv[0].U holds the flows
+template <typename T>
+static int brox_spatial_dev(ofx_ctx *ctx, int G, const T *const *dI1, const T *const *dI2, int nx, int ny,
+                            const BroxParams &P, int nscales, double nu, std::vector<BroxLevel<T>> &lv, ofx_stats *stats)
+{
+    if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "brox: group of %d pairs", G);
+    std::vector<int> nxs, nys;
+    OFX_TRY(op_pyramid_sizes(ctx, nx, ny, nscales, nu, nxs, nys));
+    for (int g = 0; g < G; g++) {
+        sor_stats_begin(&stats[g], nscales, P.inner_iter * P.outer_iter);
+        for (int s = 0; s < nscales && s < OFX_MAX_SCALES; s++) { stats[g].nx[s] = nxs[s]; stats[g].ny[s] = nys[s]; }
+    }
+    lv.resize(nscales);
+    for (int s = 0; s < nscales; s++) OFX_TRY(brox_level_alloc<T>(ctx, lv[s], nxs[s], nys[s], G));
+    {                                                                                              // :467-504
+        T *tmpA, *tmpB;
+        double *scr;
+        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &tmpA));
+        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &tmpB));
+        OFX_TRY(ofx_alloc(ctx, op_pyramid_scratch_doubles(), &scr));
+        std::vector<ImgLevel<T>> img(nscales);
+        for (int g = 0; g < G; g++) {
+            for (int s = 0; s < nscales; s++) {
+                img[s].nx = nxs[s];
+                img[s].ny = nys[s];
+                img[s].A = lv[s].I1 + g * lv[s].n();
+                img[s].B = lv[s].I2 + g * lv[s].n();
+            }
+            OFX_TRY(op_build_pyramid_into<T>(ctx, dI1[g], dI2[g], nscales, nu, BROX_SIGMA, img, tmpA, tmpB, scr));
+        }
+    }
+    BroxLevel<T> &C = lv[nscales - 1];
+    OFX_TRY(op_fill2<T>(ctx, C.U, C.n() * G));                                                     // :507-509
+    for (int s = nscales - 1; s >= 0; s--) {                                                      // :516
+        if (P.verbose && G == 1) { printf("Scale: %d\n", s); fflush(stdout); }
+        OFX_TRY(brox_single_scale_dev<T>(ctx, lv[s], P, s, stats));
+        if (s)
+            for (int g = 0; g < G; g++)
+                OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U + g * lv[s].n(), lv[s - 1].U + g * lv[s - 1].n(), lv[s].nx, lv[s].ny,
+                                           lv[s - 1].nx, lv[s - 1].ny, 1.0 / nu));                // :529-535
+    }
+    return OFX_OK;
+}
+
 template <typename T>
 static int brox_spatial_host(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nx, int ny,
                              const BroxParams &P, int nscales, double nu)
@@ -1140,27 +1333,21 @@ static int brox_spatial_host(ofx_ctx *ctx, const double *I1, const double *I2, d
     T *dI1, *dI2;
     OFX_TRY(upload_plane<T>(ctx, I1, n, &dI1));
     OFX_TRY(upload_plane<T>(ctx, I2, n, &dI2));
-    sor_stats_begin(ctx, nscales, P.inner_iter * P.outer_iter);
-    std::vector<ImgLevel<T>> img;
-    OFX_TRY(op_build_pyramid<T>(ctx, dI1, dI2, nx, ny, nscales, nu, BROX_SIGMA, img));             // :467-504
-    std::vector<BroxLevel<T>> lv(nscales);
-    for (int s = 0; s < nscales; s++) {
-        OFX_TRY(brox_level_alloc<T>(ctx, lv[s], img[s].nx, img[s].ny));
-        lv[s].I1 = img[s].A;
-        lv[s].I2 = img[s].B;
-        ctx->stats.nx[s] = img[s].nx;
-        ctx->stats.ny[s] = img[s].ny;
-    }
-    BroxLevel<T> &C = lv[nscales - 1];
-    OFX_TRY(op_fill2<T>(ctx, C.U, (size_t) C.nx * C.ny));                                          // :507-509
-    for (int s = nscales - 1; s >= 0; s--) {                                                      // :516
-        if (P.verbose) { printf("Scale: %d\n", s); fflush(stdout); }
-        OFX_TRY(brox_single_scale_dev<T>(ctx, lv[s], P, s));
-        if (s)
-            OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U, lv[s - 1].U, lv[s].nx, lv[s].ny, lv[s - 1].nx, lv[s - 1].ny,
-                                       1.0 / nu));                                                // :529-535
-    }
+    std::vector<BroxLevel<T>> lv;
+    const T *a = dI1, *b = dI2;
+    OFX_TRY(brox_spatial_dev<T>(ctx, 1, &a, &b, nx, ny, P, nscales, nu, lv, &ctx->stats));
     return download_flow<T>(ctx, lv[0].U, u, v, n);
+}
+
+template <typename T>
+static int brox_group_devapi(ofx_ctx *ctx, int G, const void *const *dI1, const void *const *dI2, void *const *d_flo, int nx,
+                             int ny, const BroxParams &P, int nscales, double nu, ofx_stats *stats)
+{
+    std::vector<BroxLevel<T>> lv;
+    OFX_TRY(brox_spatial_dev<T>(ctx, G, (const T *const *) dI1, (const T *const *) dI2, nx, ny, P, nscales, nu, lv, stats));
+    const size_t n = (size_t) nx * ny;
+    for (int g = 0; g < G; g++) OFX_TRY(op_to_flo<T>(ctx, lv[0].U + g * n, (float2 *) d_flo[g], n));
+    return OFX_OK;
 }
 
 extern "C" int ofx_brox_spatial(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nxx,
@@ -1176,6 +1363,101 @@ extern "C" int ofx_brox_spatial(ofx_ctx *ctx, const double *I1, const double *I2
                                       : brox_spatial_host<float>(ctx, I1, I2, u, v, nxx, nyy, P, nscales, nu);
     ctx->stats.total_ms = ofx_now_ms() - t0;
     return s;
+}
+
+extern "C" int ofx_brox_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *dI1, const void *const *dI2,
+                                  void *const *d_flo, int nxx, int nyy, double alpha, double gamma, int nscales, double nu,
+                                  double TOL, int inner_iter, int outer_iter, ofx_stats *stats_out)
+{
+    OFX_ENTER(ctx);
+    if (!dI1 || !dI2 || !d_flo) return ofx_fail(ctx, OFX_ERR_ARG, "brox: NULL pointer");
+    if (n_pairs < 1 || n_pairs > OFX_MAX_GROUP)
+        return ofx_fail(ctx, OFX_ERR_ARG, "brox: a lockstep group holds 1..%d pairs (got %d)", OFX_MAX_GROUP, n_pairs);
+    for (int g = 0; g < n_pairs; g++)
+        if (!dI1[g] || !dI2[g] || !d_flo[g]) return ofx_fail(ctx, OFX_ERR_ARG, "brox: NULL pointer (pair %d)", g);
+    if (inner_iter < 0 || outer_iter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "brox: negative iteration count");
+    const double t0 = ofx_now_ms();
+    const BroxParams P = {alpha, gamma, TOL, inner_iter, outer_iter, 0};
+    std::vector<ofx_stats> local(stats_out ? 0 : n_pairs);
+    ofx_stats *st = stats_out ? stats_out : local.data();
+    int s = ctx->precision == OFX_F64 ? brox_group_devapi<double>(ctx, n_pairs, dI1, dI2, d_flo, nxx, nyy, P, nscales, nu, st)
+                                      : brox_group_devapi<float>(ctx, n_pairs, dI1, dI2, d_flo, nxx, nyy, P, nscales, nu, st);
+    const double ms = ofx_now_ms() - t0;
+    for (int g = 0; g < n_pairs; g++) st[g].total_ms = ms;
+    ctx->stats = st[0];
+    return s;
+}
+
+// ---- batches of pairs for the SOR solvers: lockstep groups, one worker thread per context (as ofx_tvl1_batch_dev) ----
+template <class GroupFn>
+static int sor_batch_run(ofx_ctx *const *ctxs, int n_ctx, int n_pairs, int G, double *work_pix_iters, GroupFn group)
+{
+    const int n_groups = (n_pairs + G - 1) / G;
+    std::atomic<int> status(OFX_OK);
+    auto worker = [&](int w) {
+        std::vector<ofx_stats> st(G);
+        for (int q = w; q < n_groups; q += n_ctx) {
+            if (status.load() != OFX_OK) return;
+            const int first = q * G, cnt = (n_pairs - first < G) ? n_pairs - first : G;
+            const int s = group(ctxs[w], first, cnt, st.data());
+            if (s != OFX_OK) { int expected = OFX_OK; status.compare_exchange_strong(expected, s); return; }
+            if (work_pix_iters)
+                for (int g = 0; g < cnt; g++) work_pix_iters[first + g] = st[g].work_pix_iters;
+        }
+        (void) hipStreamSynchronize(ctxs[w]->stream);
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < n_ctx && w < n_groups; w++) th.emplace_back(worker, w);
+    worker(0);
+    for (auto &t : th) t.join();
+    return status.load();
+}
+
+// group size of the SOR batches: option "lockstep" of ctxs[0], else as large as possible (16), evened out over the
+// contexts like ofx_tvl1_batch_group_size
+static int sor_batch_group_size(ofx_ctx *const *ctxs, int n_ctx, int n_pairs)
+{
+    int G = ctxs[0]->lockstep;
+    if (G > 0) return G > OFX_MAX_GROUP ? OFX_MAX_GROUP : G;
+    if (n_pairs <= 1) return 1;
+    const int cap = OFX_MAX_GROUP;
+    const int rounds = (n_pairs + n_ctx * cap - 1) / (n_ctx * cap);
+    G = (n_pairs + n_ctx * rounds - 1) / (n_ctx * rounds);
+    return G < 1 ? 1 : G;
+}
+
+static int sor_batch_check(ofx_ctx *const *ctxs, int n_ctx, int n_pairs, const void *a, const void *b, const void *c)
+{
+    if (!ctxs || n_ctx < 1 || n_pairs < 0 || !a || !b || !c) return OFX_ERR_ARG;
+    for (int w = 0; w < n_ctx; w++)
+        if (!ctxs[w] || ctxs[w]->device != ctxs[0]->device || ctxs[w]->precision != ctxs[0]->precision) return OFX_ERR_ARG;
+    return OFX_OK;
+}
+
+extern "C" int ofx_hs_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI1, const void *const *dI2,
+                                void *const *d_flo, int n_pairs, int nx, int ny, double alpha, int nscales, double zfactor,
+                                int warps, double TOL, int maxiter, double *work_pix_iters)
+{
+    OFX_TRY(sor_batch_check(ctxs, n_ctx, n_pairs, dI1, dI2, d_flo));
+    if (n_pairs == 0) return OFX_OK;
+    const int G = sor_batch_group_size(ctxs, n_ctx, n_pairs);
+    return sor_batch_run(ctxs, n_ctx, n_pairs, G, work_pix_iters, [&](ofx_ctx *c, int first, int cnt, ofx_stats *st) {
+        return ofx_hs_group_dev(c, cnt, dI1 + first, dI2 + first, d_flo + first, nx, ny, alpha, nscales, zfactor, warps, TOL,
+                                maxiter, st);
+    });
+}
+
+extern "C" int ofx_brox_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI1, const void *const *dI2,
+                                  void *const *d_flo, int n_pairs, int nxx, int nyy, double alpha, double gamma, int nscales,
+                                  double nu, double TOL, int inner_iter, int outer_iter, double *work_pix_iters)
+{
+    OFX_TRY(sor_batch_check(ctxs, n_ctx, n_pairs, dI1, dI2, d_flo));
+    if (n_pairs == 0) return OFX_OK;
+    const int G = sor_batch_group_size(ctxs, n_ctx, n_pairs);
+    return sor_batch_run(ctxs, n_ctx, n_pairs, G, work_pix_iters, [&](ofx_ctx *c, int first, int cnt, ofx_stats *st) {
+        return ofx_brox_group_dev(c, cnt, dI1 + first, dI2 + first, d_flo + first, nxx, nyy, alpha, gamma, nscales, nu, TOL,
+                                  inner_iter, outer_iter, st);
+    });
 }
 
 
@@ -1416,18 +1698,18 @@ static int broxt_single_scale_dev(ofx_ctx *ctx, BroxtLevel<T> &L, const BroxPara
                 OFX_TRY(ofx_alloc(ctx, n1 * batch, &L.Snap));
                 L.snap_planes = batch;
             }
-            auto window = [&](const SorWin &w, int blocks, int sweeps) -> int {
+            auto window = [&](const SorWin &w, int blocks, int sweeps, unsigned, int) -> int {
                 hipLaunchKernelGGL(k_broxt_window<T>, dim3(blocks, nz, sweeps), dim3(sor_window_threads(w.R + 3)), 0,
                                    ctx->stream, L.DU, L.Snap, L.CO, (const T *) L.Dm, (const T *) L.Psis, ctx->d_err, w, nx,
                                    ny, nz, P.alpha);
                 OFX_LAUNCH_CHECK(ctx);
                 return OFX_OK;
             };
-            auto take = [&](int k) -> int {
+            auto take = [&](int, int k) -> int {
                 OFX_HIP(ctx, hipMemcpyAsync(L.DU, L.Snap + (size_t) (k - 1) * n1, ub, hipMemcpyDeviceToDevice, ctx->stream));
                 return OFX_OK;
             };
-            OFX_TRY(sor_window_loop(ctx, (int) n1, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
+            OFX_TRY(sor_window_loop(ctx, 1, (int) n1, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
                                     take, &nsor, &error, nz, &L.sweep_hint));                                       // :430-461
             if (P.verbose) { printf("Iterations: %d\n", nsor); fflush(stdout); }                     // :463-465
             if (scale < OFX_MAX_SCALES) {
@@ -1449,7 +1731,7 @@ static int broxt_host(ofx_ctx *ctx, const double *I, double *u, double *v, int n
                       int nscales, double nu)
 {
     const size_t n = (size_t) nx * ny;
-    int nxs[OFX_MAX_SCALES], nys[OFX_MAX_SCALES];
+    std::vector<int> nxs, nys;
     OFX_TRY(op_pyramid_sizes(ctx, nx, ny, nscales, nu, nxs, nys));
     sor_stats_begin(ctx, nscales, P.inner_iter * P.outer_iter);
     T *dI, *dummy, *tmpA, *tmpB;
@@ -1462,8 +1744,7 @@ static int broxt_host(ofx_ctx *ctx, const double *I, double *u, double *v, int n
     std::vector<BroxtLevel<T>> lv(nscales);
     for (int s = 0; s < nscales; s++) {
         OFX_TRY(broxt_level_alloc<T>(ctx, lv[s], nxs[s], nys[s], frames));
-        ctx->stats.nx[s] = nxs[s];
-        ctx->stats.ny[s] = nys[s];
+        if (s < OFX_MAX_SCALES) { ctx->stats.nx[s] = nxs[s]; ctx->stats.ny[s] = nys[s]; }
     }
     // image_normalization_1 over the whole sequence (:548): the joint-min/max kernel of normalization_2 fed the
     // sequence twice computes the same 255 (I - min) / den

@@ -845,11 +845,11 @@ static int tvl1_multiscale_dev(ofx_ctx *ctx, int G, const T *const *dI0, const T
     if (P.warps < 1) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: warps=%d", P.warps);
     if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: group of %d pairs", G);
 
-    int nxs[OFX_MAX_SCALES], nys[OFX_MAX_SCALES];
+    std::vector<int> nxs, nys;
     OFX_TRY(op_pyramid_sizes(ctx, nxx, nyy, nscales, zfactor, nxs, nys));
     for (int g = 0; g < G; g++) {
         stats_begin(&stats[g], nscales, P.warps);
-        for (int s = 0; s < nscales; s++) { stats[g].nx[s] = nxs[s]; stats[g].ny[s] = nys[s]; }
+        for (int s = 0; s < nscales && s < OFX_MAX_SCALES; s++) { stats[g].nx[s] = nxs[s]; stats[g].ny[s] = nys[s]; }
     }
     lv.resize(nscales);
     for (int s = 0; s < nscales; s++) OFX_TRY(tvl1_level_alloc<T>(ctx, lv[s], nxs[s], nys[s], G, true));
@@ -1109,21 +1109,23 @@ extern "C" int ofx_tvl1_iterations(ofx_ctx *ctx, double *u1, double *u2, double 
 // 5 groups of 4 with one context working alone at the end.  Measured on MI355X (1080p f64, 4 contexts):
 // bigger groups keep winning up to the cap (32 pairs: groups of 4 / 8 = 48.9k / 50.6k Mpix*it/s; 64 pairs:
 // 4 / 8 / 16 = 49.5k / 50.8k / 51.2k).  The cap is OFX_MAX_GROUP, lowered so that all contexts' level arrays
-// together stay within half of the device memory that is free now.
+// together stay within half of the device memory that is free now (or within option "mem_budget" bytes).
 extern "C" int ofx_tvl1_batch_group_size(ofx_ctx *const *ctxs, int n_ctx, int n_pairs, int nx, int ny, int nscales,
                                          double zfactor)
 {
-    if (!ctxs || n_ctx < 1 || !ctxs[0] || n_pairs < 0 || nx < 1 || ny < 1) return OFX_ERR_ARG;
+    if (!ctxs || n_ctx < 1 || !ctxs[0] || n_pairs < 0 || nx < 1 || ny < 1) return -OFX_ERR_ARG;
     int G = ctxs[0]->lockstep;
     if (G > 0) return G > OFX_MAX_GROUP ? OFX_MAX_GROUP : G;
     if (n_pairs <= 1) return 1;
-    int nxs[OFX_MAX_SCALES], nys[OFX_MAX_SCALES];
+    std::vector<int> nxs, nys;
     const int st = op_pyramid_sizes(ctxs[0], nx, ny, nscales, zfactor, nxs, nys);
-    if (st != OFX_OK) return st;
+    if (st != OFX_OK) return -st;
     double px = 0;
     for (int s = 0; s < nscales; s++) px += (double) nxs[s] * nys[s];
     const double elem = ctxs[0]->precision == OFX_F32 ? 4.0 : 8.0;
-    const double per_pair = 12.0 * px * elem;                 // tvl1_level_alloc: 12 arrays per level
+    // tvl1_level_alloc: I0, I1, pb, R (1 element per pixel each) + pa, U[2], P1[2], P2[2], A (2 each) = 20 per level
+    const double per_pair = 20.0 * px * elem;
+    const double per_ctx = 2.0 * (double) nx * ny * elem + 64e6;   // pyramid temporaries, error slots, arena slack
     size_t mfree = 0, mtotal = 0;
     int dev_now = 0;
     (void) hipGetDevice(&dev_now);
@@ -1131,8 +1133,9 @@ extern "C" int ofx_tvl1_batch_group_size(ofx_ctx *const *ctxs, int n_ctx, int n_
     const hipError_t e = hipMemGetInfo(&mfree, &mtotal);
     (void) hipSetDevice(dev_now);
     int cap = OFX_MAX_GROUP;
-    if (e == hipSuccess) {
-        const double fit = 0.5 * (double) mfree / n_ctx / per_pair;
+    double budget = ctxs[0]->mem_budget > 0 ? ctxs[0]->mem_budget : (e == hipSuccess ? 0.5 * (double) mfree : -1.0);
+    if (budget >= 0) {
+        const double fit = (budget / n_ctx - per_ctx) / per_pair;
         if (fit < cap) cap = fit < 1.0 ? 1 : (int) fit;
     }
     const int rounds = (n_pairs + n_ctx * cap - 1) / (n_ctx * cap);
@@ -1154,7 +1157,7 @@ extern "C" int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *c
     for (int w = 0; w < n_ctx; w++)
         if (!ctxs[w] || ctxs[w]->device != ctxs[0]->device || ctxs[w]->precision != ctxs[0]->precision) return OFX_ERR_ARG;
     const int G = ofx_tvl1_batch_group_size(ctxs, n_ctx, n_pairs, nx, ny, nscales, zfactor);
-    if (G < 1) return G < 0 ? G : OFX_ERR_ARG;
+    if (G < 1) return G < 0 ? -G : OFX_ERR_ARG;                 // negative = -status of the failing check
     const int n_groups = (n_pairs + G - 1) / G;
     std::atomic<int> status(OFX_OK);
     auto worker = [&](int w) {

@@ -303,3 +303,118 @@ def test_hs_classic_f32_and_cli(gpu32, orc, synth, tmp_path):
     assert np.array_equal(got, np.stack([uo, vo], axis=-1).astype(np.float32))       # byte-identical payload
     r = subprocess.run([exe, "100", "20"], capture_output=True, text=True)
     assert "usage:" in r.stderr and r.returncode == len("usage:\n\t%s niter alpha a b f\n" % exe) % 256
+
+
+# ---- lockstep groups of the SOR solvers (ofx_hs_group_dev / ofx_brox_group_dev / *_batch_dev) ---------------------------
+def _group_inputs(synth, G, nx, ny):
+    import torch
+    pairs = [synth.pair("P0" if k % 3 == 2 else "P1", nx, ny, k) for k in range(G)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in pairs]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in pairs]
+    flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    return pairs, d0, d1, flo
+
+
+@pytest.mark.parametrize("G", [1, 2, 5, 16])
+def test_hs_lockstep_group_equals_pairs_solved_alone(gpu64, orc, synth, G):
+    """G different pairs through the same windowed launches (blockIdx.z = pair).  Each pair keeps its own error slots,
+    snapshots and stopping test: sweep tables equal the oracle's (reference order) pair by pair, and the .flo payloads
+    are bit-identical to the flows ofx_hs_pyramidal computes for the pair alone."""
+    nx, ny = 150, 97
+    kw = dict(alpha=15.0, nscales=3, zfactor=0.5, warps=4, TOL=1e-4, maxiter=150)
+    pairs, d0, d1, flo = _group_inputs(synth, G, nx, ny)
+    st = gpu64.hs_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1], [flo[k].data_ptr() for k in range(G)],
+                            nx, ny, **kw)
+    gpu64.synchronize()
+    got = flo.cpu().numpy()
+    seen = set()
+    for k in range(G):
+        ua, va = gpu64.hs_pyramidal(pairs[k][0], pairs[k][1], **kw)
+        assert np.array_equal(st[k].iterations(), gpu64.stats().iterations()), k
+        assert np.array_equal(got[k], np.stack([ua, va], axis=-1).astype(np.float32)), k
+        uo, vo, it_o = orc.hs_pyramidal(pairs[k][0], pairs[k][1], **kw)
+        assert np.array_equal(st[k].iterations(), it_o), k
+        assert np.abs(ua - uo).max() < 1e-12 and np.abs(va - vo).max() < 1e-12
+        seen.add(tuple(int(x) for x in np.asarray(it_o).ravel()))
+    if G >= 5:
+        assert len(seen) > 1        # the pairs really stop at different sweeps
+
+
+@pytest.mark.parametrize("G", [1, 3, 16])
+def test_brox_lockstep_group_equals_pairs_solved_alone(gpu64, orc, synth, G):
+    nx, ny = 140, 90
+    kw = dict(alpha=50.0, gamma=10.0, nscales=3, nu=0.5, TOL=1e-4, inner=2, outer=4)
+    pairs, d0, d1, flo = _group_inputs(synth, G, nx, ny)
+    st = gpu64.brox_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1], [flo[k].data_ptr() for k in range(G)],
+                              nx, ny, **kw)
+    gpu64.synchronize()
+    got = flo.cpu().numpy()
+    for k in range(G):
+        ua, va = gpu64.brox_spatial(pairs[k][0], pairs[k][1], **kw)
+        assert np.array_equal(st[k].iterations(), gpu64.stats().iterations()), k
+        assert np.array_equal(got[k], np.stack([ua, va], axis=-1).astype(np.float32)), k
+        uo, vo, it_o = orc.brox_spatial(pairs[k][0], pairs[k][1], **kw)
+        assert np.array_equal(st[k].iterations(), it_o), k
+        assert np.abs(ua - uo).max() < 1e-11 and np.abs(va - vo).max() < 1e-11
+
+
+def test_sor_groups_with_small_batches_and_windows(gpu64, synth):
+    """pairs that stop in different batches of a solve (small snapshot capacity) and odd window / row-block sizes"""
+    nx, ny, G = 96, 70, 4
+    kw = dict(alpha=10.0, nscales=2, zfactor=0.5, warps=3, TOL=1e-5, maxiter=90)
+    pairs, d0, d1, flo = _group_inputs(synth, G, nx, ny)
+    want = [gpu64.hs_pyramidal(p[0], p[1], **kw) + (gpu64.stats().iterations().copy(),) for p in pairs]
+    for batch, window, rows in ((5, 3, 16), (9, 8, 64), (300, 5, 7)):
+        for name, val in (("sor_batch", batch), ("sor_window", window), ("sor_rows", rows)):
+            gpu64.set_option(name, val)
+        try:
+            st = gpu64.hs_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1],
+                                    [flo[k].data_ptr() for k in range(G)], nx, ny, **kw)
+            gpu64.synchronize()
+        finally:
+            for name in ("sor_batch", "sor_window", "sor_rows"):
+                gpu64.set_option(name, 0)
+        got = flo.cpu().numpy()
+        for k in range(G):
+            assert np.array_equal(st[k].iterations(), want[k][2]), (batch, k)
+            assert np.array_equal(got[k], np.stack(want[k][:2], axis=-1).astype(np.float32)), (batch, k)
+
+
+def test_sor_batch_entry_points(ofx_mod, synth):
+    """ofx_hs_batch_dev / ofx_brox_batch_dev: 7 pairs on 2 contexts (groups of 4 + 3), work records per pair"""
+    nx, ny, n = 120, 80, 7
+    pairs, d0, d1, flo = _group_inputs(synth, n, nx, ny)
+    ctxs = [ofx_mod.Ofx(0, ofx_mod.F64) for _ in range(2)]
+    solo = ofx_mod.Ofx(0, ofx_mod.F64)
+    ptr = lambda ts: [t.data_ptr() for t in ts]
+    hk = dict(alpha=20.0, nscales=3, zfactor=0.5, warps=3, TOL=1e-4, maxiter=100)
+    work = ofx_mod.hs_batch_dev(ctxs, ptr(d0), ptr(d1), [flo[k].data_ptr() for k in range(n)], nx, ny, **hk)
+    got = flo.cpu().numpy().copy()
+    for k in range(n):
+        u, v = solo.hs_pyramidal(pairs[k][0], pairs[k][1], **hk)
+        assert np.array_equal(got[k], np.stack([u, v], axis=-1).astype(np.float32)), k
+        assert work[k] == solo.stats().work_pix_iters
+    bk = dict(alpha=50.0, gamma=10.0, nscales=3, nu=0.5, TOL=1e-4, inner=1, outer=3)
+    work = ofx_mod.brox_batch_dev(ctxs, ptr(d0), ptr(d1), [flo[k].data_ptr() for k in range(n)], nx, ny, **bk)
+    got = flo.cpu().numpy().copy()
+    for k in range(n):
+        u, v = solo.brox_spatial(pairs[k][0], pairs[k][1], **bk)
+        assert np.array_equal(got[k], np.stack([u, v], axis=-1).astype(np.float32)), k
+        assert work[k] == solo.stats().work_pix_iters
+    for c in ctxs + [solo]:
+        c.close()
+
+
+def test_sor_groups_need_the_exact_mode(ofx_mod, gpu64, synth):
+    pairs, d0, d1, flo = _group_inputs(synth, 2, 64, 48)
+    gpu64.set_option("sor_exact", 0)
+    try:
+        with pytest.raises(ofx_mod.OfxError) as e:
+            gpu64.hs_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1], [flo[k].data_ptr() for k in range(2)],
+                               64, 48, nscales=2)
+        assert e.value.status == 1
+    finally:
+        gpu64.set_option("sor_exact", 1)
+    with pytest.raises(ofx_mod.OfxError):
+        gpu64.brox_group_dev([], [], [], 64, 48)
