@@ -94,6 +94,10 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *   "sor_window"     time steps per launch of sor_exact = 1 (default 8)
  *   "sor_rows"       rows per workgroup (row block of a sweep) of sor_exact = 1 (default 64)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
+ *   "store_a"        TV-L1, fused pairs: a loop that stops on the first iteration of a pair needs the state between the
+ *                         two iterations; 1 (default) = a launch also stores it when the previous error is within 1.5x
+ *                         of the threshold (the host then just switches buffers), 0 = never (the iteration is
+ *                         recomputed alone), 2 = always.  Results are bit-identical in all three settings.
  *   "warp_lds"       1/0  TV-L1 warp with the bicubic taps staged through LDS (default 1)
  *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default 0 = ofx_tvl1_batch_group_size's
  *                         rule: as large as possible, evened out over the contexts; at most 16)

@@ -64,6 +64,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->rows_per_wave = 0;     // 0 = pick per level
     ctx->rows_per_wave2 = 0;
     ctx->fuse2 = 1;             // two TV-L1 iterations per launch
+    ctx->store_a = 1;
     ctx->concurrency = 1;
     ctx->lockstep = 0;
     ctx->warp_lds = 1;
@@ -181,6 +182,11 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
         return OFX_OK;
     }
     if (!strcmp(name, "fuse2")) { ctx->fuse2 = value != 0; return OFX_OK; }
+    if (!strcmp(name, "store_a")) {
+        if (value != 0 && value != 1 && value != 2) return ofx_fail(ctx, OFX_ERR_ARG, "store_a must be 0, 1 or 2");
+        ctx->store_a = (int) value;
+        return OFX_OK;
+    }
     if (!strcmp(name, "chunk")) {
         if (value < 0 || value > OFX_TVL1_MAX_ITERATIONS) return ofx_fail(ctx, OFX_ERR_ARG, "chunk out of range");
         ctx->chunk = (int) value;

@@ -21,6 +21,9 @@ struct OfxIterState {
     int    n;        // iterations that did real work so far (== reference's `n`)
     int    done;     // 1: the stopping test fired (or MAX reached)
     double error;    // value of the stopping criterion after iteration n
+    int    apred;    // TV-L1 fused pairs: n is odd and the launch that ran iteration n - 1 had predicted the stop and
+                     // stored its intermediate state (tvl1_store_a in ofx_tvl1.hip, same formula)
+    int    pad_;
 };
 
 struct OfxSlab {
@@ -52,6 +55,8 @@ struct ofx_ctx {
     int rows_per_wave;
     int rows_per_wave2;
     int fuse2;
+    int store_a;        // TV-L1 fused pairs: 1 (default) store the intermediate state when a stop is plausible, 0 never
+                        // (odd stops are recomputed), 2 always (tests)
     int concurrency;    // contexts expected to share the device (tuning hint, default 1)
     int lockstep;       // pairs per lockstep group in ofx_tvl1_batch_dev (0 = default)
     int warp_lds;       // 1 (default): TV-L1 warp with the taps staged through LDS; 0: gathered from global memory

@@ -52,6 +52,8 @@ struct LoopSpec {
     int    chunk;      // sweeps per poll
     bool   fixed;      // run exactly max_iter sweeps (stopping test disabled)
     bool   pairs;      // the solver fuses two sweeps per launch where it can (TV-L1)
+    double afac = 0.0; // pairs only: a fused launch whose previous error is <= thr * afac also stores the state between
+                       // its two sweeps (0 = never); the finalize kernel reports whether the stopping launch did
 };
 
 int ofx_loop_reserve(ofx_ctx *ctx, int max_iter);                      // err slots for max_iter sweeps
@@ -72,10 +74,12 @@ static inline int ofx_loop_finalize(ofx_ctx *ctx, const LoopSpec &L, int start, 
 // take (ctx->d_err, k, thr) and use the helpers above.  With L.pairs the second sweep of a pair runs even
 // when the first one ended the loop; if that happens for any problem (n odd), redo(k_of) is called ONCE with
 // k_of[g] = n_g - 1 for those problems and -1 for the others, and must recompute sweep k_of[g] of each such
-// problem alone from the pair's untouched input buffers.  Returns the reference's n and error per problem.
+// problem alone from the pair's untouched input buffers.  Problems whose stopping launch had stored its intermediate
+// state (L.afac, or bit g of amask0 for a loop that stopped in its very first launch) need no redo: took_alt[g] = 1
+// tells the caller to continue from that stored state.  Returns the reference's n and error per problem.
 template <class LaunchFn, class RedoFn>
 static int ofx_run_loop_group(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn launch, RedoFn redo, int *n_out,
-                              double *err_out, float *ms_out)
+                              double *err_out, float *ms_out, unsigned amask0 = 0, int *took_alt = nullptr)
 {
     if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "loop group of %d problems", G);
     const int per = L.max_iter + 1;                      // +1: scratch slot for the redo's error
@@ -135,7 +139,10 @@ static int ofx_run_loop_group(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn l
     int redo_k[OFX_MAX_GROUP];
     bool any_redo = false;
     for (int g = 0; g < G; g++) {
-        const bool r = S.pairs && (fin[g].n & 1) && fin[g].n != S.max_iter;
+        bool r = S.pairs && (fin[g].n & 1) && fin[g].n != S.max_iter;
+        const bool stored = r && took_alt && (fin[g].apred || (fin[g].n == 1 && ((amask0 >> g) & 1u)));
+        if (took_alt) took_alt[g] = stored ? 1 : 0;
+        r = r && !stored;
         redo_k[g] = r ? fin[g].n - 1 : -1;
         any_redo = any_redo || r;
     }

@@ -6,7 +6,7 @@
 // value at exit.
 __global__ __launch_bounds__(1024) void k_loop_finalize(const double *__restrict__ err, int slots_per_problem, int start,
                                                         int launched, int max_iter, int size, double thr, int crit,
-                                                        OfxIterState *st, OfxIterState *host_st)
+                                                        double afac, OfxIterState *st, OfxIterState *host_st)
 {
     extern __shared__ double s_err[];
     err += (size_t) blockIdx.x * slots_per_problem * OFX_NSHARD;
@@ -22,18 +22,29 @@ __global__ __launch_bounds__(1024) void k_loop_finalize(const double *__restrict
         if (lane == 0) s_err[k - start] = e;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (w == 0) {                                           // every lane of wave 0 computes the same record
         int n = launched, done = (launched >= max_iter);
         double error = launched > start ? s_err[launched - start - 1] : st->error;
         for (int k = start; k < launched; k++) {
             if (!(s_err[k - start] > thr)) { n = k + 1; done = 1; error = s_err[k - start]; break; }
         }
-        st->n = n;
-        st->done = done;
-        st->error = error;
-        host_st->n = n;                                     // pinned host memory: visible once the kernel retires
-        host_st->error = error;
-        host_st->done = done;
+        // odd n: iteration n - 1 was the first of a fused pair; its launch stored the intermediate state iff the
+        // error of iteration n - 2 was within afac of the threshold (tvl1_store_a)
+        int apred = 0;
+        if (afac > 0.0 && done && (n & 1) && n >= 3) {
+            const double e = loop_error_from_sum(wave_allreduce_sum(err[(size_t) (n - 2) * OFX_NSHARD + lane]), size, crit);
+            apred = e <= thr * afac;
+        }
+        if (lane == 0) {
+            st->n = n;
+            st->done = done;
+            st->error = error;
+            st->apred = apred;
+            host_st->n = n;                                 // pinned host memory: visible once the kernel retires
+            host_st->error = error;
+            host_st->apred = apred;
+            host_st->done = done;
+        }
     }
 }
 
@@ -42,7 +53,7 @@ int ofx_loop_finalize_group(ofx_ctx *ctx, const LoopSpec &L, int G, int slots_pe
 {
     const size_t shmem = sizeof(double) * (size_t) (launched - start);
     hipLaunchKernelGGL(k_loop_finalize, dim3(G), dim3(1024), shmem, ctx->stream, (const double *) ctx->d_err,
-                       slots_per_problem, start, launched, L.max_iter, L.size, L.thr, L.crit, ctx->d_state, host_slot);
+                       slots_per_problem, start, launched, L.max_iter, L.size, L.thr, L.crit, L.afac, ctx->d_state, host_slot);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
     return OFX_OK;

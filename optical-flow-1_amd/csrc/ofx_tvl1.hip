@@ -150,30 +150,51 @@ OFX_DEV void tvl1_dual(double2 p1, double2 p2, double2 un, double r1, double r2,
 // iterations ended the loop: with two iterations fused per launch the second one always executes, so a
 // loop that ends on the first iteration of a pair leaves a live error in the second slot -- looking
 // two slots back keeps every later launch a no-op (and the pair's input buffers intact for the redo).
-OFX_DEV bool tvl1_continues(double prev1, double prev2, int k, int size, double eps2)
+// e1 = error of iteration k - 1 (0 when k = 0): the fused kernel predicts from it whether the loop may stop on ITS
+// first iteration (tvl1_store_a).
+OFX_DEV bool tvl1_continues(double prev1, double prev2, int k, int size, double eps2, double &e1)
 {
-    if (k >= 1 && !(loop_error_from_sum(wave_allreduce_sum(prev1), size, OFX_CRIT_MEAN) > eps2)) return false;
+    e1 = 0.0;
+    if (k >= 1) {
+        e1 = loop_error_from_sum(wave_allreduce_sum(prev1), size, OFX_CRIT_MEAN);
+        if (!(e1 > eps2)) return false;
+    }
     if (k >= 2 && !(loop_error_from_sum(wave_allreduce_sum(prev2), size, OFX_CRIT_MEAN) > eps2)) return false;
     return true;
 }
+// The fused kernel always executes both iterations of its pair, so a loop that stops on the FIRST one (odd n) needs
+// the intermediate state u_A / p_A, which normally never leaves the registers.  A launch therefore also stores that
+// state into the third buffer of the rotation when the stop is plausible: the previous error is within a factor
+// `afac` of the threshold (errors decay by 6-14 % per iteration near convergence) or the host asks for it (bit of
+// `amask`: first launch of a loop whose predecessor stopped at once).  If the loop then stops on the first
+// iteration the host just points the level at that buffer; a miss falls back to recomputing the single iteration.
+// Same formula in k_loop_finalize, which tells the host whether the stopping launch had stored its A state.
+OFX_DEV bool tvl1_store_a(int k, double e1, double eps2, double afac) { return k >= 1 && e1 <= eps2 * afac; }
 
 // ---- lockstep groups ------------------------------------------------------------------------------------
 // Every array of a level holds G image pairs back to back (pair g at element offset g * nx * ny) and one
 // launch serves all of them: blockIdx.y = pair.  The pairs of a group run the same launches k = 0, 1, ...
-// but converge on their own: each has its own error slots (err + g * err_stride) and its own ping-pong
-// phase -- bit g of `inmask` says which half pair g reads in THIS launch (the host knows every pair's n
-// at the end of each loop, so it can keep the phases itself).  A pair whose loop has ended just returns.
-template <typename V> struct PairHalves {
-    const V *in;
-    V       *out;
+// but converge on their own: each has its own error slots (err + g * err_stride) and its own position in the
+// buffer rotation (the host knows every pair's n at the end of each loop, so it keeps the positions itself).  A
+// pair whose loop has ended just returns.
+// The three buffers of a state array rotate: launch unit j (a fused pair, or a single iteration) of pair g reads
+// buffer (b_g + j) % 3, writes (b_g + j + 1) % 3, and (b_g + j + 2) % 3 -- the output of the unit after next --
+// receives the intermediate state when tvl1_store_a says so.  `code` holds the index read in THIS launch, two bits
+// per pair.
+template <typename V> struct Tri {
+    V *b0, *b1, *b2;
 };
-template <typename V>
-OFX_DEV PairHalves<V> pick_halves(V *h0, V *h1, unsigned inmask, int g, size_t n)
+template <typename V> struct TriSel {
+    const V *in;
+    V       *out, *alt;
+};
+template <typename V> OFX_DEV TriSel<V> pick3(const Tri<V> &t, unsigned code, int g, size_t n)
 {
-    const bool in1 = (inmask >> g) & 1u;
-    PairHalves<V> r;
-    r.in = (in1 ? h1 : h0) + (size_t) g * n;
-    r.out = (in1 ? h0 : h1) + (size_t) g * n;
+    const unsigned i = (code >> (2 * g)) & 3u;
+    TriSel<V> r;
+    r.in = (i == 0 ? t.b0 : (i == 1 ? t.b1 : t.b2)) + (size_t) g * n;
+    r.out = (i == 0 ? t.b1 : (i == 1 ? t.b2 : t.b0)) + (size_t) g * n;
+    r.alt = (i == 0 ? t.b2 : (i == 1 ? t.b0 : t.b1)) + (size_t) g * n;
     return r;
 }
 
@@ -188,12 +209,10 @@ OFX_DEV PairHalves<V> pick_halves(V *h0, V *h1, unsigned inmask, int g, size_t n
 #endif
 template <typename T>
 __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
-    typename Pix<T>::v2 *__restrict__ U0, typename Pix<T>::v2 *__restrict__ U1,
-    typename Pix<T>::v2 *__restrict__ P10, typename Pix<T>::v2 *__restrict__ P11,
-    typename Pix<T>::v2 *__restrict__ P20, typename Pix<T>::v2 *__restrict__ P21,
+    Tri<typename Pix<T>::v2> Ut, Tri<typename Pix<T>::v2> P1t, Tri<typename Pix<T>::v2> P2t,
     const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int check, int slot,
     int nx, int ny, int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2,
-    unsigned inmask, unsigned runmask, int err_stride)
+    unsigned incode, unsigned runmask, int err_stride)
 {
     using v2 = typename Pix<T>::v2;
     const int lane = threadIdx.x & 63;
@@ -201,8 +220,7 @@ __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
     const int g = blockIdx.y;
     if (!((runmask >> g) & 1u)) return;
     const size_t npix = (size_t) nx * ny;
-    const PairHalves<v2> hu = pick_halves(U0, U1, inmask, g, npix), h1 = pick_halves(P10, P11, inmask, g, npix),
-                         h2 = pick_halves(P20, P21, inmask, g, npix);
+    const TriSel<v2> hu = pick3(Ut, incode, g, npix), h1 = pick3(P1t, incode, g, npix), h2 = pick3(P2t, incode, g, npix);
     const v2 *__restrict__ Uin = hu.in, *__restrict__ P1in = h1.in, *__restrict__ P2in = h2.in;
     v2 *__restrict__ Uout = hu.out, *__restrict__ P1out = h1.out, *__restrict__ P2out = h2.out;
     const v2 *__restrict__ A = Ag + (size_t) g * npix;
@@ -241,7 +259,8 @@ __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
     }
 
     // stopping test of src/tvl1flow.cpp:113
-    if (!tvl1_continues(prev1, prev2, check, nx * ny, eps2)) return;
+    double e1;
+    if (!tvl1_continues(prev1, prev2, check, nx * ny, eps2, e1)) return;
     if (idle) return;
 
     const unsigned level_bytes = (unsigned) nx * (unsigned) ny * E2;
@@ -311,69 +330,25 @@ __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
 #else
 #define OFX_ITER2_BOUNDS __launch_bounds__(256)
 #endif
-template <typename T, bool NT>
-__global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
-    typename Pix<T>::v2 *__restrict__ U0, typename Pix<T>::v2 *__restrict__ U1,
-    typename Pix<T>::v2 *__restrict__ P10, typename Pix<T>::v2 *__restrict__ P11,
-    typename Pix<T>::v2 *__restrict__ P20, typename Pix<T>::v2 *__restrict__ P21,
-    const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int k, int nx, int ny,
-    int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2, unsigned inmask,
-    int err_stride)
+// The marching loop of the fused kernel.  SA = true also stores the intermediate state u_A / p_A (tvl1_store_a).
+template <typename T, bool NT, bool SA>
+OFX_DEV void tvl1_iter2_march(const typename Pix<T>::v2 *__restrict__ Uin, const typename Pix<T>::v2 *__restrict__ P1in,
+                              const typename Pix<T>::v2 *__restrict__ P2in, const typename Pix<T>::v2 *__restrict__ A,
+                              const T *__restrict__ R, typename Pix<T>::v2 *Uout, typename Pix<T>::v2 *P1out,
+                              typename Pix<T>::v2 *P2out, typename Pix<T>::v2 *Ualt, typename Pix<T>::v2 *P1alt,
+                              typename Pix<T>::v2 *P2alt, double *__restrict__ err, int k, int gw, int nx, int ny, int y0,
+                              int yend, int ys, int yl, bool lef, bool rig, bool owner, unsigned off, unsigned so,
+                              double up12, double up22, RowIn<T> cur, double l_t, double theta, double taut)
 {
-    using v2 = typename Pix<T>::v2;
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int g = blockIdx.y;
-    const size_t npix = (size_t) nx * ny;
-    const PairHalves<v2> hu = pick_halves(U0, U1, inmask, g, npix), h1 = pick_halves(P10, P11, inmask, g, npix),
-                         h2 = pick_halves(P20, P21, inmask, g, npix);
-    const v2 *__restrict__ Uin = hu.in, *__restrict__ P1in = h1.in, *__restrict__ P2in = h2.in;
-    v2 *__restrict__ Uout = hu.out, *__restrict__ P1out = h1.out, *__restrict__ P2out = h2.out;
-    const v2 *__restrict__ A = Ag + (size_t) g * npix;
-    const T *__restrict__ R = Rg + (size_t) g * npix;
-    double *__restrict__ err = errg + (size_t) g * err_stride;
-    const double prev1 = loop_fetch_prev(err, k), prev2 = loop_fetch_prev(err, k - 1);
-
-    const int band = gw / strips_pad;
-#ifdef OFX_XCD_ROT   // A/B knob: rotate the tile columns from band to band, so vertical neighbours sit on different XCDs
-    const int strip = (gw % strips_pad + 4 * OFX_XCD_ROT * band) % strips_pad;
-#else
-    const int strip = gw % strips_pad;
-#endif
-    const int y0 = band * rows;
-    const bool idle = (strip >= strips_x) || (y0 >= ny);
-    const int yend = (y0 + rows < ny) ? y0 + rows : ny;     // rows [y0, yend) are written by this wave
-    const int ys = y0 > 0 ? y0 - 1 : 0;                      // first row loaded
-    const int yl = (yend + 1 < ny - 1) ? yend + 1 : ny - 1;  // last row loaded
-
-    const int c = strip * STRIP2_OUT - 2 + lane;            // lanes 0,1 / 62,63 are halo columns
-    const int cc = c < 0 ? 0 : (c > nx - 1 ? nx - 1 : c);
-    const bool lef = (c == 0), rig = (c == nx - 1);
-    const bool owner = (lane >= 2) && (lane <= STRIP2_OUT + 1) && (c < nx);
-
-    const unsigned E2 = 2 * sizeof(T);                      // bytes per pixel of the pair arrays
+    const unsigned E2 = 2 * sizeof(T);
     const unsigned row2 = (unsigned) nx * E2;
-    unsigned off = ((unsigned) ys * nx + cc) * E2;          // byte offset of (y, cc): loads
 #ifdef OFX_CEIL_ALU
     const unsigned off0 = off;
 #endif
-    unsigned so = ((unsigned) ys * nx + (c < 0 ? 0 : c)) * E2;   // ... of (y, c): stores (owner lanes only)
-
-    double up12 = 0.0, up22 = 0.0;                           // p12 / p22 (iteration k-1) of row y-1
-    RowIn<T> cur;
-    if (!idle) {
-        if (ys > 0) {
-            up12 = ldw2(at(P1in, off - row2)).y;
-            up22 = ldw2(at(P2in, off - row2)).y;
-        }
-        cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off);
-    }
-    if (!tvl1_continues(prev1, prev2, k, nx * ny, eps2)) return;
-    if (idle) return;
-
     const double2 z2 = make_double2(0.0, 0.0);
     const unsigned level_bytes = (unsigned) nx * (unsigned) ny * E2;
     const ofx_rsrc rU = make_rsrc(Uout, level_bytes), rP1 = make_rsrc(P1out, level_bytes), rP2 = make_rsrc(P2out, level_bytes);
+    const ofx_rsrc rUa = make_rsrc(Ualt, level_bytes), rP1a = make_rsrc(P1alt, level_bytes), rP2a = make_rsrc(P2alt, level_bytes);
     double accA = 0.0, accB = 0.0;
     double2 uA0 = z2, uA1 = z2, uA2 = z2;                    // u_A of rows y, y-1, y-2
     double2 a1 = z2, a2 = z2;                                // (I1wx, I1wy) of rows y-1, y-2
@@ -392,13 +367,16 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
 
         // S1: u_A(y)
         const bool have1 = (y <= yl);
+        unsigned sa1 = OFX_OOB, sa2 = OFX_OOB;
         if (have1) {
             const double l11 = wave_shift_up(cur.p1.x);
             const double l21 = wave_shift_up(cur.p2.x);
             uA0 = tvl1_primal<T>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0, y == ny - 1,
                                  l_t, theta);
-            if (owner && y >= y0 && y < yend)
+            if (owner && y >= y0 && y < yend) {
                 accA += (uA0.x - cur.u.x) * (uA0.x - cur.u.x) + (uA0.y - cur.u.y) * (uA0.y - cur.u.y);
+                sa1 = so;
+            }
         }
         // S2: p_A(y-1)
         double2 pAna = z2, pAnb = z2;
@@ -408,6 +386,7 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
             tvl1_dual<T>(p0a, p0b, uA1, n1, n2, uA0, rig, y - 1 == ny - 1, taut, pAna, pAnb);
             pAna.x = rnd_to<T>(pAna.x); pAna.y = rnd_to<T>(pAna.y);
             pAnb.x = rnd_to<T>(pAnb.x); pAnb.y = rnd_to<T>(pAnb.y);
+            if (owner && y - 1 >= y0 && y - 1 < yend) sa2 = so - row2;
         }
         // S3: u_B(y-2)
         unsigned st3 = OFX_OOB, st4 = OFX_OOB;
@@ -432,10 +411,15 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
 #ifdef OFX_CEIL_ALU   // ceiling experiment: every store dropped (still issued, out of range), loads stay on the first row
         st3 = OFX_OOB; st4 = OFX_OOB;
 #endif
-        // the three stores of this step: always issued, lanes / steps with nothing to write are out of range
+        // the stores of this step: always issued, lanes / steps with nothing to write are out of range
         bst2<NT>(rU, st3, uB0, Uout);
         bst2<NT>(rP1, st4, q1, P1out);
         bst2<NT>(rP2, st4, q2, P2out);
+        if (SA) {
+            bst2<NT>(rUa, sa1, uA0, Ualt);
+            bst2<NT>(rP1a, sa2, pAna, P1alt);
+            bst2<NT>(rP2a, sa2, pAnb, P2alt);
+        }
         // advance the pipeline by one row
         uA2 = uA1; uA1 = uA0;
         a2 = a1; a1 = cur.a;
@@ -452,6 +436,68 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
     loop_accumulate(err, k + 1, accB, gw);
 }
 
+template <typename T, bool NT>
+__global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
+    Tri<typename Pix<T>::v2> Ut, Tri<typename Pix<T>::v2> P1t, Tri<typename Pix<T>::v2> P2t,
+    const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int k, int nx, int ny,
+    int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2, unsigned incode,
+    unsigned amask, double afac, int err_stride)
+{
+    using v2 = typename Pix<T>::v2;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = blockIdx.y;
+    const size_t npix = (size_t) nx * ny;
+    const TriSel<v2> hu = pick3(Ut, incode, g, npix), h1 = pick3(P1t, incode, g, npix), h2 = pick3(P2t, incode, g, npix);
+    const v2 *__restrict__ Uin = hu.in, *__restrict__ P1in = h1.in, *__restrict__ P2in = h2.in;
+    const v2 *__restrict__ A = Ag + (size_t) g * npix;
+    const T *__restrict__ R = Rg + (size_t) g * npix;
+    double *__restrict__ err = errg + (size_t) g * err_stride;
+    const double prev1 = loop_fetch_prev(err, k), prev2 = loop_fetch_prev(err, k - 1);
+
+    const int band = gw / strips_pad;
+#ifdef OFX_XCD_ROT   // A/B knob: rotate the tile columns from band to band, so vertical neighbours sit on different XCDs
+    const int strip = (gw % strips_pad + 4 * OFX_XCD_ROT * band) % strips_pad;
+#else
+    const int strip = gw % strips_pad;
+#endif
+    const int y0 = band * rows;
+    const bool idle = (strip >= strips_x) || (y0 >= ny);
+    const int yend = (y0 + rows < ny) ? y0 + rows : ny;     // rows [y0, yend) are written by this wave
+    const int ys = y0 > 0 ? y0 - 1 : 0;                      // first row loaded
+    const int yl = (yend + 1 < ny - 1) ? yend + 1 : ny - 1;  // last row loaded
+
+    const int c = strip * STRIP2_OUT - 2 + lane;            // lanes 0,1 / 62,63 are halo columns
+    const int cc = c < 0 ? 0 : (c > nx - 1 ? nx - 1 : c);
+    const bool lef = (c == 0), rig = (c == nx - 1);
+    const bool owner = (lane >= 2) && (lane <= STRIP2_OUT + 1) && (c < nx);
+
+    const unsigned E2 = 2 * sizeof(T);                      // bytes per pixel of the pair arrays
+    const unsigned row2 = (unsigned) nx * E2;
+    const unsigned off = ((unsigned) ys * nx + cc) * E2;    // byte offset of (y, cc): loads
+    const unsigned so = ((unsigned) ys * nx + (c < 0 ? 0 : c)) * E2;   // ... of (y, c): stores (owner lanes only)
+
+    double up12 = 0.0, up22 = 0.0;                           // p12 / p22 (iteration k-1) of row y-1
+    RowIn<T> cur;
+    if (!idle) {
+        if (ys > 0) {
+            up12 = ldw2(at(P1in, off - row2)).y;
+            up22 = ldw2(at(P2in, off - row2)).y;
+        }
+        cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off);
+    }
+    double e1;
+    if (!tvl1_continues(prev1, prev2, k, nx * ny, eps2, e1)) return;
+    if (idle) return;
+    // wave-uniform (every wave of the pair reduces the same shards in the same order)
+    if (((amask >> g) & 1u) || tvl1_store_a(k, e1, eps2, afac))
+        tvl1_iter2_march<T, NT, true>(Uin, P1in, P2in, A, R, hu.out, h1.out, h2.out, hu.alt, h1.alt, h2.alt, err, k, gw, nx, ny,
+                                      y0, yend, ys, yl, lef, rig, owner, off, so, up12, up22, cur, l_t, theta, taut);
+    else
+        tvl1_iter2_march<T, NT, false>(Uin, P1in, P2in, A, R, hu.out, h1.out, h2.out, hu.alt, h1.alt, h2.alt, err, k, gw, nx, ny,
+                                       y0, yend, ys, yl, lef, rig, owner, off, so, up12, up22, cur, l_t, theta, taut);
+}
+
 // Warp + linearisation (src/tvl1flow.cpp:94-109): the three bicubic warps of I1, I1x, I1y share one
 // set of tap indices and one 4-wide gather per tap; writes A = (I1wx, I1wy) and R = rho_c.
 // Thread block of the warp kernel: BX x BY pixels, a wave covers BX x (64 / BX) of them.
@@ -461,8 +507,8 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
 #endif
 template <typename T>
 __global__ void k_tvl1_warp(const typename Pix<T>::v2 *__restrict__ pag, const T *__restrict__ pbg, const T *__restrict__ I0g,
-                            const typename Pix<T>::v2 *__restrict__ U0, const typename Pix<T>::v2 *__restrict__ U1,
-                            typename Pix<T>::v2 *__restrict__ Ag, T *__restrict__ Rg, int nx, int ny, unsigned curmask)
+                            Tri<typename Pix<T>::v2> Ut,
+                            typename Pix<T>::v2 *__restrict__ Ag, T *__restrict__ Rg, int nx, int ny, unsigned curcode)
 {
     const int j = blockIdx.x * OFX_WARP_BX + threadIdx.x;
     const int i = blockIdx.y * OFX_WARP_BY + threadIdx.y;
@@ -472,7 +518,7 @@ __global__ void k_tvl1_warp(const typename Pix<T>::v2 *__restrict__ pag, const T
     const typename Pix<T>::v2 *__restrict__ pa = pag + goff;
     const T *__restrict__ pb = pbg + goff;
     const T *__restrict__ I0 = I0g + goff;
-    const typename Pix<T>::v2 *__restrict__ U = (((curmask >> g) & 1u) ? U1 : U0) + goff;
+    const typename Pix<T>::v2 *__restrict__ U = pick3(Ut, curcode, g, (size_t) nx * ny).in;
     typename Pix<T>::v2 *__restrict__ A = Ag + goff;
     T *__restrict__ R = Rg + goff;
     const size_t p = (size_t) i * nx + j;
@@ -515,8 +561,8 @@ __global__ void k_tvl1_warp(const typename Pix<T>::v2 *__restrict__ pag, const T
 template <typename T>
 __global__ __launch_bounds__(WARP_NT) WARP_ATTR void k_tvl1_warp_lds(
     const typename Pix<T>::v2 *__restrict__ pag, const T *__restrict__ pbg, const T *__restrict__ I0g,
-    const typename Pix<T>::v2 *__restrict__ U0, const typename Pix<T>::v2 *__restrict__ U1,
-    typename Pix<T>::v2 *__restrict__ Ag, T *__restrict__ Rg, int nx, int ny, unsigned curmask)
+    Tri<typename Pix<T>::v2> Ut, typename Pix<T>::v2 *__restrict__ Ag, T *__restrict__ Rg, int nx, int ny,
+    unsigned curcode)
 {
     __shared__ double2 s_a[WARP_TH * WARP_TW];
     __shared__ double s_b[WARP_TH * WARP_TW];
@@ -529,7 +575,7 @@ __global__ __launch_bounds__(WARP_NT) WARP_ATTR void k_tvl1_warp_lds(
     const size_t goff = (size_t) g * nx * ny;
     const typename Pix<T>::v2 *__restrict__ pa = pag + goff;
     const T *__restrict__ pb = pbg + goff;
-    const typename Pix<T>::v2 *__restrict__ U = (((curmask >> g) & 1u) ? U1 : U0) + goff;
+    const typename Pix<T>::v2 *__restrict__ U = pick3(Ut, curcode, g, (size_t) nx * ny).in;
     const size_t p = (size_t) (inside ? i : 0) * nx + (inside ? j : 0);
     double2 u = make_double2(0.0, 0.0);
     BicubicTaps t;
@@ -603,10 +649,18 @@ template <typename T> struct Tvl1Level {
     T  *I0, *I1;
     v2 *pa;         // (I1, I1x): gathered by the warp
     T  *pb;         // I1y
-    v2 *U[2], *P1[2], *P2[2], *A;
+    v2 *U[3], *P1[3], *P2[3], *A;
     T  *R;
-    unsigned cur;   // bit g: which ping-pong half holds the live u / p of pair g
+    unsigned cur;   // two bits per pair: which buffer of the rotation holds the live u / p of pair g
+    int last_n[OFX_MAX_GROUP];   // iterations of the previous loop of pair g at this level (0 = none yet)
     size_t n() const { return (size_t) nx * ny; }
+    unsigned curidx(int g) const { return (cur >> (2 * g)) & 3u; }
+    v2 *Ucur(int g) const { return U[curidx(g)] + (size_t) g * n(); }
+    v2 *P1cur(int g) const { return P1[curidx(g)] + (size_t) g * n(); }
+    v2 *P2cur(int g) const { return P2[curidx(g)] + (size_t) g * n(); }
+    Tri<v2> Ut() const { return Tri<v2>{U[0], U[1], U[2]}; }
+    Tri<v2> P1t() const { return Tri<v2>{P1[0], P1[1], P1[2]}; }
+    Tri<v2> P2t() const { return Tri<v2>{P2[0], P2[1], P2[2]}; }
 };
 
 struct Tvl1Params {
@@ -622,6 +676,7 @@ template <typename T> static int tvl1_level_alloc(ofx_ctx *ctx, Tvl1Level<T> &L,
     L.ny = ny;
     L.G = G;
     L.cur = 0;
+    for (int g = 0; g < OFX_MAX_GROUP; g++) L.last_n[g] = 0;
     L.I0 = L.I1 = nullptr;
     if (images) {
         OFX_TRY(ofx_alloc(ctx, n, &L.I0));
@@ -629,7 +684,7 @@ template <typename T> static int tvl1_level_alloc(ofx_ctx *ctx, Tvl1Level<T> &L,
     }
     OFX_TRY(ofx_alloc(ctx, n, &L.pa));
     OFX_TRY(ofx_alloc(ctx, n, &L.pb));
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < 3; h++) {
         OFX_TRY(ofx_alloc(ctx, n, &L.U[h]));
         OFX_TRY(ofx_alloc(ctx, n, &L.P1[h]));
         OFX_TRY(ofx_alloc(ctx, n, &L.P2[h]));
@@ -732,50 +787,69 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
     S.pairs = pairs;
     const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
     const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
-    const unsigned base = L.cur & all;
     // one launch touches 15 storage elements per pixel; beyond the Infinity Cache its output is streamed out
     const bool nt_stores = (double) nx * ny * G * 15.0 * sizeof(T) > 300e6;
-    // launch unit u (a pair of iterations, or a single one) reads half (base_g + u) & 1 of pair g and writes
-    // the other one
-    auto single = [&](unsigned inmask, unsigned runmask, int check, int slot, double thr) -> int {
-        hipLaunchKernelGGL(k_tvl1_iter<T>, dim3(gx1, G), block, 0, ctx->stream, L.U[0], L.U[1], L.P1[0], L.P1[1], L.P2[0],
-                           L.P2[1], L.A, (const T *) L.R, ctx->d_err, check, slot, nx, ny, rows, strips_x, strips_pad,
-                           l_t, theta, taut, thr, inmask, runmask, err_stride);
+    // Launch unit j (a fused pair of iterations, or a single one) of pair g reads buffer (b_g + j) % 3 of the rotation
+    // and writes (b_g + j + 1) % 3; (b_g + j + 2) % 3 receives the intermediate state of a fused pair (tvl1_store_a).
+    unsigned b0[OFX_MAX_GROUP];
+    for (int g = 0; g < G; g++) b0[g] = L.curidx(g);
+    auto code_of = [&](unsigned unit) -> unsigned {
+        unsigned c = 0;
+        for (int g = 0; g < G; g++) c |= ((b0[g] + unit) % 3u) << (2 * g);
+        return c;
+    };
+    // intermediate state: stored when the previous error is within this factor of the threshold ...
+    // (option "store_a": 0 = never, 2 = always -- 1e300 stands for "any error" -- for the tests)
+    const bool sa = pairs && !P.fixed && ctx->store_a != 0;
+    S.afac = sa ? (ctx->store_a == 2 ? 1e300 : 1.5) : 0.0;
+    // ... and by the first launch of a loop whose predecessor (previous warp, same level) stopped within two iterations
+    unsigned amask0 = 0;
+    if (sa)
+        for (int g = 0; g < G; g++)
+            if (ctx->store_a == 2 || (L.last_n[g] >= 1 && L.last_n[g] <= 2)) amask0 |= 1u << g;
+    auto single = [&](unsigned incode, unsigned runmask, int check, int slot, double thr) -> int {
+        hipLaunchKernelGGL(k_tvl1_iter<T>, dim3(gx1, G), block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A, (const T *) L.R,
+                           ctx->d_err, check, slot, nx, ny, rows, strips_x, strips_pad, l_t, theta, taut, thr, incode, runmask,
+                           err_stride);
         OFX_LAUNCH_CHECK(ctx);
         return OFX_OK;
     };
     auto launch = [&](int k, int cnt, double thr) -> int {
-        const int unit = (pairs ? k / 2 : k);
-        const unsigned inmask = (unit & 1) ? (base ^ all) : base;
-        if (cnt == 1) return single(inmask, all, k, k, thr);
+        const unsigned incode = code_of((unsigned) (pairs ? k / 2 : k));
+        if (cnt == 1) return single(incode, all, k, k, thr);
+        const unsigned amask = k == 0 ? amask0 : 0u;
         if (nt_stores)
-            hipLaunchKernelGGL((k_tvl1_iter2<T, true>), grid2, block, 0, ctx->stream, L.U[0], L.U[1], L.P1[0], L.P1[1],
-                               L.P2[0], L.P2[1], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
-                               strips2_pad, l_t, theta, taut, thr, inmask, err_stride);
+            hipLaunchKernelGGL((k_tvl1_iter2<T, true>), grid2, block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A,
+                               (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x, strips2_pad, l_t, theta, taut, thr,
+                               incode, amask, S.afac, err_stride);
         else
-            hipLaunchKernelGGL((k_tvl1_iter2<T, false>), grid2, block, 0, ctx->stream, L.U[0], L.U[1], L.P1[0], L.P1[1],
-                               L.P2[0], L.P2[1], L.A, (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x,
-                               strips2_pad, l_t, theta, taut, thr, inmask, err_stride);
+            hipLaunchKernelGGL((k_tvl1_iter2<T, false>), grid2, block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A,
+                               (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x, strips2_pad, l_t, theta, taut, thr,
+                               incode, amask, S.afac, err_stride);
         OFX_LAUNCH_CHECK(ctx);
         return OFX_OK;
     };
-    // pairs whose loop ended on the first iteration of a fused pair: recompute that iteration alone (no stopping
-    // test, error into the scratch slot) from each pair's input half, overwriting its output half -- one launch
-    // for all of them (runmask), every pair reading the half its own unit k / 2 started from
+    // pairs whose loop ended on the first iteration of a fused pair WITHOUT its intermediate state in the third
+    // buffer: recompute that iteration alone (no stopping test, error into the scratch slot) from the unit's input
+    // buffer into its output buffer -- one launch for all of them (runmask)
     auto redo = [&](const int *k_of) -> int {
-        unsigned inmask = 0, runmask = 0;
+        unsigned incode = 0, runmask = 0;
         for (int g = 0; g < G; g++) {
             if (k_of[g] < 0) continue;
             runmask |= 1u << g;
-            inmask |= ((((base >> g) & 1u) + (unsigned) (k_of[g] / 2)) & 1u) << g;
+            incode |= ((b0[g] + (unsigned) (k_of[g] / 2)) % 3u) << (2 * g);
         }
-        return single(inmask, runmask, 0, S.max_iter, -1.0);
+        return single(incode, runmask, 0, S.max_iter, -1.0);
     };
-    OFX_TRY(ofx_run_loop_group(ctx, S, G, launch, redo, n_out, err_out, ms_out));
+    int took_alt[OFX_MAX_GROUP];
+    OFX_TRY(ofx_run_loop_group(ctx, S, G, launch, redo, n_out, err_out, ms_out, amask0, took_alt));
     unsigned cur = 0;
     for (int g = 0; g < G; g++) {
         const unsigned units = (unsigned) (pairs ? (n_out[g] + 1) / 2 : n_out[g]);
-        cur |= ((((base >> g) & 1u) + units) & 1u) << g;
+        // normally the result is the output of the last unit = the input of the next; a loop that stopped on the first
+        // iteration of a pair whose intermediate state was stored continues from the unit's third buffer instead
+        cur |= ((b0[g] + units + (took_alt[g] ? 1u : 0u)) % 3u) << (2 * g);
+        L.last_n[g] = n_out[g];
     }
     L.cur = cur;
     return OFX_OK;
@@ -792,22 +866,23 @@ static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params
     if (nx < 2 || ny < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: level %dx%d too small", nx, ny);
 
     for (int g = 0; g < G; g++) OFX_TRY(op_grad_pack<T>(ctx, L.I1 + g * n, L.pa + g * n, L.pb + g * n, nx, ny));   // :84
-    // p = 0 in the half each pair's u lives in (:87-90); both halves are cleared when the phases differ
-    for (int h = 0; h < 2; h++) {
+    // p = 0 in the buffer each pair's u lives in (:87-90)
+    for (int h = 0; h < 3; h++) {
         bool used = false;
-        for (int g = 0; g < G; g++) used = used || (((L.cur >> g) & 1u) == (unsigned) h);
+        for (int g = 0; g < G; g++) used = used || (L.curidx(g) == (unsigned) h);
         if (!used) continue;
         OFX_TRY(op_fill2<T>(ctx, L.P1[h], n * G));
         OFX_TRY(op_fill2<T>(ctx, L.P2[h], n * G));
     }
+    for (int g = 0; g < G; g++) L.last_n[g] = 0;
 
     for (int w = 0; w < P.warps; w++) {
         if (ctx->warp_lds)
             hipLaunchKernelGGL(k_tvl1_warp_lds<T>, dim3(ofx_cdiv(nx, 32), ofx_cdiv(ny, WARP_BY), G), dim3(32, WARP_BY), 0, ctx->stream, L.pa,
-                               (const T *) L.pb, (const T *) L.I0, L.U[0], L.U[1], L.A, L.R, nx, ny, L.cur);
+                               (const T *) L.pb, (const T *) L.I0, L.Ut(), L.A, L.R, nx, ny, L.cur);
         else
-            hipLaunchKernelGGL(k_tvl1_warp<T>, g2, b2, 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I0, L.U[0],
-                               L.U[1], L.A, L.R, nx, ny, L.cur);                                                   // :94-109
+            hipLaunchKernelGGL(k_tvl1_warp<T>, g2, b2, 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I0, L.Ut(),
+                               L.A, L.R, nx, ny, L.cur);                                                           // :94-109
         OFX_LAUNCH_CHECK(ctx);
         // p lives in the same ping-pong half as u
         int it[OFX_MAX_GROUP];
@@ -880,7 +955,7 @@ static int tvl1_multiscale_dev(ofx_ctx *ctx, int G, const T *const *dI0, const T
         if (!s) break;
         lv[s - 1].cur = 0;
         for (int g = 0; g < G; g++)
-            OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U[(lv[s].cur >> g) & 1u] + g * lv[s].n(), lv[s - 1].U[0] + g * lv[s - 1].n(),
+            OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].Ucur(g), lv[s - 1].U[0] + g * lv[s - 1].n(),
                                        lv[s].nx, lv[s].ny, lv[s - 1].nx, lv[s - 1].ny, 1.0 / zfactor));   // :302-309
     }
     return OFX_OK;
@@ -921,7 +996,7 @@ static int tvl1_multiscale_host(ofx_ctx *ctx, const double *I0, const double *I1
     double *d1, *d2;
     OFX_TRY(ofx_alloc(ctx, n, &d1));
     OFX_TRY(ofx_alloc(ctx, n, &d2));
-    OFX_TRY(op_deinterleave2<T>(ctx, lv[0].U[lv[0].cur & 1u], d1, d2, n));
+    OFX_TRY(op_deinterleave2<T>(ctx, lv[0].Ucur(0), d1, d2, n));
     OFX_HIP(ctx, hipMemcpyAsync(u1, d1, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     OFX_HIP(ctx, hipMemcpyAsync(u2, d2, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -953,7 +1028,7 @@ static int tvl1_group_devapi(ofx_ctx *ctx, int G, const void *const *dI0, const 
                                    stats));
     const size_t n = (size_t) nx * ny;
     for (int g = 0; g < G; g++)
-        OFX_TRY(op_to_flo<T>(ctx, lv[0].U[(lv[0].cur >> g) & 1u] + g * n, (float2 *) d_flo[g], n));
+        OFX_TRY(op_to_flo<T>(ctx, lv[0].Ucur(g), (float2 *) d_flo[g], n));
     return OFX_OK;
 }
 
@@ -1014,7 +1089,7 @@ static int tvl1_single_scale_host(ofx_ctx *ctx, const double *I0, const double *
     OFX_HIP(ctx, hipMemcpyAsync(d2, u2, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     OFX_TRY(op_interleave2<T>(ctx, d1, d2, L.U[0], n));
     OFX_TRY(tvl1_single_scale_dev<T>(ctx, L, P, 0, &ctx->stats));
-    OFX_TRY(op_deinterleave2<T>(ctx, L.U[L.cur & 1u], d1, d2, n));
+    OFX_TRY(op_deinterleave2<T>(ctx, L.Ucur(0), d1, d2, n));
     OFX_HIP(ctx, hipMemcpyAsync(u1, d1, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     OFX_HIP(ctx, hipMemcpyAsync(u2, d2, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1071,9 +1146,8 @@ static int tvl1_iterations_host(ofx_ctx *ctx, double *u1, double *u2, double *p1
     ctx->stats.work_pix_iters = (double) it * nx * ny;
     if (error) *error = err;
 
-    const int h = (int) (L.cur & 1u);
     struct { double *a, *b; typename Pix<T>::v2 *src; } down[3] = {
-        {u1, u2, L.U[h]}, {p11, p12, L.P1[h]}, {p21, p22, L.P2[h]}};
+        {u1, u2, L.Ucur(0)}, {p11, p12, L.P1cur(0)}, {p21, p22, L.P2cur(0)}};
     for (auto &e : down) {
         OFX_TRY(op_deinterleave2<T>(ctx, e.src, d[0], d[1], n));
         OFX_HIP(ctx, hipMemcpyAsync(e.a, d[0], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1123,8 +1197,8 @@ extern "C" int ofx_tvl1_batch_group_size(ofx_ctx *const *ctxs, int n_ctx, int n_
     double px = 0;
     for (int s = 0; s < nscales; s++) px += (double) nxs[s] * nys[s];
     const double elem = ctxs[0]->precision == OFX_F32 ? 4.0 : 8.0;
-    // tvl1_level_alloc: I0, I1, pb, R (1 element per pixel each) + pa, U[2], P1[2], P2[2], A (2 each) = 20 per level
-    const double per_pair = 20.0 * px * elem;
+    // tvl1_level_alloc: I0, I1, pb, R (1 element per pixel each) + pa, U[3], P1[3], P2[3], A (2 each) = 26 per level
+    const double per_pair = 26.0 * px * elem;
     const double per_ctx = 2.0 * (double) nx * ny * elem + 64e6;   // pyramid temporaries, error slots, arena slack
     size_t mfree = 0, mtotal = 0;
     int dev_now = 0;

@@ -303,3 +303,37 @@ def test_warp_tile_and_gather_paths_agree(gpu64, orc, synth, amp):
             gpu64.set_option("warp_lds", 1)
     assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1])
     assert np.abs(res[1][0] - uo).max() < 1e-9 and np.abs(res[1][1] - vo).max() < 1e-9
+
+
+@pytest.mark.parametrize("G", [1, 5])
+def test_stored_intermediate_state_equals_recomputed_iteration(gpu64, orc, synth, G):
+    """A loop that stops on the first iteration of a fused pair continues either from the intermediate state a
+    predicting launch stored in the third buffer of the rotation (option store_a = 1 default, 2 = every launch) or
+    from a recomputation of that iteration (store_a = 0): iteration tables and .flo payloads must be identical, and
+    equal to the oracle's."""
+    import torch
+    nx, ny = 203, 131
+    pairs = [synth.pair("P0" if k % 3 == 2 else "P1", nx, ny, k) for k in range(G)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in pairs]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in pairs]
+    flo = torch.zeros((3, G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    tables = []
+    for mode in (0, 1, 2):
+        gpu64.set_option("store_a", mode)
+        try:
+            st = gpu64.tvl1_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1],
+                                      [flo[mode, k].data_ptr() for k in range(G)], nx, ny, nscales=4, **PAR)
+            gpu64.synchronize()
+        finally:
+            gpu64.set_option("store_a", 1)
+        tables.append([s.iterations().copy() for s in st])
+    got = flo.cpu().numpy()
+    odd = 0
+    for k in range(G):
+        uo, vo, it, _ = orc.tvl1_multiscale(pairs[k][0], pairs[k][1], nscales=4, **PAR)
+        for mode in (0, 1, 2):
+            assert np.array_equal(tables[mode][k], it), (mode, k)
+            assert np.array_equal(got[mode, k], np.stack([uo, vo], axis=-1).astype(np.float32)), (mode, k)
+        odd += int((np.asarray(it) % 2 == 1).sum())
+    assert odd > 0              # the case under test really occurs
