@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--check", action="store_true",
                     help="N > 1: rank 0 re-solves every pair of every rank and compares the gathered payloads byte for byte")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value for every context (A/B runs)")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--rows2", type=int, default=0)
@@ -328,6 +329,8 @@ def main():
             c_.set_option("chunk", a.chunk)
         if a.rows2:
             c_.set_option("rows_per_wave2", a.rows2)
+        for kv in a.opt:
+            c_.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     nrounds = a.rounds if a.rounds > 0 else (2 if (world > 1 and nsteps >= 32) else 1)
     rounds = split_rounds(slots, nrounds, nstreams)          # by slot count: identical on every rank (gather sizes must agree)
     # group size: --lockstep, or what the library picks for the largest round on these contexts; pinned for the whole
