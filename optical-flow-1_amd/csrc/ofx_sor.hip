@@ -26,6 +26,8 @@
 #include <thread>
 
 #define HS_SOR_W 1.9                 // src/horn_schunck_pyramidal.cpp:21
+#define HS_PLANE_C_SKEW 2             // Horn-Schunck hyperplanes: pos = 2 i + j (k_hs_plane)
+#define BROX_PLANE_C_SKEW 1           // Brox hyperplanes: pos = i + j (k_brox_plane)
 #define HS_PRESMOOTH_SIGMA 0.8       // src/horn_schunck_pyramidal.cpp:22
 #define BROX_EPSILON 0.001           // src/brox_optic_flow_spatial.cpp:23
 #define BROX_SOR_W 1.9               // src/brox_optic_flow_spatial.cpp:25
@@ -81,16 +83,59 @@ __global__ void k_hs_warp(const typename Pix<T>::v2 *__restrict__ pa, const T *_
 // (An accessor that served same-launch hand-offs from an LDS ring was built and measured: correct, but slower --
 // a windowed step is bound by the memory latency of the PREVIOUS sweep's values and by one CU's f64 rate, not by
 // the store drain the ring removes.  DESIGN.md 5.3.)
-template <typename T, bool COH, bool SNAP> struct UGlobal {
-    typename Pix<T>::v2 *U, *snap;
+// ---- where pixel (i, j) of a plane lives --------------------------------------------------------------------------
+// LayRow: row-major, the layout of every array outside the windowed sweeps.
+// LaySkew: hyperplane-major.  In the windowed exact sweeps the lanes of a wave are consecutive ROWS of one hyperplane
+// (pixel (r, q - c r) for lane r), so in a row-major array every lane of every load sits in a different cache line: 64
+// lines per wave instruction, 13 memory instructions per update -- the vector L1 (one line per clock and CU) was the
+// bound, and a launch took 16x as long for 16 lockstep pairs (profiles/r02_c_*).  With element (i, j) at
+// (c i + j) ny + i the pixels of a hyperplane are contiguous in i, and so are all their neighbours (each lies on a
+// hyperplane q + const at row i + const): every access of a wave is one contiguous run.  The plane is padded to
+// (c (ny - 1) + nx) * ny elements; c = 2 for the 8-neighbour stencil of Horn-Schunck, 1 for Brox.
+struct LayRow {
     int nx;
-    OFX_DEV double2 get(int ii, int jj) const { return ldu2<COH>(U + (size_t) ii * nx + jj); }
+    OFX_DEV size_t idx(int i, int j) const { return (size_t) i * nx + j; }
+};
+struct LaySkew {
+    int ny, c;
+    OFX_DEV size_t idx(int i, int j) const { return (size_t) (c * i + j) * ny + i; }
+};
+static inline size_t skew_plane_elems(int nx, int ny, int c) { return (size_t) (c * (ny - 1) + nx) * ny; }
+
+template <typename T, bool COH, bool SNAP, class Lay = LayRow> struct UGlobal {
+    typename Pix<T>::v2 *U, *snap;
+    Lay lay;
+    OFX_DEV double2 get(int ii, int jj) const { return ldu2<COH>(U + lay.idx(ii, jj)); }
     OFX_DEV void put(int i, int j, double2 v) const
     {
-        stn2(U + (size_t) i * nx + j, v);
-        if (SNAP) stn2(snap + (size_t) i * nx + j, v);
+        const size_t p = lay.idx(i, j);
+        stn2(U + p, v);
+        if (SNAP) stn2(snap + p, v);
     }
 };
+
+// row-major <-> skewed copies of one array of a lockstep group (blockIdx.z = pair): IN = true writes dst[skew] =
+// src[row-major], false the other way.  Once per solve and array, next to tens of sweeps.
+template <typename V, bool IN>
+__global__ void k_skew(const V *__restrict__ src, V *__restrict__ dst, int nx, int ny, int c, size_t plane_s)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const LaySkew lay = {ny, c};
+    const size_t rm = (size_t) blockIdx.z * nx * ny + (size_t) i * nx + j, sk = blockIdx.z * plane_s + lay.idx(i, j);
+    if (IN) dst[sk] = src[rm];
+    else dst[rm] = src[sk];
+}
+template <typename V, bool IN>
+static int op_skew(ofx_ctx *ctx, const V *src, V *dst, int nx, int ny, int c, int G)
+{
+    hipLaunchKernelGGL((k_skew<V, IN>), dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), G), dim3(64, 4), 0, ctx->stream, src, dst, nx,
+                       ny, c, skew_plane_elems(nx, ny, c));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "skew copy launch failed: %s", hipGetErrorString(e));
+    return OFX_OK;
+}
 // SOR update of one pixel, src/horn_schunck_pyramidal.cpp:31-71.  Neighbour indices are the clamped
 // coordinates -- exactly what the reference's replicated border indices are (:161-228) -- in the order
 // up-left, up-right, bottom-left, bottom-right / up, left, bottom, right, with ONE quirk kept for
@@ -102,7 +147,7 @@ OFX_DEV double hs_point_acc(const Acc &acc, const typename Pix<T>::v2 *__restric
 {
     const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
     const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
-    const size_t p = (size_t) i * nx + j;
+    const size_t p = acc.lay.idx(i, j);
     double2 p1 = acc.get(iu, jl), p2 = acc.get(iu, jr);
     double2 p3 = acc.get(id, jl), p4 = acc.get(id, jr);
     if (i == ny - 1 && j == nx - 1) {
@@ -132,7 +177,15 @@ OFX_DEV double hs_point(typename Pix<T>::v2 *U, const typename Pix<T>::v2 *__res
                         const T *__restrict__ Dif, int i, int j, int nx, int ny, double alpha2,
                         typename Pix<T>::v2 *snap = nullptr)
 {
-    const UGlobal<T, COH, SNAP> acc = {U, snap, nx};
+    const UGlobal<T, COH, SNAP, LayRow> acc = {U, snap, LayRow{nx}};
+    return hs_point_acc<T>(acc, A, Dif, i, j, nx, ny, alpha2);
+}
+// the same on hyperplane-major arrays (windowed sweeps)
+template <typename T, bool COH, bool SNAP>
+OFX_DEV double hs_point_skew(typename Pix<T>::v2 *U, const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif,
+                             int i, int j, int nx, int ny, double alpha2, typename Pix<T>::v2 *snap)
+{
+    const UGlobal<T, COH, SNAP, LaySkew> acc = {U, snap, LaySkew{ny, HS_PLANE_C_SKEW}};
     return hs_point_acc<T>(acc, A, Dif, i, j, nx, ny, alpha2);
 }
 
@@ -232,7 +285,7 @@ struct SorWin {
 struct SorGrp {
     unsigned runmask;
     int      err_stride;     // doubles between the error slots of consecutive pairs
-    size_t   npix;           // elements between consecutive pairs in the level arrays
+    size_t   npix;           // elements of one (hyperplane-major, padded) plane = distance between consecutive pairs
     size_t   snap_stride;    // elements between the snapshot planes of consecutive pairs
 };
 // which plane item thread t of block b plays: its R rows, then the three shared items (first column, last
@@ -268,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_hs_window(typename Pix<T>::v2 *Ug, typ
     const typename Pix<T>::v2 *__restrict__ A = Ag + g * grp.npix;
     const T *__restrict__ Dif = Difg + g * grp.npix;
     double *__restrict__ err = errg + (size_t) g * grp.err_stride;
-    typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) s * nx * ny;
+    typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) s * grp.npix;
     const int r = sor_window_item(w, b, threadIdx.x, ny);
     double e = 0.0;
     for (int q = q_first; q < q_first + w.K; q++) {
@@ -277,9 +330,9 @@ __global__ __launch_bounds__(1024) void k_hs_window(typename Pix<T>::v2 *Ug, typ
             if (r == ny + 2) {
                 for (int corner = 0; corner < 4; corner++)
                     if (hs_plane_item(r, q, nx, ny, corner, i, j) && sor_border_block(i, ny, w.R) == b)
-                        e += hs_point<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
+                        e += hs_point_skew<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
             } else if (hs_plane_item(r, q, nx, ny, 0, i, j) && (r < ny || sor_border_block(i, ny, w.R) == b)) {
-                e += hs_point<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
+                e += hs_point_skew<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this step's stores have reached L2 ...
@@ -460,7 +513,10 @@ template <typename T> struct HsLevel {
     T *pb;                      // I2y
     typename Pix<T>::v2 *U, *A, *Uck;
     T *Dif;
-    typename Pix<T>::v2 *Snap;  // windowed exact mode: snap_planes snapshot planes per pair (allocated on first use)
+    // windowed exact mode, hyperplane-major (LaySkew) and allocated on first use: the unknowns, the coefficients and
+    // snap_planes snapshot planes per pair
+    typename Pix<T>::v2 *Us, *As, *Snap;
+    T *Difs;
     int snap_planes;
     int sweep_hint;             // sweeps of the previous solve at this level (sizes the next first batch)
     size_t n() const { return (size_t) nx * ny; }
@@ -483,7 +539,8 @@ template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int
     OFX_TRY(ofx_alloc(ctx, n, &L.Uck));
     OFX_TRY(ofx_alloc(ctx, n, &L.A));
     OFX_TRY(ofx_alloc(ctx, n, &L.Dif));
-    L.Snap = nullptr;
+    L.Snap = L.Us = L.As = nullptr;
+    L.Difs = nullptr;
     L.snap_planes = 0;
     L.sweep_hint = 0;
     return OFX_OK;
@@ -522,28 +579,38 @@ static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L, const HsParams &P, i
         for (int g = 0; g < G; g++) error[g] = 1000;                                          // :140
         float ms = 0.f;
         if (windowed) {
-            // windowed exact mode (default)
-            const size_t ub = npix * sizeof(typename Pix<T>::v2);
-            const int batch = sor_pick_batch(ctx, npix, sizeof(typename Pix<T>::v2), P.maxiter, G);
+            // windowed exact mode (default): the sweeps run on hyperplane-major copies of U, A, Dif
+            const size_t ps = skew_plane_elems(nx, ny, HS_PLANE_C_SKEW);
+            const size_t ub = ps * sizeof(typename Pix<T>::v2);
+            const int batch = sor_pick_batch(ctx, ps, sizeof(typename Pix<T>::v2), P.maxiter, G);
+            if (!L.Us) {
+                OFX_TRY(ofx_alloc(ctx, ps * G, &L.Us));
+                OFX_TRY(ofx_alloc(ctx, ps * G, &L.As));
+                OFX_TRY(ofx_alloc(ctx, ps * G, &L.Difs));
+            }
             if (L.snap_planes < batch) {
-                OFX_TRY(ofx_alloc(ctx, npix * batch * G, &L.Snap));
+                OFX_TRY(ofx_alloc(ctx, ps * batch * G, &L.Snap));
                 L.snap_planes = batch;
             }
-            const size_t snap_stride = npix * L.snap_planes;
+            OFX_TRY((op_skew<typename Pix<T>::v2, true>(ctx, L.U, L.Us, nx, ny, HS_PLANE_C_SKEW, G)));
+            OFX_TRY((op_skew<typename Pix<T>::v2, true>(ctx, L.A, L.As, nx, ny, HS_PLANE_C_SKEW, G)));
+            OFX_TRY((op_skew<T, true>(ctx, L.Dif, L.Difs, nx, ny, HS_PLANE_C_SKEW, G)));
+            const size_t snap_stride = ps * L.snap_planes;
             auto window = [&](const SorWin &w, int blocks, int sweeps, unsigned runmask, int err_stride) -> int {
-                const SorGrp grp = {runmask, err_stride, npix, snap_stride};
+                const SorGrp grp = {runmask, err_stride, ps, snap_stride};
                 hipLaunchKernelGGL(k_hs_window<T>, dim3(blocks, sweeps, G), dim3(sor_window_threads(w.R + 3)), 0, ctx->stream,
-                                   L.U, L.Snap, L.A, (const T *) L.Dif, ctx->d_err, w, grp, nx, ny, alpha2);
+                                   L.Us, L.Snap, L.As, (const T *) L.Difs, ctx->d_err, w, grp, nx, ny, alpha2);
                 OFX_LAUNCH_CHECK(ctx);
                 return OFX_OK;
             };
             auto take = [&](int g, int n) -> int {
-                OFX_HIP(ctx, hipMemcpyAsync(L.U + g * npix, L.Snap + g * snap_stride + (size_t) (n - 1) * npix, ub,
+                OFX_HIP(ctx, hipMemcpyAsync(L.Us + g * ps, L.Snap + g * snap_stride + (size_t) (n - 1) * ps, ub,
                                             hipMemcpyDeviceToDevice, ctx->stream));
                 return OFX_OK;
             };
             OFX_TRY(sor_window_loop(ctx, G, nx * ny, ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, batch, window, take,
                                     niter, error, 1, &L.sweep_hint));
+            OFX_TRY((op_skew<typename Pix<T>::v2, false>(ctx, L.Us, L.U, nx, ny, HS_PLANE_C_SKEW, G)));
         } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
             // one launch per time step (option sor_exact = 2): the reference implementation of the exact schedule
             const size_t ub = (size_t) nx * ny * sizeof(typename Pix<T>::v2);
@@ -898,16 +965,19 @@ __global__ void k_brox_psis(const typename Pix<T>::v2 *__restrict__ U, T *__rest
 
 // psi1..4 of src/brox_spatial_mask.cpp:16-93 at one pixel (0 across the image border)
 struct Psi4 { double p1, p2, p3, p4; };
+template <typename T, class Lay> OFX_DEV Psi4 brox_psi4_lay(const T *Psis, const Lay &lay, int i, int j, int nx, int ny)
+{
+    const double c = ldw(Psis + lay.idx(i, j));
+    Psi4 r;
+    r.p1 = (i < ny - 1) ? 0.5 * (ldw(Psis + lay.idx(i + 1, j)) + c) : 0.0;
+    r.p2 = (i > 0) ? 0.5 * (ldw(Psis + lay.idx(i - 1, j)) + c) : 0.0;
+    r.p3 = (j < nx - 1) ? 0.5 * (ldw(Psis + lay.idx(i, j + 1)) + c) : 0.0;
+    r.p4 = (j > 0) ? 0.5 * (ldw(Psis + lay.idx(i, j - 1)) + c) : 0.0;
+    return r;
+}
 template <typename T> OFX_DEV Psi4 brox_psi4(const T *Psis, int i, int j, int nx, int ny)
 {
-    const size_t k = (size_t) i * nx + j;
-    const double c = ldw(Psis + k);
-    Psi4 r;
-    r.p1 = (i < ny - 1) ? 0.5 * (ldw(Psis + k + nx) + c) : 0.0;
-    r.p2 = (i > 0) ? 0.5 * (ldw(Psis + k - nx) + c) : 0.0;
-    r.p3 = (j < nx - 1) ? 0.5 * (ldw(Psis + k + 1) + c) : 0.0;
-    r.p4 = (j > 0) ? 0.5 * (ldw(Psis + k - 1) + c) : 0.0;
-    return r;
+    return brox_psi4_lay(Psis, LayRow{nx}, i, j, nx, ny);
 }
 
 // div_u, div_v (src/brox_spatial_mask.cpp:100-171), div_d and du = dv = 0 (:261-274)
@@ -997,8 +1067,8 @@ template <typename T, class Acc>
 OFX_DEV double brox_point_acc(const Acc &acc, const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
                               const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha)
 {
-    const size_t p = (size_t) i * nx + j;
-    const Psi4 s = brox_psi4(Psis, i, j, nx, ny);
+    const size_t p = acc.lay.idx(i, j);
+    const Psi4 s = brox_psi4_lay(Psis, acc.lay, i, j, nx, ny);
     // a missing neighbour is addressed as the pixel itself (offset 0) with psi = 0, :332-388
     const double2 c = acc.get(i, j);
     const double2 dn = (i < ny - 1) ? acc.get(i + 1, j) : c, up = (i > 0) ? acc.get(i - 1, j) : c;
@@ -1020,7 +1090,16 @@ OFX_DEV double brox_point(typename Pix<T>::v2 *DU, const typename Pix<T>::v4 *__
                           const T *__restrict__ Dm, const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha,
                           typename Pix<T>::v2 *snap = nullptr)
 {
-    const UGlobal<T, COH, SNAP> acc = {DU, snap, nx};
+    const UGlobal<T, COH, SNAP, LayRow> acc = {DU, snap, LayRow{nx}};
+    return brox_point_acc<T>(acc, CO, Dm, Psis, i, j, nx, ny, alpha);
+}
+// the same on hyperplane-major arrays (windowed sweeps)
+template <typename T, bool COH, bool SNAP>
+OFX_DEV double brox_point_skew(typename Pix<T>::v2 *DU, const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
+                               const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha,
+                               typename Pix<T>::v2 *snap)
+{
+    const UGlobal<T, COH, SNAP, LaySkew> acc = {DU, snap, LaySkew{ny, BROX_PLANE_C_SKEW}};
     return brox_point_acc<T>(acc, CO, Dm, Psis, i, j, nx, ny, alpha);
 }
 
@@ -1098,7 +1177,7 @@ __global__ __launch_bounds__(1024) void k_brox_window(typename Pix<T>::v2 *DUg, 
     const T *__restrict__ Dm = Dmg + g * grp.npix;
     const T *__restrict__ Psis = Psisg + g * grp.npix;
     double *__restrict__ err = errg + (size_t) g * grp.err_stride;
-    typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) s * nx * ny;
+    typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) s * grp.npix;
     const int r = sor_window_item(w, b, threadIdx.x, ny);
     double e = 0.0;
     for (int q = q_first; q < q_first + w.K; q++) {
@@ -1107,9 +1186,9 @@ __global__ __launch_bounds__(1024) void k_brox_window(typename Pix<T>::v2 *DUg, 
             if (r == ny + 2) {
                 for (int corner = 0; corner < 4; corner++)
                     if (brox_plane_item(r, q, nx, ny, corner, i, j) && sor_border_block(i, ny, w.R) == b)
-                        e += brox_point<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
+                        e += brox_point_skew<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
             } else if (brox_plane_item(r, q, nx, ny, 0, i, j) && (r < ny || sor_border_block(i, ny, w.R) == b)) {
-                e += brox_point<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
+                e += brox_point_skew<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1136,7 +1215,11 @@ template <typename T> struct BroxLevel {
     T *I1, *I2, *Psis, *Dd, *Dm;
     v2 *G1, *PB, *WB, *U, *DV, *DU, *DUck;
     v4 *PA, *WA, *CO;
-    v2 *Snap;           // windowed exact mode: snap_planes snapshot planes of (du, dv) per pair
+    // windowed exact mode, hyperplane-major (LaySkew), allocated on first use: (du, dv), the coefficients, psi_s and
+    // snap_planes snapshot planes per pair
+    v2 *DUs, *Snap;
+    v4 *COs;
+    T  *Dms, *Psiss;
     int snap_planes;
     int sweep_hint;
     size_t n() const { return (size_t) nx * ny; }
@@ -1163,7 +1246,9 @@ template <typename T> static int brox_level_alloc(ofx_ctx *ctx, BroxLevel<T> &L,
     OFX_TRY(ofx_alloc(ctx, n, &L.PA));
     OFX_TRY(ofx_alloc(ctx, n, &L.WA));
     OFX_TRY(ofx_alloc(ctx, n, &L.CO));
-    L.Snap = nullptr;
+    L.Snap = L.DUs = nullptr;
+    L.COs = nullptr;
+    L.Dms = L.Psiss = nullptr;
     L.snap_planes = 0;
     L.sweep_hint = 0;
     return OFX_OK;
@@ -1204,28 +1289,41 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
             for (int q = 0; q < G; q++) error[q] = 1000;                                          // :312
             float ms = 0.f;
             if (windowed) {
-                const size_t ub = npix * sizeof(typename Pix<T>::v2);
-                const int batch = sor_pick_batch(ctx, npix, sizeof(typename Pix<T>::v2), OFX_BROX_MAX_ITERATIONS, G);
+                // the sweeps run on hyperplane-major copies of DU, CO, Dm, psi_s
+                const size_t ps = skew_plane_elems(nx, ny, BROX_PLANE_C_SKEW);
+                const size_t ub = ps * sizeof(typename Pix<T>::v2);
+                const int batch = sor_pick_batch(ctx, ps, sizeof(typename Pix<T>::v2), OFX_BROX_MAX_ITERATIONS, G);
+                if (!L.DUs) {
+                    OFX_TRY(ofx_alloc(ctx, ps * G, &L.DUs));
+                    OFX_TRY(ofx_alloc(ctx, ps * G, &L.COs));
+                    OFX_TRY(ofx_alloc(ctx, ps * G, &L.Dms));
+                    OFX_TRY(ofx_alloc(ctx, ps * G, &L.Psiss));
+                }
                 if (L.snap_planes < batch) {
-                    OFX_TRY(ofx_alloc(ctx, npix * batch * G, &L.Snap));
+                    OFX_TRY(ofx_alloc(ctx, ps * batch * G, &L.Snap));
                     L.snap_planes = batch;
                 }
-                const size_t snap_stride = npix * L.snap_planes;
+                OFX_TRY((op_skew<typename Pix<T>::v2, true>(ctx, L.DU, L.DUs, nx, ny, BROX_PLANE_C_SKEW, G)));
+                OFX_TRY((op_skew<typename Pix<T>::v4, true>(ctx, L.CO, L.COs, nx, ny, BROX_PLANE_C_SKEW, G)));
+                OFX_TRY((op_skew<T, true>(ctx, L.Dm, L.Dms, nx, ny, BROX_PLANE_C_SKEW, G)));
+                OFX_TRY((op_skew<T, true>(ctx, L.Psis, L.Psiss, nx, ny, BROX_PLANE_C_SKEW, G)));
+                const size_t snap_stride = ps * L.snap_planes;
                 auto window = [&](const SorWin &w, int blocks, int sweeps, unsigned runmask, int err_stride) -> int {
-                    const SorGrp grp = {runmask, err_stride, npix, snap_stride};
+                    const SorGrp grp = {runmask, err_stride, ps, snap_stride};
                     hipLaunchKernelGGL(k_brox_window<T>, dim3(blocks, sweeps, G), dim3(sor_window_threads(w.R + 3)), 0,
-                                       ctx->stream, L.DU, L.Snap, L.CO, (const T *) L.Dm, (const T *) L.Psis, ctx->d_err, w,
+                                       ctx->stream, L.DUs, L.Snap, L.COs, (const T *) L.Dms, (const T *) L.Psiss, ctx->d_err, w,
                                        grp, nx, ny, P.alpha);
                     OFX_LAUNCH_CHECK(ctx);
                     return OFX_OK;
                 };
                 auto take = [&](int q, int k) -> int {
-                    OFX_HIP(ctx, hipMemcpyAsync(L.DU + q * npix, L.Snap + q * snap_stride + (size_t) (k - 1) * npix, ub,
+                    OFX_HIP(ctx, hipMemcpyAsync(L.DUs + q * ps, L.Snap + q * snap_stride + (size_t) (k - 1) * ps, ub,
                                                 hipMemcpyDeviceToDevice, ctx->stream));
                     return OFX_OK;
                 };
                 OFX_TRY(sor_window_loop(ctx, G, n, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
                                         take, nsor, error, 1, &L.sweep_hint));
+                OFX_TRY((op_skew<typename Pix<T>::v2, false>(ctx, L.DUs, L.DU, nx, ny, BROX_PLANE_C_SKEW, G)));
             } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
                 const size_t ub = (size_t) n * sizeof(typename Pix<T>::v2);
                 const unsigned gpx = ofx_cdiv(ny + 3, 64);
