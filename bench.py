@@ -438,6 +438,17 @@ def main():
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         elapsed, gather_ms, work = float(t[0].item()), float(t[1].item()), float(w.item())
 
+    # how the loops of this workload end (one lockstep group, untimed): a loop that stops on the first iteration of a
+    # fused pair continues from the stored intermediate state (option store_a) or recomputes that iteration
+    odd = None
+    if rank == 0 and nsteps > 0:
+        gsz = min(lockstep, nsteps)
+        st_ = ctx.tvl1_group_dev([dI0s[var_of(i)].data_ptr() for i in range(gsz)], [dI1s[var_of(i)].data_ptr() for i in range(gsz)],
+                                 [flo[i].data_ptr() for i in range(gsz)], nx, ny, **PAR)
+        ctx.synchronize()
+        odd = {"loops": gsz * PAR["nscales"] * PAR["warps"], "odd_stops": sum(s_.odd_stops for s_ in st_),
+               "served_from_stored_state": sum(s_.odd_stops_stored for s_ in st_)}
+
     # ---- fixed-work pass + roofline (rank 0's numbers are reported; every rank runs it to stay in step) ----
     fixed, roof, roof4k = None, None, None
     if a.fixed_steps > 0 and nsteps > 0:
@@ -522,6 +533,8 @@ def main():
         "pairs_per_s": round(npairs_job / elapsed, 3),
         "gather_ms": round(gather_ms, 3) if world > 1 else 0.0,
     }
+    if odd:
+        line["loop_ends"] = odd
     if gather_check:
         line["gather_check"] = gather_check
     if fixed:

@@ -71,6 +71,10 @@ typedef struct ofx_stats {
     long long iter_launches[OFX_MAX_SCALES];          /* iteration kernels that did real work    */
     double work_pix_iters;                            /* sum n_iter * nx_s * ny_s                */
     double total_ms;                                  /* wall time of the call on the host       */
+    int    odd_stops;                                 /* TV-L1: loops that stopped on the first iteration of a
+                                                         fused pair ...                                        */
+    int    odd_stops_stored;                          /* ... of which the launch had stored its intermediate
+                                                         state (option "store_a"): no recomputation needed     */
 } ofx_stats;
 
 /* ---- context ---------------------------------------------------------------------------------*/

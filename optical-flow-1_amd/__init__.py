@@ -38,7 +38,8 @@ class Stats(C.Structure):
                 ("error", (C.c_double * MAX_SOLVES) * MAX_SCALES),
                 ("iter_ms", C.c_double * MAX_SCALES),
                 ("iter_launches", C.c_longlong * MAX_SCALES),
-                ("work_pix_iters", C.c_double), ("total_ms", C.c_double)]
+                ("work_pix_iters", C.c_double), ("total_ms", C.c_double),
+                ("odd_stops", C.c_int), ("odd_stops_stored", C.c_int)]
 
     def iterations(self):
         return np.array([[self.iters[s][w] for w in range(min(self.nsolves, MAX_SOLVES))]

@@ -762,7 +762,7 @@ static int tvl1_pick_chunk(const ofx_ctx *ctx, int nx, int ny, int G)
 // L.cur points at the halves holding the results; n_out[g] / err_out[g] are what the reference prints.
 template <typename T>
 static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, int *n_out, double *err_out,
-                               float *ms_out)
+                               float *ms_out, int *alt_out = nullptr)     // alt_out[g]: 0 even stop, 1 odd + recomputed, 2 odd + stored
 {
     const int nx = L.nx, ny = L.ny, G = L.G;
     if ((long long) nx * ny >= (1LL << 27)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: image larger than 2^27 pixels");
@@ -850,6 +850,7 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
         // iteration of a pair whose intermediate state was stored continues from the unit's third buffer instead
         cur |= ((b0[g] + units + (took_alt[g] ? 1u : 0u)) % 3u) << (2 * g);
         L.last_n[g] = n_out[g];
+        if (alt_out) alt_out[g] = (pairs && (n_out[g] & 1) && n_out[g] != S.max_iter) ? (took_alt[g] ? 2 : 1) : 0;
     }
     L.cur = cur;
     return OFX_OK;
@@ -888,10 +889,13 @@ static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params
         int it[OFX_MAX_GROUP];
         double error[OFX_MAX_GROUP];
         float ms = 0.f;
-        OFX_TRY(tvl1_run_iterations<T>(ctx, L, P, it, error, ctx->profile ? &ms : nullptr));
+        int odd[OFX_MAX_GROUP];
+        OFX_TRY(tvl1_run_iterations<T>(ctx, L, P, it, error, ctx->profile ? &ms : nullptr, odd));
         if (P.verbose && G == 1) fprintf(stderr, "Warping: %d, Iterations: %d, Error: %f\n", w, it[0], error[0]);   // :184-188
         for (int g = 0; g < G; g++) {
             ofx_stats &S = stats[g];
+            S.odd_stops += odd[g] != 0;
+            S.odd_stops_stored += odd[g] == 2;
             if (scale < OFX_MAX_SCALES) {
                 if (w < OFX_MAX_SOLVES) { S.iters[scale][w] = it[g]; S.error[scale][w] = error[g]; }
                 S.iter_ms[scale] += ms;
