@@ -489,13 +489,25 @@ static int sor_exact_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int q
     return OFX_OK;
 }
 
-// snapshot capacity (= most sweeps in one batch) of the windowed mode: option "sor_batch", else 64, capped by maxiter
-// and by ~4 GiB of snapshots per pair (40 GiB per lockstep group)
+// snapshot capacity (= most sweeps in one batch) of the windowed mode: option "sor_batch", else 64, capped by maxiter,
+// by ~4 GiB of snapshots per pair and -- for all pairs of a lockstep group -- by a third of the device memory that is
+// free right now, shared between the contexts expected to solve concurrently (option "concurrency"; the batch entry
+// points set it to their number of contexts)
 static int sor_pick_batch(const ofx_ctx *ctx, size_t npix, size_t elem_bytes, int maxiter, int G = 1)
 {
     int b = ctx->sor_batch > 0 ? ctx->sor_batch : 64;
-    const size_t cap = (size_t) 4 << 30, cap_group = (size_t) 40 << 30;      // per pair / for all pairs of a group
-    while (b > 1 && ((size_t) b * npix * elem_bytes > cap || (size_t) b * npix * elem_bytes * G > cap_group)) b /= 2;
+    const double cap = (double) ((size_t) 4 << 30);
+    double cap_group = (double) ((size_t) 40 << 30);
+    size_t mfree = 0, mtotal = 0;
+    if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
+        const double share = 0.33 * (double) mfree / (ctx->concurrency > 1 ? ctx->concurrency : 1);
+        if (share < cap_group) cap_group = share;
+    } else {
+        (void) hipGetLastError();
+    }
+    const double plane = (double) npix * (double) elem_bytes;
+    while (b > 8 && (b * plane > cap || b * plane * G > cap_group)) b /= 2;
+    while (b > 1 && b * plane > cap) b /= 2;
     if (b > maxiter) b = maxiter;
     return b < 1 ? 1 : b;
 }
@@ -1492,6 +1504,12 @@ static int sor_batch_run(ofx_ctx *const *ctxs, int n_ctx, int n_pairs, int G, do
 {
     const int n_groups = (n_pairs + G - 1) / G;
     std::atomic<int> status(OFX_OK);
+    const int n_workers = n_ctx < n_groups ? n_ctx : n_groups;
+    std::vector<int> conc(n_ctx);
+    for (int w = 0; w < n_ctx; w++) {                           // memory budgets are shared between the workers
+        conc[w] = ctxs[w]->concurrency;
+        if (ctxs[w]->concurrency < n_workers) ctxs[w]->concurrency = n_workers;
+    }
     auto worker = [&](int w) {
         std::vector<ofx_stats> st(G);
         for (int q = w; q < n_groups; q += n_ctx) {
@@ -1508,6 +1526,7 @@ static int sor_batch_run(ofx_ctx *const *ctxs, int n_ctx, int n_pairs, int G, do
     for (int w = 1; w < n_ctx && w < n_groups; w++) th.emplace_back(worker, w);
     worker(0);
     for (auto &t : th) t.join();
+    for (int w = 0; w < n_ctx; w++) ctxs[w]->concurrency = conc[w];
     return status.load();
 }
 

@@ -170,11 +170,66 @@ class _Lib:
         self._fn("image_normalization_2", None, _dp, _dp, _dp, _dp, C.c_int)(_f64(I1), _f64(I2), a, b, I1.size)
         return a, b
 
+    # ---- SURVEY 8(f)4 colour operators / 8(f)1 building blocks of TV-L1 with occlusions ----------------------------
+    def bicubic_warp_color(self, I, u, v, border_out=False):
+        """I: (ny, nx, nz) interleaved channels; u, v: (ny, nx)"""
+        ny, nx, nz = I.shape
+        out = np.empty((ny, nx, nz))
+        self._fn("bicubic_warp_color", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int)(
+            _f64(I), _f64(u), _f64(v), out, nx, ny, nz, int(border_out))
+        return out
+
+    def image_normalization_2_color(self, I1, I2, size=None):
+        """I1, I2: (..., nz) interleaved; `size` = element count handed to the reference (default: all)"""
+        nz = I1.shape[-1]
+        a, b = _f64(I1).copy(), _f64(I2).copy()
+        self._fn("image_normalization_2_color", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int)(
+            _f64(I1), _f64(I2), a, b, I1.size if size is None else size, nz)
+        return a, b
+
+    def image_normalization_3(self, I0, I1, I2):
+        a, b, c = _f64(I0).copy(), _f64(I1).copy(), _f64(I2).copy()
+        self._fn("image_normalization_3", None, _dp, _dp, _dp, C.c_int)(a, b, c, a.size)
+        return a, b, c
+
+    def image_normalization_4(self, I_1, I0, I1, F):
+        outs = [np.empty(I0.shape) for _ in range(4)]
+        self._fn("image_normalization_4", None, *([_dp] * 8), C.c_int)(_f64(I_1), _f64(I0), _f64(I1), _f64(F), *outs, I0.size)
+        return outs
+
+    def median_filtering(self, I, wsize=3):
+        ny, nx = I.shape
+        out = _f64(I).copy()
+        self._fn("median_filtering", None, _dp, C.c_int, C.c_int, C.c_int)(out, nx, ny, wsize)
+        return out
+
+    def occ_solver_v(self, u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, grad1, grad3, alpha, theta, lam):
+        """Solver_wrt_v -> (v1, v2, Vfwd_1, Vfwd_2, Vbck_1, Vbck_2)"""
+        ny, nx = u1.shape
+        outs = [np.empty((ny, nx)) for _ in range(6)]
+        v1, v2, f1, f2, b1, b2 = outs
+        self._fn("occ_solver_v", None, *([_dp] * 17), C.c_double, C.c_double, C.c_double, C.c_int, C.c_int)(
+            _f64(u1), _f64(u2), v1, v2, _f64(chi), _f64(I1wx), _f64(I1wy), _f64(I_1wx), _f64(I_1wy), _f64(rho1_c),
+            _f64(rho3_c), f1, f2, b1, b2, _f64(grad1), _f64(grad3), alpha, theta, lam, nx, ny)
+        return outs
+
 
 class Oracle(_Lib):
     """Our C restatement (oracle/ofx_oracle.c)."""
     prefix = "orc_"
     kind = "port"
+
+    def occ_solver_chi(self, u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, Vf1, Vf2, Vb1, Vb2, g, lam, theta, alpha,
+                       beta, tau_chi, tau_eta, eta1=None, eta2=None, n_iter=100):
+        """Solver_wrt_chi with the dual variable as explicit state -> (chi, eta1, eta2); eta defaults to zero"""
+        ny, nx = u1.shape
+        chi = _f64(chi).copy()
+        eta1 = np.zeros((ny, nx)) if eta1 is None else _f64(eta1).copy()
+        eta2 = np.zeros((ny, nx)) if eta2 is None else _f64(eta2).copy()
+        self._fn("occ_solver_chi", None, *([_dp] * 14), *([C.c_double] * 6), C.c_int, C.c_int, _dp, _dp, C.c_int)(
+            _f64(u1), _f64(u2), chi, _f64(I1wx), _f64(I1wy), _f64(I_1wx), _f64(I_1wy), _f64(rho1_c), _f64(rho3_c), _f64(Vf1),
+            _f64(Vf2), _f64(Vb1), _f64(Vb2), _f64(g), lam, theta, alpha, beta, tau_chi, tau_eta, nx, ny, eta1, eta2, n_iter)
+        return chi, eta1, eta2
 
     def __init__(self):
         super().__init__(ORACLE_SO)
@@ -278,6 +333,17 @@ class Ref(_Lib):
     """The compiled reference itself (oracle/_ref/libofref.so via oracle/ref_shim.cpp)."""
     prefix = "ref_"
     kind = "reference"
+
+    def occ_solver_chi(self, u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, Vf1, Vf2, Vb1, Vb2, g, lam, theta, alpha,
+                       beta, tau_chi, tau_eta, fresh=True):
+        """One call of the reference's Solver_wrt_chi (100 iterations).  fresh: start from a zero dual variable
+        (oracle/ref_shim.cpp); otherwise continue with the one the previous call left in the function's statics."""
+        ny, nx = u1.shape
+        chi = _f64(chi).copy()
+        self._fn("occ_solver_chi", None, *([_dp] * 14), *([C.c_double] * 6), C.c_int, C.c_int, C.c_int)(
+            _f64(u1), _f64(u2), chi, _f64(I1wx), _f64(I1wy), _f64(I_1wx), _f64(I_1wy), _f64(rho1_c), _f64(rho3_c), _f64(Vf1),
+            _f64(Vf2), _f64(Vb1), _f64(Vb2), _f64(g), lam, theta, alpha, beta, tau_chi, tau_eta, nx, ny, int(fresh))
+        return chi
 
     def __init__(self):
         super().__init__(REF_SO)

@@ -1490,3 +1490,253 @@ void orc_hs_classic(double *u, double *v, const double *a, const double *b, int 
     }
     free(Ex); free(Ey); free(Et); free(ubar); free(vbar);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* colour operators.  src/bicubic_interpolation.cpp:381-405 -- channel by channel, every sample through
+ * bicubic_interpolation_at_color; (double)(j + u[p]) is j + u[p] evaluated in double. */
+void orc_bicubic_warp_color(const double *in, const double *u, const double *v, double *out, int nx, int ny, int nz,
+                            int border_out)
+{
+    for (int k = 0; k < nz; k++)
+        for (int i = 0; i < ny; i++)
+            for (int j = 0; j < nx; j++) {
+                const int p = i * nx + j;
+                out[(size_t) p * nz + k] = orc_bicubic_at_color(in, j + u[p], i + v[p], nx, ny, nz, k, border_out);
+            }
+}
+
+/* src/utils.cpp:333-404.  `size` is the element count of the interleaved arrays; channel c starts from element c and the
+ * scan visits i = nz, 2 nz, ... < size (so the last pixel is read at i + c, as in the reference). */
+void orc_image_normalization_2_color(const double *I1, const double *I2, double *I1n, double *I2n, int size, int nz)
+{
+    for (int c = 0; c < nz; c++) {
+        double max = I1[c] > I2[c] ? I1[c] : I2[c];
+        double min = I1[c] < I2[c] ? I1[c] : I2[c];
+        for (int i = nz; i < size; i += nz) {
+            const int r = i + c;
+            if (I1[r] > max) max = I1[r];
+            if (I1[r] < min) min = I1[r];
+            if (I2[r] > max) max = I2[r];
+            if (I2[r] < min) min = I2[r];
+        }
+        const double den = max - min;
+        for (int i = 0; i < size; i += nz) {
+            const int r = i + c;
+            if (den > 0) {
+                I1n[r] = 255.0 * (I1[r] - min) / den;
+                I2n[r] = 255.0 * (I2[r] - min) / den;
+            } else {
+                I1n[r] = I1[r];
+                I2n[r] = I2[r];
+            }
+        }
+    }
+}
+
+/* src/utils.cpp:412-450: joint min/max of three images, in place, NO den > 0 test (a constant triple divides by zero) */
+void orc_image_normalization_3(double *I0, double *I1, double *I2, int size)
+{
+    double min0, max0, min1, max1, min2, max2;
+    orc_getminmax(&min0, &max0, I0, size);
+    orc_getminmax(&min1, &max1, I1, size);
+    orc_getminmax(&min2, &max2, I2, size);
+    double max = max0, min = min0;
+    if (max1 > max) max = max1;
+    if (min1 < min) min = min1;
+    if (max2 > max) max = max2;
+    if (min2 < min) min = min2;
+    const double den = max - min;
+    for (int i = 0; i < size; i++) {
+        I0[i] = 255.0 * (I0[i] - min) / den;
+        I1[i] = 255.0 * (I1[i] - min) / den;
+        I2[i] = 255.0 * (I2[i] - min) / den;
+    }
+}
+
+/* src/utils.cpp:452-501 */
+void orc_image_normalization_4(const double *I_1, const double *I0, const double *I1, const double *filtI0, double *I_1n,
+                               double *I0n, double *I1n, double *filtI0n, int size)
+{
+    double min_1, max_1, min0, max0, min1, max1, minf, maxf;
+    orc_getminmax(&min_1, &max_1, I_1, size);
+    orc_getminmax(&min0, &max0, I0, size);
+    orc_getminmax(&min1, &max1, I1, size);
+    orc_getminmax(&minf, &maxf, filtI0, size);
+    double max = (max_1 > max0) ? max_1 : max0;
+    max = (max > max1) ? max : max1;
+    max = (max > maxf) ? max : maxf;
+    double min = (min_1 < min0) ? min_1 : min0;
+    min = (min < min1) ? min : min1;
+    min = (min < minf) ? min : minf;
+    const double den = max - min;
+    for (int i = 0; i < size; i++) {
+        if (den > 0) {
+            I_1n[i] = 255.0 * (I_1[i] - min) / den;
+            I0n[i] = 255.0 * (I0[i] - min) / den;
+            I1n[i] = 255.0 * (I1[i] - min) / den;
+            filtI0n[i] = 255.0 * (filtI0[i] - min) / den;
+        } else {
+            I_1n[i] = I_1[i];
+            I0n[i] = I0[i];
+            I1n[i] = I1[i];
+            filtI0n[i] = filtI0[i];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the deterministic building blocks of TV-L1 with occlusions.
+ * src/utils.cpp:150-213 me_median_filtering: wsize x wsize window, indices mirrored WITH repetition of the border
+ * sample (-1 -> 0, n -> n - 1), element [count / 2] of the sorted window (the sort order among equal values cannot
+ * matter), in place through a copy. */
+static int median_cmp(const void *a, const void *b)
+{
+    const double x = *(const double *) a, y = *(const double *) b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+void orc_median_filtering(double *in, int nx, int ny, int wsize)
+{
+    const int border = wsize >> 1;
+    double *win = dalloc((size_t) wsize * wsize), *out = dalloc((size_t) nx * ny);
+    for (int x = 0; x < nx; x++)
+        for (int y = 0; y < ny; y++) {
+            int n = 0;
+            for (int yy = y - border; yy <= y + border; yy++)
+                for (int xx = x - border; xx <= x + border; xx++) {
+                    int x0 = xx, y0 = yy;
+                    if (x0 < 0) x0 = -x0 - 1;
+                    if (x0 >= nx) x0 = 2 * nx - x0 - 1;
+                    if (y0 < 0) y0 = -y0 - 1;
+                    if (y0 >= ny) y0 = 2 * ny - y0 - 1;
+                    win[n++] = in[y0 * nx + x0];
+                }
+            qsort(win, (size_t) n, sizeof(double), median_cmp);
+            out[y * nx + x] = win[n / 2];
+        }
+    memcpy(in, out, sizeof(double) * (size_t) nx * ny);
+    free(win);
+    free(out);
+}
+
+#define OCC_IS_ZERO 1E-10      /* src/tvl1occflow_constants.h:31 */
+#define OCC_THR_CHI 0.75       /* src/tvl1occflow_constants.h:32 */
+
+/* src/tvl1occflow_solvers.cpp:56-147 Solver_wrt_v: pointwise thresholding of the forward and the backward data term */
+void orc_occ_solver_v(const double *u1, const double *u2, double *v1, double *v2, const double *chi, const double *I1wx,
+                      const double *I1wy, const double *I_1wx, const double *I_1wy, const double *rho1_c,
+                      const double *rho3_c, double *Vfwd_1, double *Vfwd_2, double *Vbck_1, double *Vbck_2,
+                      const double *grad1, const double *grad3, double alpha, double theta, double lambda, int nx, int ny)
+{
+    const int size = nx * ny;
+    const double l_t = lambda * theta;
+    const double _1pat = 1. + alpha * theta;
+    const double at_d_1pat = alpha * theta / _1pat;
+    const double lt_d_1pat = 2. * lambda * theta / _1pat;
+    for (int i = 0; i < size; i++) {
+        double d1 = 0, d2 = 0;
+        const double rho1 = rho1_c[i] + (I1wx[i] * u1[i] + I1wy[i] * u2[i]);
+        if (rho1 < -l_t * grad1[i]) {
+            d1 = l_t * I1wx[i];
+            d2 = l_t * I1wy[i];
+        } else if (rho1 > l_t * grad1[i]) {
+            d1 = -l_t * I1wx[i];
+            d2 = -l_t * I1wy[i];
+        } else if (grad1[i] < OCC_IS_ZERO) {
+            d1 = d2 = 0;
+        } else {
+            d1 = -rho1 * I1wx[i] / grad1[i];
+            d2 = -rho1 * I1wy[i] / grad1[i];
+        }
+        Vfwd_1[i] = u1[i] + d1;
+        Vfwd_2[i] = u2[i] + d2;
+
+        const double rho3 = rho3_c[i] - (I_1wx[i] * u1[i] + I_1wy[i] * u2[i]);
+        const double A = rho3 + at_d_1pat * (I_1wx[i] * u1[i] + I_1wy[i] * u2[i]);
+        if (A < -lt_d_1pat * grad3[i]) {
+            d1 = -lt_d_1pat * I_1wx[i];
+            d2 = -lt_d_1pat * I_1wy[i];
+            Vbck_1[i] = (u1[i] / _1pat) + d1;
+            Vbck_2[i] = (u2[i] / _1pat) + d2;
+        } else if (A > lt_d_1pat * grad3[i]) {
+            d1 = lt_d_1pat * I_1wx[i];
+            d2 = lt_d_1pat * I_1wy[i];
+            Vbck_1[i] = (u1[i] / _1pat) + d1;
+            Vbck_2[i] = (u2[i] / _1pat) + d2;
+        } else {
+            if (grad3[i] < OCC_IS_ZERO) {
+                d1 = d2 = 0;
+            } else {
+                d1 = rho3 * I_1wx[i] / grad3[i];
+                d2 = rho3 * I_1wy[i] / grad3[i];
+            }
+            Vbck_1[i] = u1[i] + d1;
+            Vbck_2[i] = u2[i] + d2;
+        }
+        if (chi[i] < OCC_THR_CHI) {
+            v1[i] = Vfwd_1[i];
+            v2[i] = Vfwd_2[i];
+        } else {
+            v1[i] = Vbck_1[i];
+            v2[i] = Vbck_2[i];
+        }
+    }
+}
+
+/* src/tvl1occflow_solvers.cpp:218-337 Solver_wrt_chi with the dual variable (eta1, eta2) as EXPLICIT state.  The
+ * reference keeps eta in function-local statics that it never initialises (its own "#warning eta1 and eta2 are used
+ * uninitialized"); n_iter is its MAX_ITERATIONS_CHI (100).  Per iteration: eta += tau_eta g grad(chi), projection onto
+ * the unit ball (:33-53), chi += tau_chi (div(g eta) - F - G - beta div u), clamped to [0, 1]. */
+void orc_occ_solver_chi(const double *u1, const double *u2, double *chi, const double *I1wx, const double *I1wy,
+                        const double *I_1wx, const double *I_1wy, const double *rho1_c, const double *rho3_c,
+                        const double *Vfwd_1, const double *Vfwd_2, const double *Vbck_1, const double *Vbck_2,
+                        const double *g, double lambda, double theta, double alpha, double beta, double tau_chi,
+                        double tau_eta, int nx, int ny, double *eta1, double *eta2, int n_iter)
+{
+    const int size = nx * ny;
+    double *chix = dalloc((size_t) size), *chiy = dalloc((size_t) size), *geta1 = dalloc((size_t) size);
+    double *geta2 = dalloc((size_t) size), *div_eta = dalloc((size_t) size), *div_u = dalloc((size_t) size);
+    for (int n_chi = 0; n_chi < n_iter; n_chi++) {
+        orc_forward_gradient(chi, chix, chiy, nx, ny);
+        for (int i = 0; i < size; i++) {
+            eta1[i] = eta1[i] + tau_eta * g[i] * chix[i];
+            eta2[i] = eta2[i] + tau_eta * g[i] * chiy[i];
+        }
+        for (int j = 0; j < size; j++) {                                           /* project, :33-53 */
+            const double norm2 = eta1[j] * eta1[j] + eta2[j] * eta2[j];
+            if (norm2 < OCC_IS_ZERO) {
+                eta1[j] = 0.0;
+                eta2[j] = 0.0;
+            } else {
+                const double norm = sqrt(norm2);
+                eta1[j] = eta1[j] / norm;
+                eta2[j] = eta2[j] / norm;
+            }
+        }
+        for (int i = 0; i < size; i++) {
+            geta1[i] = g[i] * eta1[i];
+            geta2[i] = g[i] * eta2[i];
+        }
+        orc_divergence(geta1, geta2, div_eta, nx, ny);
+        orc_divergence(u1, u2, div_u, nx, ny);
+        for (int i = 0; i < size; i++) {
+            const double rho1 = rho1_c[i] + (I1wx[i] * Vfwd_1[i] + I1wy[i] * Vfwd_2[i]);
+            const double abs_rho1 = (rho1 < 0.) ? -rho1 : rho1;
+            const double rho3 = rho3_c[i] - (I_1wx[i] * Vbck_1[i] + I_1wy[i] * Vbck_2[i]);
+            const double abs_rho3 = (rho3 < 0.) ? -rho3 : rho3;
+            double F, G;
+            if (chi[i] < 0.5) {
+                F = -lambda * abs_rho1;
+                G = -(0.5 / theta) * ((Vfwd_1[i] - u1[i]) * (Vfwd_1[i] - u1[i]) + (Vfwd_2[i] - u2[i]) * (Vfwd_2[i] - u2[i]));
+            } else {
+                F = lambda * abs_rho3;
+                G = (0.5 / theta) * ((Vbck_1[i] - u1[i]) * (Vbck_1[i] - u1[i]) + (Vbck_2[i] - u2[i]) * (Vbck_2[i] - u2[i]))
+                    + alpha * theta * (Vbck_1[i] * Vbck_1[i] + Vbck_2[i] * Vbck_2[i]);
+            }
+            chi[i] = chi[i] + tau_chi * (div_eta[i] - F - G - beta * div_u[i]);
+            if (chi[i] > 1.) chi[i] = 1.;
+            else if (chi[i] < 0.) chi[i] = 0.;
+        }
+    }
+    free(chix); free(chiy); free(geta1); free(geta2); free(div_eta); free(div_u);
+}

@@ -92,6 +92,28 @@ void orc_hs_classic(double *u, double *v, const double *a, const double *b, int 
 double orc_bicubic_at_color(const double *in, double uu, double vv, int nx, int ny, int nz, int k, int border_out);
 void orc_getminmax(double *mn, double *mx, const double *x, int n);
 
+
+/* SURVEY 8(f)4 colour operators: bicubic_interpolation.cpp:381-405, utils.cpp:333-501 */
+void orc_bicubic_warp_color(const double *in, const double *u, const double *v, double *out, int nx, int ny, int nz,
+                            int border_out);
+void orc_image_normalization_2_color(const double *I1, const double *I2, double *I1n, double *I2n, int size, int nz);
+void orc_image_normalization_3(double *I0, double *I1, double *I2, int size);
+void orc_image_normalization_4(const double *I_1, const double *I0, const double *I1, const double *filtI0, double *I_1n,
+                               double *I0n, double *I1n, double *filtI0n, int size);
+
+/* SURVEY 8(f)1 building blocks of TV-L1 with occlusions: utils.cpp:150-213, tvl1occflow_solvers.cpp:56-147,218-337.
+ * The chi solver takes its dual variable as explicit state (the reference keeps it in uninitialised statics). */
+void orc_median_filtering(double *in, int nx, int ny, int wsize);
+void orc_occ_solver_v(const double *u1, const double *u2, double *v1, double *v2, const double *chi, const double *I1wx,
+                      const double *I1wy, const double *I_1wx, const double *I_1wy, const double *rho1_c,
+                      const double *rho3_c, double *Vfwd_1, double *Vfwd_2, double *Vbck_1, double *Vbck_2,
+                      const double *grad1, const double *grad3, double alpha, double theta, double lambda, int nx, int ny);
+void orc_occ_solver_chi(const double *u1, const double *u2, double *chi, const double *I1wx, const double *I1wy,
+                        const double *I_1wx, const double *I_1wy, const double *rho1_c, const double *rho3_c,
+                        const double *Vfwd_1, const double *Vfwd_2, const double *Vbck_1, const double *Vbck_2,
+                        const double *g, double lambda, double theta, double alpha, double beta, double tau_chi,
+                        double tau_eta, int nx, int ny, double *eta1, double *eta2, int n_iter);
+
 #ifdef __cplusplus
 }
 #endif

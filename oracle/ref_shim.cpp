@@ -21,10 +21,29 @@
 #include "horn_schunck.h"
 #include "brox_optic_flow.h"
 #include "brox_spatial_mask.h"
+#include "tvl1occflow_solvers.h"
+
+#include <cstdlib>
+#include <new>
 
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+
+// Array allocations of THIS library return zeroed memory (the library is linked -Bsymbolic, nothing outside it is
+// affected).  Needed for exactly one function: Solver_wrt_chi (tvl1occflow_solvers.cpp:239-263) reads its dual variable
+// eta straight after `new[]` -- the source says so itself ("#warning eta1 and eta2 are used uninitialized") -- so its
+// result depends on the heap's history.  With zero-filled arrays the function is deterministic and can pin the
+// restatement, which takes eta as explicit, zero-initialised state.  Every other function writes its arrays before
+// reading them.
+void *operator new[](std::size_t n)
+{
+    void *p = std::calloc(1, n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void operator delete[](void *p) noexcept { std::free(p); }
+void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
 
 extern "C" {
 
@@ -157,5 +176,53 @@ void ref_getminmax(double *mn, double *mx, const double *x, int n) { getminmax(m
 
 void ref_hs_classic(double *u, double *v, const double *a, const double *b, int w, int h, int n, double alpha)
 { hs(u, v, const_cast<double *>(a), const_cast<double *>(b), w, h, n, alpha); }
+
+
+// ---- SURVEY 8(f)4 colour operators -------------------------------------------------------------------------------
+void ref_bicubic_warp_color(const double *in, const double *u, const double *v, double *out, int nx, int ny, int nz,
+                            int border_out)
+{ bicubic_interpolation_warp_color(in, u, v, out, nx, ny, nz, border_out != 0); }
+
+void ref_image_normalization_2_color(const double *I1, const double *I2, double *I1n, double *I2n, int size, int nz)
+{ image_normalization_2_color(I1, I2, I1n, I2n, size, nz); }
+
+void ref_image_normalization_3(double *I0, double *I1, double *I2, int size) { image_normalization_3(I0, I1, I2, size); }
+
+void ref_image_normalization_4(const double *I_1, const double *I0, const double *I1, const double *filtI0, double *I_1n,
+                               double *I0n, double *I1n, double *filtI0n, int size)
+{ image_normalization_4(I_1, I0, I1, filtI0, I_1n, I0n, I1n, filtI0n, size); }
+
+// ---- SURVEY 8(f)1 building blocks of TV-L1 with occlusions ------------------------------------------------------------
+void ref_median_filtering(double *in, int nx, int ny, int wsize) { me_median_filtering(in, nx, ny, wsize); }
+
+void ref_occ_solver_v(const double *u1, const double *u2, double *v1, double *v2, const double *chi, const double *I1wx,
+                      const double *I1wy, const double *I_1wx, const double *I_1wy, const double *rho1_c,
+                      const double *rho3_c, double *Vfwd_1, double *Vfwd_2, double *Vbck_1, double *Vbck_2,
+                      const double *grad1, const double *grad3, double alpha, double theta, double lambda, int nx, int ny)
+{
+    Solver_wrt_v(const_cast<double *>(u1), const_cast<double *>(u2), v1, v2, const_cast<double *>(chi), I1wx, I1wy, I_1wx,
+                 I_1wy, rho1_c, rho3_c, Vfwd_1, Vfwd_2, Vbck_1, Vbck_2, grad1, grad3, alpha, theta, lambda, nx, ny);
+}
+
+// One call of the reference's Solver_wrt_chi (MAX_ITERATIONS_CHI = 100 iterations).  Its dual variable lives in
+// function-local statics that are re-allocated -- zero-filled, see operator new[] above -- whenever nx differs from the
+// previous call's: `fresh` != 0 first makes a dummy call with another width, so that the real call starts from eta = 0;
+// fresh == 0 continues with the eta the previous call left (same nx).
+void ref_occ_solver_chi(const double *u1, const double *u2, double *chi, const double *I1wx, const double *I1wy,
+                        const double *I_1wx, const double *I_1wy, const double *rho1_c, const double *rho3_c,
+                        const double *Vfwd_1, const double *Vfwd_2, const double *Vbck_1, const double *Vbck_2,
+                        const double *g, double lambda, double theta, double alpha, double beta, double tau_chi,
+                        double tau_eta, int nx, int ny, int fresh)
+{
+    if (fresh) {
+        const int dn = (nx == 3) ? 4 : 3;
+        double z[16 * 14] = {0};
+        double *a = z;
+        Solver_wrt_chi(a, a + 16, a + 32, a + 48, a + 64, a + 80, a + 96, a + 112, a + 128, a + 144, a + 160, a + 176,
+                       a + 192, a + 208, lambda, theta, alpha, beta, tau_chi, tau_eta, dn, dn);
+    }
+    Solver_wrt_chi(u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, Vfwd_1, Vfwd_2, Vbck_1, Vbck_2, g, lambda, theta,
+                   alpha, beta, tau_chi, tau_eta, nx, ny);
+}
 
 } // extern "C"

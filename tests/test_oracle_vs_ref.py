@@ -106,3 +106,71 @@ def test_colour_and_minmax_operators(orc, ref):
             for bo in (False, True):
                 assert orc.bicubic_at_color(img, uu, vv, k, bo) == ref.bicubic_at_color(img, uu, vv, k, bo)
     assert orc.getminmax(img) == ref.getminmax(img) == (img.min(), img.max())
+
+
+# ---- SURVEY 8(f)4 colour operators and 8(f)1 building blocks of TV-L1 with occlusions -----------------------------------
+def _occ_inputs(rng, nx, ny):
+    f = lambda s=1.0: rng.standard_normal((ny, nx)) * s
+    u1, u2 = f(0.8), f(0.8)
+    chi = np.clip(rng.random((ny, nx)) * 1.4 - 0.2, 0, 1)
+    I1wx, I1wy, I_1wx, I_1wy = f(6), f(6), f(6), f(6)
+    I1wx[::5, ::3] = 0.0
+    I1wy[::5, ::3] = 0.0                               # grad < IS_ZERO branch
+    rho1_c, rho3_c = f(3), f(3)
+    grad1, grad3 = I1wx ** 2 + I1wy ** 2, I_1wx ** 2 + I_1wy ** 2
+    g = 1.0 / (1.0 + 0.05 * rng.random((ny, nx)) * 40)
+    return u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, grad1, grad3, g
+
+
+def test_colour_operators(orc, ref):
+    rng = np.random.default_rng(5)
+    for ny, nx, nz in ((9, 13, 3), (17, 8, 2), (6, 6, 1)):
+        I = rng.random((ny, nx, nz)) * 255
+        u, v = rng.standard_normal((ny, nx)) * 3, rng.standard_normal((ny, nx)) * 3
+        for bo in (False, True):
+            assert np.array_equal(orc.bicubic_warp_color(I, u, v, bo), ref.bicubic_warp_color(I, u, v, bo))
+        J = rng.random((ny, nx, nz)) * 100 - 20
+        for a, b in zip(orc.image_normalization_2_color(I, J), ref.image_normalization_2_color(I, J)):
+            assert np.array_equal(a, b)
+        K = np.full((ny, nx, nz), 7.0)                   # den = 0: copy path
+        for a, b in zip(orc.image_normalization_2_color(K, K), ref.image_normalization_2_color(K, K)):
+            assert np.array_equal(a, b) and np.array_equal(a, K)
+    A, B, Cc, D = (rng.random((11, 7)) * s - o for s, o in ((255, 0), (90, 30), (300, 100), (10, 5)))
+    for a, b in zip(orc.image_normalization_3(A, B, Cc), ref.image_normalization_3(A, B, Cc)):
+        assert np.array_equal(a, b)
+    for a, b in zip(orc.image_normalization_4(A, B, Cc, D), ref.image_normalization_4(A, B, Cc, D)):
+        assert np.array_equal(a, b)
+    Z = np.full((4, 5), 3.0)
+    for a, b in zip(orc.image_normalization_4(Z, Z, Z, Z), ref.image_normalization_4(Z, Z, Z, Z)):
+        assert np.array_equal(a, b) and np.array_equal(a, Z)
+
+
+def test_median_filtering(orc, ref):
+    rng = np.random.default_rng(6)
+    for ny, nx in ((7, 9), (3, 3), (1, 6), (12, 2), (20, 31)):
+        I = np.round(rng.standard_normal((ny, nx)) * 4, 1)           # ties on purpose
+        for w in (3, 5):
+            assert np.array_equal(orc.median_filtering(I, w), ref.median_filtering(I, w)), (ny, nx, w)
+
+
+def test_occlusion_solvers(orc, ref):
+    rng = np.random.default_rng(7)
+    for nx, ny in ((19, 13), (8, 22), (33, 9)):
+        u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, grad1, grad3, g = _occ_inputs(rng, nx, ny)
+        args_v = (u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, grad1, grad3, 0.01, 0.3, 0.15)
+        vo, vr = orc.occ_solver_v(*args_v), ref.occ_solver_v(*args_v)
+        for a, b in zip(vo, vr):
+            assert np.array_equal(a, b)
+        v1, v2, f1, f2, b1, b2 = vo
+        par = (0.15, 0.3, 0.01, 0.15, 0.15, 0.15)             # lambda, theta, alpha, beta, tau_chi, tau_eta
+        args_c = (u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, f1, f2, b1, b2, g) + par
+        # the reference from a zero dual variable = the restatement with eta = 0, 100 iterations ...
+        c_ref = ref.occ_solver_chi(*args_c, fresh=True)
+        c_orc, e1, e2 = orc.occ_solver_chi(*args_c)
+        assert np.array_equal(c_ref, c_orc)
+        assert 0.0 < c_orc.mean() < 1.0
+        # ... and a second call continues with the dual variable the first one left
+        args_c2 = (u1, u2, c_orc) + args_c[3:]
+        c_ref2 = ref.occ_solver_chi(*args_c2, fresh=False)
+        c_orc2, _, _ = orc.occ_solver_chi(*args_c2, eta1=e1, eta2=e2)
+        assert np.array_equal(c_ref2, c_orc2)
