@@ -255,6 +255,40 @@ int ofx_brox_temporal(ofx_ctx *ctx, const double *I, double *u, double *v, int n
                       double alpha, double gamma, int nscales, double nu, double TOL, int inner_iter,
                       int outer_iter, int verbose);
 
+/* ---- colour operators (replace src/bicubic_interpolation.h:66-75, src/utils.h:39-96) -----------------*/
+/* bicubic_interpolation_warp_color: nz interleaved channels, every sample through bicubic_interpolation_at_color */
+int ofx_bicubic_warp_color(ofx_ctx *ctx, const double *input, const double *u, const double *v, double *output,
+                           int nx, int ny, int nz, int border_out);
+/* image_normalization_2_color: per channel joint min / max of both images; `size` = number of ELEMENTS (pixels * nz,
+ * a multiple of nz: the reference reads past its arrays otherwise), copy when max == min */
+int ofx_image_normalization_2_color(ofx_ctx *ctx, const double *I1, const double *I2, double *I1n, double *I2n,
+                                    int size, int nz);
+/* image_normalization_3: joint min / max of three images, IN PLACE, no test for max == min (as the reference) */
+int ofx_image_normalization_3(ofx_ctx *ctx, double *I0, double *I1, double *I2, int size);
+int ofx_image_normalization_4(ofx_ctx *ctx, const double *I_1, const double *I0, const double *I1, const double *filtI0,
+                              double *I_1n, double *I0n, double *I1n, double *filtI0n, int size);
+
+/* ---- building blocks of TV-L1 with occlusions ---------------------------------------------------------------
+ * The reference PROGRAM (tvl1occflow) is not reproducible by any implementation: Solver_wrt_chi reads its dual variable
+ * uninitialised and Solver_wrt_u keeps its dual variables in function-local statics across calls
+ * (src/tvl1occflow_solvers.cpp:161-186,239-263).  Its functions are deterministic once that state is explicit: */
+/* me_median_filtering (src/utils.h:10, src/utils.cpp:150-213): wsize x wsize median, in place; wsize <= 9 */
+int ofx_me_median_filtering(ofx_ctx *ctx, double *in, int nx, int ny, int wsize);
+/* Solver_wrt_v (src/tvl1occflow_solvers.h, src/tvl1occflow_solvers.cpp:56-147); same argument order */
+int ofx_solver_wrt_v(ofx_ctx *ctx, const double *u1, const double *u2, double *v1, double *v2, const double *chi,
+                     const double *I1wx, const double *I1wy, const double *I_1wx, const double *I_1wy,
+                     const double *rho1_c, const double *rho3_c, double *Vfwd_1, double *Vfwd_2, double *Vbck_1,
+                     double *Vbck_2, const double *grad1, const double *grad3, double alpha, double theta, double lambda,
+                     int nx, int ny);
+/* Solver_wrt_chi (src/tvl1occflow_solvers.cpp:218-337); the reference's argument order, followed by the dual variable
+ * (eta1, eta2) as explicit in/out state -- zero it for what the reference computes on a zero-filled heap -- and the
+ * iteration count (the reference's MAX_ITERATIONS_CHI = 100) */
+int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *u2, double *chi, const double *I1wx,
+                       const double *I1wy, const double *I_1wx, const double *I_1wy, const double *rho1_c,
+                       const double *rho3_c, const double *Vfwd_1, const double *Vfwd_2, const double *Vbck_1,
+                       const double *Vbck_2, const double *g, double lambda, double theta, double alpha, double beta,
+                       double tau_chi, double tau_eta, int nx, int ny, double *eta1, double *eta2, int n_iter);
+
 #ifdef __cplusplus
 }
 #endif

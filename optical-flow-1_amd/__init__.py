@@ -122,6 +122,13 @@ def lib():
                                     _i, C.POINTER(Stats)]),
         "ofx_brox_batch_dev": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _d, _d, _i,
                                     _d, _d, _i, _i, C.POINTER(_d)]),
+        "ofx_bicubic_warp_color": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _i]),
+        "ofx_image_normalization_2_color": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i]),
+        "ofx_image_normalization_3": (_i, [_vp, _dp, _dp, _dp, _i]),
+        "ofx_image_normalization_4": (_i, [_vp] + [_dp] * 8 + [_i]),
+        "ofx_me_median_filtering": (_i, [_vp, _dp, _i, _i, _i]),
+        "ofx_solver_wrt_v": (_i, [_vp] + [_dp] * 17 + [_d, _d, _d, _i, _i]),
+        "ofx_solver_wrt_chi": (_i, [_vp] + [_dp] * 14 + [_d] * 6 + [_i, _i, _dp, _dp, _i]),
         "ofx_hs_classic": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _d]),
         "ofx_brox_temporal": (_i, [_vp, _dp, _dp, _dp, _i, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
     }
@@ -421,3 +428,54 @@ class Ofx:
         u, v = np.zeros((h, w)), np.zeros((h, w))
         self._ck(self.L.ofx_hs_classic(self.h, _f64(a), _f64(b), u, v, w, h, niter, alpha))
         return u, v
+
+    # ---- SURVEY 8(f)4 colour operators / 8(f)1 building blocks of TV-L1 with occlusions ------------------------------
+    def bicubic_warp_color(self, I, u, v, border_out=False):
+        """I: (ny, nx, nz) interleaved channels; u, v: (ny, nx)"""
+        ny, nx, nz = I.shape
+        out = np.empty((ny, nx, nz))
+        self._ck(self.L.ofx_bicubic_warp_color(self.h, _f64(I), _f64(u), _f64(v), out, nx, ny, nz, int(border_out)))
+        return out
+
+    def image_normalization_2_color(self, I1, I2, size=None):
+        nz = I1.shape[-1]
+        a, b = _f64(I1).copy(), _f64(I2).copy()
+        self._ck(self.L.ofx_image_normalization_2_color(self.h, _f64(I1), _f64(I2), a, b, I1.size if size is None else size, nz))
+        return a, b
+
+    def image_normalization_3(self, I0, I1, I2):
+        a, b, c = _f64(I0).copy(), _f64(I1).copy(), _f64(I2).copy()
+        self._ck(self.L.ofx_image_normalization_3(self.h, a, b, c, a.size))
+        return a, b, c
+
+    def image_normalization_4(self, I_1, I0, I1, F):
+        outs = [np.empty(I0.shape) for _ in range(4)]
+        self._ck(self.L.ofx_image_normalization_4(self.h, _f64(I_1), _f64(I0), _f64(I1), _f64(F), *outs, I0.size))
+        return outs
+
+    def median_filtering(self, I, wsize=3):
+        ny, nx = I.shape
+        out = _f64(I).copy()
+        self._ck(self.L.ofx_me_median_filtering(self.h, out, nx, ny, wsize))
+        return out
+
+    def occ_solver_v(self, u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, grad1, grad3, alpha, theta, lam):
+        """Solver_wrt_v -> (v1, v2, Vfwd_1, Vfwd_2, Vbck_1, Vbck_2)"""
+        ny, nx = u1.shape
+        v1, v2, f1, f2, b1, b2 = outs = [np.empty((ny, nx)) for _ in range(6)]
+        self._ck(self.L.ofx_solver_wrt_v(self.h, _f64(u1), _f64(u2), v1, v2, _f64(chi), _f64(I1wx), _f64(I1wy), _f64(I_1wx),
+                                         _f64(I_1wy), _f64(rho1_c), _f64(rho3_c), f1, f2, b1, b2, _f64(grad1), _f64(grad3),
+                                         alpha, theta, lam, nx, ny))
+        return outs
+
+    def occ_solver_chi(self, u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, Vf1, Vf2, Vb1, Vb2, g, lam, theta, alpha,
+                       beta, tau_chi, tau_eta, eta1=None, eta2=None, n_iter=100):
+        """Solver_wrt_chi with the dual variable as explicit state -> (chi, eta1, eta2); eta defaults to zero"""
+        ny, nx = u1.shape
+        chi = _f64(chi).copy()
+        eta1 = np.zeros((ny, nx)) if eta1 is None else _f64(eta1).copy()
+        eta2 = np.zeros((ny, nx)) if eta2 is None else _f64(eta2).copy()
+        self._ck(self.L.ofx_solver_wrt_chi(self.h, _f64(u1), _f64(u2), chi, _f64(I1wx), _f64(I1wy), _f64(I_1wx), _f64(I_1wy),
+                                           _f64(rho1_c), _f64(rho3_c), _f64(Vf1), _f64(Vf2), _f64(Vb1), _f64(Vb2), _f64(g), lam,
+                                           theta, alpha, beta, tau_chi, tau_eta, nx, ny, eta1, eta2, n_iter))
+        return chi, eta1, eta2

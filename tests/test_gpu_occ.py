@@ -1,0 +1,74 @@
+"""GPU parity of the operators next to the hot path: colour warp and normalisations, the median
+filter and the two pointwise / stencil solvers of TV-L1 with occlusions -- bit for bit against the oracle, which
+tests/test_oracle_vs_ref.py pins against the compiled reference (Solver_wrt_chi: from a zero dual variable)."""
+import numpy as np
+import pytest
+
+from test_oracle_vs_ref import _occ_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ny,nx,nz", [(9, 13, 3), (40, 70, 3), (17, 8, 2), (6, 6, 1), (130, 97, 4)])
+def test_colour_warp_and_normalisation_bitexact(gpu64, orc, ny, nx, nz):
+    rng = np.random.default_rng(nx * ny + nz)
+    I = rng.random((ny, nx, nz)) * 255
+    u, v = rng.standard_normal((ny, nx)) * 3, rng.standard_normal((ny, nx)) * 3
+    u[0, :] = -30.0                                    # far out of range
+    for bo in (False, True):
+        assert np.array_equal(gpu64.bicubic_warp_color(I, u, v, bo), orc.bicubic_warp_color(I, u, v, bo))
+    J = rng.random((ny, nx, nz)) * 100 - 20
+    for a, b in zip(gpu64.image_normalization_2_color(I, J), orc.image_normalization_2_color(I, J)):
+        assert np.array_equal(a, b)
+    K = np.full((ny, nx, nz), 7.0)
+    K[..., 0] = I[..., 0]                              # one varying channel, the others constant: copy path per channel
+    for a, b in zip(gpu64.image_normalization_2_color(K, K), orc.image_normalization_2_color(K, K)):
+        assert np.array_equal(a, b)
+
+
+def test_joint_normalisations_bitexact(gpu64, ofx_mod, orc):
+    rng = np.random.default_rng(11)
+    A, B, Cc, D = (rng.random((57, 43)) * s - o for s, o in ((255, 0), (90, 30), (300, 100), (10, 5)))
+    for a, b in zip(gpu64.image_normalization_3(A, B, Cc), orc.image_normalization_3(A, B, Cc)):
+        assert np.array_equal(a, b)
+    for a, b in zip(gpu64.image_normalization_4(A, B, Cc, D), orc.image_normalization_4(A, B, Cc, D)):
+        assert np.array_equal(a, b)
+    Z = np.full((4, 5), 3.0)
+    for a in gpu64.image_normalization_4(Z, Z, Z, Z):
+        assert np.array_equal(a, Z)                    # max == min: copy
+    with pytest.raises(ofx_mod.OfxError):
+        gpu64.image_normalization_2_color(np.zeros((4, 4, 3)), np.zeros((4, 4, 3)), size=47)     # not a multiple of nz
+
+
+@pytest.mark.parametrize("ny,nx", [(7, 9), (3, 3), (1, 6), (12, 2), (90, 131)])
+def test_median_filter_bitexact(gpu64, ofx_mod, orc, ny, nx):
+    rng = np.random.default_rng(ny * 100 + nx)
+    I = np.round(rng.standard_normal((ny, nx)) * 4, 1)               # ties on purpose
+    for w in (1, 3, 5):
+        if (w >> 1) > min(nx, ny):
+            with pytest.raises(ofx_mod.OfxError):
+                gpu64.median_filtering(I, w)
+            continue
+        assert np.array_equal(gpu64.median_filtering(I, w), orc.median_filtering(I, w)), w
+    with pytest.raises(ofx_mod.OfxError):
+        gpu64.median_filtering(I, 11)
+
+
+@pytest.mark.parametrize("nx,ny", [(19, 13), (8, 22), (150, 97)])
+def test_occlusion_solvers_bitexact(gpu64, orc, nx, ny):
+    rng = np.random.default_rng(nx + 1000 * ny)
+    u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, grad1, grad3, g = _occ_inputs(rng, nx, ny)
+    args_v = (u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, grad1, grad3, 0.01, 0.3, 0.15)
+    vg, vo = gpu64.occ_solver_v(*args_v), orc.occ_solver_v(*args_v)
+    for a, b in zip(vg, vo):
+        assert np.array_equal(a, b)
+    v1, v2, f1, f2, b1, b2 = vo
+    par = (0.15, 0.3, 0.01, 0.15, 0.15, 0.15)                 # lambda, theta, alpha, beta, tau_chi, tau_eta
+    args_c = (u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, f1, f2, b1, b2, g) + par
+    cg, e1g, e2g = gpu64.occ_solver_chi(*args_c)              # 100 iterations from eta = 0, as the reference
+    co, e1o, e2o = orc.occ_solver_chi(*args_c)
+    assert np.array_equal(cg, co) and np.array_equal(e1g, e1o) and np.array_equal(e2g, e2o)
+    # explicit state: 37 + 63 iterations with eta carried over = 100 iterations
+    c1, a1, a2 = gpu64.occ_solver_chi(*args_c, n_iter=37)
+    c2, _, _ = gpu64.occ_solver_chi(u1, u2, c1, *args_c[3:], eta1=a1, eta2=a2, n_iter=63)
+    assert np.array_equal(c2, co)

@@ -150,6 +150,8 @@ def test_median_filtering(orc, ref):
     for ny, nx in ((7, 9), (3, 3), (1, 6), (12, 2), (20, 31)):
         I = np.round(rng.standard_normal((ny, nx)) * 4, 1)           # ties on purpose
         for w in (3, 5):
+            if (w >> 1) > min(nx, ny):
+                continue                  # the mirrored index leaves the image: the reference reads out of bounds
             assert np.array_equal(orc.median_filtering(I, w), ref.median_filtering(I, w)), (ny, nx, w)
 
 
