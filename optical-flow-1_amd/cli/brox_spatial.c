@@ -11,15 +11,20 @@
 
 #include "ofx_cli_common.h"
 
-#define PAR_DEFAULT_NPROC 0                 /* src/brox_spatial_main.cpp:29-39 */
-#define PAR_DEFAULT_ALPHA 50
-#define PAR_DEFAULT_GAMMA 10
-#define PAR_DEFAULT_NSCALES 10
-#define PAR_DEFAULT_ZFACTOR 0.5
-#define PAR_DEFAULT_TOL 0.0001
-#define PAR_DEFAULT_INNER_ITER 1
-#define PAR_DEFAULT_OUTER_ITER 15
-#define PAR_DEFAULT_VERBOSE 0
+/* src/brox_spatial_main.cpp:29-39 (defaults), :102-142 (ranges, silent) */
+static const cli_opt OPTS[] = {
+    {"out_file",    CLI_TEXT, 0,      "flow.flo", CLI_ANY, 0, NULL},
+    {"nproc",       CLI_INT,  0,      NULL, CLI_ANY, 0, NULL},
+    {"alpha",       CLI_REAL, 50,     NULL, CLI_LE0, 0, NULL},
+    {"gamma",       CLI_REAL, 10,     NULL, CLI_LT0, 0, NULL},
+    {"nscales",     CLI_INT,  10,     NULL, CLI_LE0, 0, NULL},
+    {"zoom_factor", CLI_REAL, 0.5,    NULL, CLI_LE0 | CLI_GE1, 0, NULL},
+    {"TOL",         CLI_REAL, 0.0001, NULL, CLI_LE0, 0, NULL},
+    {"inner_iter",  CLI_INT,  1,      NULL, CLI_LE0, 0, NULL},
+    {"outer_iter",  CLI_INT,  15,     NULL, CLI_LE0, 0, NULL},
+    {"verbose",     CLI_INT,  0,      NULL, CLI_ANY, 0, NULL},
+};
+enum { O_OUT, O_NPROC, O_ALPHA, O_GAMMA, O_NSCALES, O_ZFACTOR, O_TOL, O_INNER, O_OUTER, O_VERBOSE, O_COUNT };
 
 int main(int argc, char *argv[])
 {
@@ -27,28 +32,13 @@ int main(int argc, char *argv[])
         printf("Usage: %s I1 I2 [out_file alpha gamma nscales zoom_factor TOL inner_iter outer_iter verbose]\n", argv[0]);
         return 0;
     }
-    int i = 1;
-    const char *image1 = argv[i]; i++;
-    const char *image2 = argv[i]; i++;
-    const char *outfile = (argc >= 4) ? argv[i] : "flow.flo"; i++;
-    int    nproc   = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_NPROC;      i++;
-    double alpha   = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_ALPHA;      i++;
-    double gamma   = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_GAMMA;      i++;
-    int    nscales = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_NSCALES;    i++;
-    double zfactor = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_ZFACTOR;    i++;
-    double TOL     = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_TOL;        i++;
-    int    initer  = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_INNER_ITER; i++;
-    int    outiter = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_OUTER_ITER; i++;
-    int    verbose = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_VERBOSE;    i++;
-    (void) nproc;
-
-    if (alpha <= 0) alpha = PAR_DEFAULT_ALPHA;              /* :122-142 */
-    if (gamma < 0) gamma = PAR_DEFAULT_GAMMA;
-    if (nscales <= 0) nscales = PAR_DEFAULT_NSCALES;
-    if (zfactor <= 0 || zfactor >= 1) zfactor = PAR_DEFAULT_ZFACTOR;
-    if (TOL <= 0) TOL = PAR_DEFAULT_TOL;
-    if (initer <= 0) initer = PAR_DEFAULT_INNER_ITER;
-    if (outiter <= 0) outiter = PAR_DEFAULT_OUTER_ITER;
+    const char *image1 = argv[1], *image2 = argv[2];
+    cli_val o[O_COUNT];
+    cli_parse(argc, argv, 3, OPTS, O_COUNT, o);
+    const char *outfile = o[O_OUT].text;
+    const int initer = (int) o[O_INNER].num, outiter = (int) o[O_OUTER].num, verbose = (int) o[O_VERBOSE].num;
+    int nscales = (int) o[O_NSCALES].num;
+    const double alpha = o[O_ALPHA].num, gamma = o[O_GAMMA].num, zfactor = o[O_ZFACTOR].num, TOL = o[O_TOL].num;
 
     int nx, ny, nx1, ny1;
     double *I1 = ofx_read_image_double(image1, &nx, &ny);

@@ -10,15 +10,19 @@
 
 #include "ofx_cli_common.h"
 
-#define PAR_DEFAULT_ALPHA 18                /* src/brox_temporal_main.cpp:19-27 */
-#define PAR_DEFAULT_GAMMA 7
-#define PAR_DEFAULT_NSCALES 100
-#define PAR_DEFAULT_ZFACTOR 0.75
-#define PAR_DEFAULT_TOL 0.0001
-#define PAR_DEFAULT_INNER_ITER 1
-#define PAR_DEFAULT_OUTER_ITER 15
-#define PAR_DEFAULT_DIR "./"
-#define PAR_DEFAULT_VERBOSE 0
+/* src/brox_temporal_main.cpp:19-27 (defaults), :141-177 (ranges, silent) */
+static const cli_opt OPTS[] = {
+    {"alpha",       CLI_REAL, 18,     NULL, CLI_LE0, 0, NULL},
+    {"gamma",       CLI_REAL, 7,      NULL, CLI_LT0, 0, NULL},
+    {"nscales",     CLI_INT,  100,    NULL, CLI_LE0, 0, NULL},
+    {"zoom_factor", CLI_REAL, 0.75,   NULL, CLI_LE0 | CLI_GE1, 0, NULL},
+    {"TOL",         CLI_REAL, 0.0001, NULL, CLI_LE0, 0, NULL},
+    {"inner_iter",  CLI_INT,  1,      NULL, CLI_LE0, 0, NULL},
+    {"outer_iter",  CLI_INT,  15,     NULL, CLI_LE0, 0, NULL},
+    {"dir",         CLI_TEXT, 0,      "./", CLI_ANY, 0, NULL},
+    {"verbose",     CLI_INT,  0,      NULL, CLI_ANY, 0, NULL},
+};
+enum { O_ALPHA, O_GAMMA, O_NSCALES, O_ZFACTOR, O_TOL, O_INNER, O_OUTER, O_DIR, O_VERBOSE, O_COUNT };
 
 int main(int argc, char *argv[])
 {
@@ -45,23 +49,12 @@ int main(int argc, char *argv[])
         free(img);
     }
     i += frames > 0 ? frames : 0;
-    double alpha   = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_ALPHA;      i++;
-    double gamma   = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_GAMMA;      i++;
-    int    nscales = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_NSCALES;    i++;
-    double zfactor = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_ZFACTOR;    i++;
-    double TOL     = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_TOL;        i++;
-    int    initer  = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_INNER_ITER; i++;
-    int    outiter = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_OUTER_ITER; i++;
-    const char *dir = (argc > i) ? argv[i] : PAR_DEFAULT_DIR;             i++;
-    int    verbose = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_VERBOSE;    i++;
-
-    if (alpha <= 0) alpha = PAR_DEFAULT_ALPHA;              /* :157-177 */
-    if (gamma < 0) gamma = PAR_DEFAULT_GAMMA;
-    if (nscales <= 0) nscales = PAR_DEFAULT_NSCALES;
-    if (zfactor <= 0 || zfactor >= 1) zfactor = PAR_DEFAULT_ZFACTOR;
-    if (TOL <= 0) TOL = PAR_DEFAULT_TOL;
-    if (initer <= 0) initer = PAR_DEFAULT_INNER_ITER;
-    if (outiter <= 0) outiter = PAR_DEFAULT_OUTER_ITER;
+    cli_val o[O_COUNT];
+    cli_parse(argc, argv, i, OPTS, O_COUNT, o);
+    const double alpha = o[O_ALPHA].num, gamma = o[O_GAMMA].num, zfactor = o[O_ZFACTOR].num, TOL = o[O_TOL].num;
+    const int initer = (int) o[O_INNER].num, outiter = (int) o[O_OUTER].num, verbose = (int) o[O_VERBOSE].num;
+    int nscales = (int) o[O_NSCALES].num;
+    const char *dir = o[O_DIR].text;
 
     if (!correct) {
         fprintf(stderr, "Cannot read the images or the size of the images are not equal\n");

@@ -9,15 +9,19 @@
 
 #include "ofx_cli_common.h"
 
-#define PAR_DEFAULT_NPROC 0                 /* src/horn_schunck_pyramidal_main.cpp:24-32 */
-#define PAR_DEFAULT_ALPHA 7
-#define PAR_DEFAULT_NSCALES 10
-#define PAR_DEFAULT_ZFACTOR 0.5
-#define PAR_DEFAULT_NWARPS 10
-#define PAR_DEFAULT_TOL 0.0001
-#define PAR_DEFAULT_MAXITER 150
-#define PAR_DEFAULT_VERBOSE 0
-#define PAR_MAX_ZFACTOR 0.99
+/* src/horn_schunck_pyramidal_main.cpp:24-32 (defaults), :93-118 (ranges, silent; zoom_factor >= 1 becomes 0.99) */
+static const cli_opt OPTS[] = {
+    {"out_file",    CLI_TEXT, 0,      "flow.flo", CLI_ANY, 0, NULL},
+    {"processors",  CLI_INT,  0,      NULL, CLI_ANY, 0, NULL},
+    {"alpha",       CLI_REAL, 7,      NULL, CLI_LE0, 0, NULL},
+    {"nscales",     CLI_INT,  10,     NULL, CLI_LE0, 0, NULL},
+    {"zoom_factor", CLI_REAL, 0.5,    NULL, CLI_LE0 | CLI_GE1, 0.99, NULL},
+    {"nwarps",      CLI_INT,  10,     NULL, CLI_LE0, 0, NULL},
+    {"TOL",         CLI_REAL, 0.0001, NULL, CLI_LE0, 0, NULL},
+    {"maxiter",     CLI_INT,  150,    NULL, CLI_ANY, 0, NULL},
+    {"verbose",     CLI_INT,  0,      NULL, CLI_ANY, 0, NULL},
+};
+enum { O_OUT, O_NPROC, O_ALPHA, O_NSCALES, O_ZFACTOR, O_NWARPS, O_TOL, O_MAXITER, O_VERBOSE, O_COUNT };
 
 int main(int argc, char *argv[])
 {
@@ -25,25 +29,14 @@ int main(int argc, char *argv[])
         fprintf(stderr, "Usage: %s I1 I2 [out_file processors alpha nscales zoom_factor nwarps TOL maxiter verbose]\n", *argv);
         return EXIT_FAILURE;
     }
-    int i = 1;
-    const char *image1 = argv[i]; i++;
-    const char *image2 = argv[i]; i++;
-    const char *outfile = (argc >= 4) ? argv[i] : "flow.flo"; i++;
-    int    nproc   = (argc >= 5)  ? atoi(argv[i]) : PAR_DEFAULT_NPROC;   i++;
-    double alpha   = (argc >= 6)  ? atof(argv[i]) : PAR_DEFAULT_ALPHA;   i++;
-    int    nscales = (argc >= 7)  ? atoi(argv[i]) : PAR_DEFAULT_NSCALES; i++;
-    double zfactor = (argc >= 8)  ? atof(argv[i]) : PAR_DEFAULT_ZFACTOR; i++;
-    int    warps   = (argc >= 9)  ? atoi(argv[i]) : PAR_DEFAULT_NWARPS;  i++;
-    double TOL     = (argc >= 10) ? atof(argv[i]) : PAR_DEFAULT_TOL;     i++;
-    int    maxiter = (argc >= 11) ? atoi(argv[i]) : PAR_DEFAULT_MAXITER; i++;
-    int    verbose = (argc >= 12) ? atoi(argv[i]) : PAR_DEFAULT_VERBOSE; i++;
-
-    if (alpha <= 0) alpha = PAR_DEFAULT_ALPHA;              /* :101-118 */
-    if (nscales <= 0) nscales = PAR_DEFAULT_NSCALES;
-    if (zfactor <= 0) zfactor = PAR_DEFAULT_ZFACTOR;
-    if (zfactor >= 1) zfactor = PAR_MAX_ZFACTOR;
-    if (warps <= 0) warps = PAR_DEFAULT_NWARPS;
-    if (TOL <= 0) TOL = PAR_DEFAULT_TOL;
+    const char *image1 = argv[1], *image2 = argv[2];
+    cli_val o[O_COUNT];
+    cli_parse(argc, argv, 3, OPTS, O_COUNT, o);
+    const char *outfile = o[O_OUT].text;
+    const int nproc = (int) o[O_NPROC].num, warps = (int) o[O_NWARPS].num, maxiter = (int) o[O_MAXITER].num;
+    const int verbose = (int) o[O_VERBOSE].num;
+    int nscales = (int) o[O_NSCALES].num;
+    const double alpha = o[O_ALPHA].num, zfactor = o[O_ZFACTOR].num, TOL = o[O_TOL].num;
 
     int nx, ny, nx1, ny1;
     double *I1 = ofx_read_image_double(image1, &nx, &ny);

@@ -24,6 +24,59 @@ static ofx_ctx *cli_context(void)
     return ctx;
 }
 
+/* ---- positional, optional, silently-corrected arguments ----------------------------------------------------------------
+ * All the reference's front-ends read their options the same way: positional, every trailing one optional, a value
+ * outside its range is replaced (by the default, or by a given substitute) instead of rejected -- with a warning on
+ * stderr only in tvl1flow and only when `verbose` (the LAST option) is set (src/tvl1flow_main.cpp:97-167,
+ * src/horn_schunck_pyramidal_main.cpp:93-118, src/brox_spatial_main.cpp:102-142, src/brox_temporal_main.cpp:141-177).
+ * One table per program (name, kind, default, range test, substitute, warning format) drives one parser. */
+enum { CLI_INT, CLI_REAL, CLI_TEXT };
+enum {                         /* when is the value out of range? */
+    CLI_ANY = 0,               /* never checked (nproc of some programs, maxiter, verbose) */
+    CLI_LE0 = 1,               /* value <= 0 */
+    CLI_LT0 = 2,               /* value <  0 */
+    CLI_GE1 = 4,               /* value >= 1            (may be combined with CLI_LE0) */
+    CLI_GT_QUARTER = 8         /* value > 0.25          (tvl1flow's tau) */
+};
+typedef struct {
+    const char *name;
+    int         kind;
+    double      def;           /* default (numbers) */
+    const char *def_text;      /* default (CLI_TEXT) */
+    int         bad;           /* CLI_* range test */
+    double      ge1_value;     /* substitute when only the CLI_GE1 test fires; 0 = the default */
+    const char *warn;          /* printf format of the warning ("warning: tau changed to %g\n"), NULL = silent */
+} cli_opt;
+typedef struct {
+    double      num;
+    const char *text;
+} cli_val;
+
+/* argv[first ...] -> out[0 .. n-1]; then the range corrections, in table order, warnings to stderr iff out[n-1] (by
+ * convention `verbose`) is non-zero and the row has a format */
+__attribute__((unused)) static void cli_parse(int argc, char *argv[], int first, const cli_opt *opt, int n, cli_val *out)
+{
+    for (int k = 0; k < n; k++) {
+        const char *a = (argc > first + k) ? argv[first + k] : NULL;
+        out[k].text = a ? a : opt[k].def_text;
+        out[k].num = opt[k].def;
+        if (a && opt[k].kind == CLI_INT) out[k].num = atoi(a);
+        if (a && opt[k].kind == CLI_REAL) out[k].num = atof(a);
+    }
+    const int verbose = n > 0 && out[n - 1].num != 0;
+    for (int k = 0; k < n; k++) {
+        const double v = out[k].num;
+        const int low = ((opt[k].bad & CLI_LE0) && v <= 0) || ((opt[k].bad & CLI_LT0) && v < 0);
+        const int high = ((opt[k].bad & CLI_GE1) && v >= 1) || ((opt[k].bad & CLI_GT_QUARTER) && v > 0.25);
+        if (!low && !high) continue;
+        out[k].num = (!low && high && opt[k].ge1_value != 0) ? opt[k].ge1_value : opt[k].def;
+        if (verbose && opt[k].warn) {
+            if (opt[k].kind == CLI_INT) fprintf(stderr, opt[k].warn, (int) out[k].num);
+            else fprintf(stderr, opt[k].warn, out[k].num);
+        }
+    }
+}
+
 /* cast to float, interleave, write (src/tvl1flow_main.cpp:209-214).  Only the .flo container is
  * implemented; the reference picks the format from the file suffix (src/iio.cpp:3671-3676). */
 static int cli_save_flow(const char *outfile, const double *u, const double *v, int nx, int ny)

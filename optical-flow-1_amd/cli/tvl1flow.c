@@ -10,16 +10,20 @@
 
 #include "ofx_cli_common.h"
 
-#define PAR_DEFAULT_OUTFLOW "flow.flo"      /* src/tvl1flow_main.cpp:24-33 */
-#define PAR_DEFAULT_NPROC   0
-#define PAR_DEFAULT_TAU     0.25
-#define PAR_DEFAULT_LAMBDA  0.15
-#define PAR_DEFAULT_THETA   0.3
-#define PAR_DEFAULT_NSCALES 100
-#define PAR_DEFAULT_ZFACTOR 0.5
-#define PAR_DEFAULT_NWARPS  5
-#define PAR_DEFAULT_EPSILON 0.01
-#define PAR_DEFAULT_VERBOSE 0
+/* src/tvl1flow_main.cpp:24-33 (defaults), :97-167 (ranges; warnings only when verbose) */
+static const cli_opt OPTS[] = {
+    {"out",     CLI_TEXT, 0,    "flow.flo", CLI_ANY, 0, NULL},
+    {"nproc",   CLI_INT,  0,    NULL, CLI_LT0, 0, "warning: nproc changed to %d\n"},
+    {"tau",     CLI_REAL, 0.25, NULL, CLI_LE0 | CLI_GT_QUARTER, 0, "warning: tau changed to %g\n"},
+    {"lambda",  CLI_REAL, 0.15, NULL, CLI_LE0, 0, "warning: lambda changed to %g\n"},
+    {"theta",   CLI_REAL, 0.3,  NULL, CLI_LE0, 0, "warning: theta changed to %g\n"},
+    {"nscales", CLI_INT,  100,  NULL, CLI_LE0, 0, "warning: nscales changed to %d\n"},
+    {"zfactor", CLI_REAL, 0.5,  NULL, CLI_LE0 | CLI_GE1, 0, "warning: zfactor changed to %g\n"},
+    {"nwarps",  CLI_INT,  5,    NULL, CLI_LE0, 0, "warning: nwarps changed to %d\n"},
+    {"epsilon", CLI_REAL, 0.01, NULL, CLI_LE0, 0, "warning: epsilon changed to %f\n"},
+    {"verbose", CLI_INT,  0,    NULL, CLI_ANY, 0, NULL},
+};
+enum { O_OUT, O_NPROC, O_TAU, O_LAMBDA, O_THETA, O_NSCALES, O_ZFACTOR, O_NWARPS, O_EPSILON, O_VERBOSE, O_COUNT };
 
 int main(int argc, char *argv[])
 {
@@ -27,29 +31,14 @@ int main(int argc, char *argv[])
         fprintf(stderr, "Usage: %s I0 I1 [out nproc tau lambda theta nscales zfactor nwarps epsilon verbose]\n", *argv);
         return EXIT_FAILURE;
     }
-    int i = 1;
-    const char *image1_name = argv[i]; i++;
-    const char *image2_name = argv[i]; i++;
-    const char *outfile = (argc > i) ? argv[i] : PAR_DEFAULT_OUTFLOW; i++;
-    int    nproc   = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_NPROC;   i++;
-    double tau     = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_TAU;     i++;
-    double lambda  = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_LAMBDA;  i++;
-    double theta   = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_THETA;   i++;
-    int    nscales = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_NSCALES; i++;
-    double zfactor = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_ZFACTOR; i++;
-    int    nwarps  = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_NWARPS;  i++;
-    double epsilon = (argc > i) ? atof(argv[i]) : PAR_DEFAULT_EPSILON; i++;
-    int    verbose = (argc > i) ? atoi(argv[i]) : PAR_DEFAULT_VERBOSE; i++;
-
-    /* out-of-range values silently fall back to the defaults, :102-167 */
-    if (nproc < 0) { nproc = PAR_DEFAULT_NPROC; if (verbose) fprintf(stderr, "warning: nproc changed to %d\n", nproc); }
-    if (tau <= 0 || tau > 0.25) { tau = PAR_DEFAULT_TAU; if (verbose) fprintf(stderr, "warning: tau changed to %g\n", tau); }
-    if (lambda <= 0) { lambda = PAR_DEFAULT_LAMBDA; if (verbose) fprintf(stderr, "warning: lambda changed to %g\n", lambda); }
-    if (theta <= 0) { theta = PAR_DEFAULT_THETA; if (verbose) fprintf(stderr, "warning: theta changed to %g\n", theta); }
-    if (nscales <= 0) { nscales = PAR_DEFAULT_NSCALES; if (verbose) fprintf(stderr, "warning: nscales changed to %d\n", nscales); }
-    if (zfactor <= 0 || zfactor >= 1) { zfactor = PAR_DEFAULT_ZFACTOR; if (verbose) fprintf(stderr, "warning: zfactor changed to %g\n", zfactor); }
-    if (nwarps <= 0) { nwarps = PAR_DEFAULT_NWARPS; if (verbose) fprintf(stderr, "warning: nwarps changed to %d\n", nwarps); }
-    if (epsilon <= 0) { epsilon = PAR_DEFAULT_EPSILON; if (verbose) fprintf(stderr, "warning: epsilon changed to %f\n", epsilon); }
+    const char *image1_name = argv[1], *image2_name = argv[2];
+    cli_val o[O_COUNT];
+    cli_parse(argc, argv, 3, OPTS, O_COUNT, o);
+    const char *outfile = o[O_OUT].text;
+    const int nproc = (int) o[O_NPROC].num, nwarps = (int) o[O_NWARPS].num, verbose = (int) o[O_VERBOSE].num;
+    int nscales = (int) o[O_NSCALES].num;
+    const double tau = o[O_TAU].num, lambda = o[O_LAMBDA].num, theta = o[O_THETA].num, zfactor = o[O_ZFACTOR].num;
+    const double epsilon = o[O_EPSILON].num;
 
     int nx, ny, nx2, ny2;
     double *I0 = ofx_read_image_double(image1_name, &nx, &ny);

@@ -224,3 +224,50 @@ def test_brox_temporal_cli(synth, tmp_path):
     assert r.returncode == 0 and "more than two frames" in r.stderr
     r = subprocess.run([os.path.join(BIN, "brox_temporal")], capture_output=True, text=True)
     assert r.returncode == 0 and "Usage:" in r.stdout
+
+
+def test_cli_option_table_warnings_and_substitutes(synth, tmp_path):
+    """the table-driven option parser (cli/ofx_cli_common.h): tvl1flow warns -- only with verbose -- in the reference's
+    order and formats (src/tvl1flow_main.cpp:102-167); horn_schunck_pyramidal turns zoom_factor >= 1 into 0.99, not the
+    default (src/horn_schunck_pyramidal_main.cpp:109-112)"""
+    nx, ny = 64, 48
+    I0, I1 = synth.pair("P0", nx, ny)
+    write_pgm(tmp_path / "a.pgm", I0)
+    write_pgm(tmp_path / "b.pgm", I1)
+    a, b = str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm")
+    r = subprocess.run([os.path.join(BIN, "tvl1flow"), a, b, str(tmp_path / "o.flo"), "-3", "9", "-1", "0", "-5", "1.5", "0",
+                        "-1", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    warn = [ln for ln in r.stderr.splitlines() if ln.startswith("warning:")]
+    assert warn == ["warning: nproc changed to 0", "warning: tau changed to 0.25", "warning: lambda changed to 0.15",
+                    "warning: theta changed to 0.3", "warning: nscales changed to 100", "warning: zfactor changed to 0.5",
+                    "warning: nwarps changed to 5", "warning: epsilon changed to 0.010000"]
+    quiet = subprocess.run([os.path.join(BIN, "tvl1flow"), a, b, str(tmp_path / "q.flo"), "-3", "9"], capture_output=True, text=True)
+    assert quiet.returncode == 0 and "warning" not in quiet.stderr
+    r = subprocess.run([os.path.join(BIN, "horn_schunck_pyramidal"), a, b, str(tmp_path / "h.flo"), "0", "-2", "2", "1.5", "0",
+                        "-1", "20", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "alpha=7 nscales=2 zfactor=0.99 warps=10 epsilon=0.0001" in r.stderr
+
+
+def test_tvl1flow_cli_many_scales(orc, synth, tmp_path):
+    """zfactor = 0.9: the reference's rule gives 1 + log(hypot(320, 240) / 16) / log(1 / 0.9) = 31.6 -> 31 pyramid levels here
+    (47 at 1080p, more than the 32 levels ofx_stats itemises): no fixed cap on the levels, .flo byte-identical"""
+    nx, ny = 320, 240
+    I0, I1 = synth.pair("P1", nx, ny)
+    write_pgm(tmp_path / "a.pgm", I0)
+    write_pgm(tmp_path / "b.pgm", I1)
+    out = tmp_path / "o.flo"
+    r = subprocess.run([os.path.join(BIN, "tvl1flow"), str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"), str(out),
+                        "0", "0.25", "0.15", "0.3", "100", "0.9", "2", "0.01", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "nscales=31 " in r.stderr
+    uo, vo, _, _ = orc.tvl1_multiscale(I0, I1, nscales=31, zfactor=0.9, warps=2)
+    assert np.array_equal(read_flo(out), np.stack([uo, vo], axis=-1).astype(np.float32))
+    # 34 levels (> OFX_MAX_SCALES = 32): zfactor = 0.91 -> 1 + log(400 / 16) / log(1 / 0.91) = 35.1 -> 35
+    r = subprocess.run([os.path.join(BIN, "tvl1flow"), str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"), str(out),
+                        "0", "0.25", "0.15", "0.3", "100", "0.91", "1", "0.01", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "nscales=35 " in r.stderr
+    uo, vo, _, _ = orc.tvl1_multiscale(I0, I1, nscales=35, zfactor=0.91, warps=1)
+    assert np.array_equal(read_flo(out), np.stack([uo, vo], axis=-1).astype(np.float32))
