@@ -248,27 +248,55 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes):
     return roof, levels, work, secs
 
 
-def sor_leg(ofx_mod, synth, local):
+def sor_leg(ofx_mod, synth, local, dev):
     """BASELINE configs 3 and 4 (parity-test cases, not the headline): exact-order Horn-Schunck 1920x1080 and Brox
-    1280x720 solves, host arrays in / out, one pair per call.  Algorithmic bytes per sweep: 56 B/px (HS), 80 B/px
-    (Brox) -- SURVEY 8(d)."""
-    ctx = ofx_mod.Ofx(local, ofx_mod.F64)
+    1280x720.  `one_pair`: one solve through the host entry point (the reference's calling convention, host arrays in /
+    out).  `batch`: 32 device-resident pairs (P0 + 31 P1 variants) through ofx_hs_batch_dev / ofx_brox_batch_dev, lockstep
+    groups of 16 pairs on 2 contexts; every flow is bit-identical to the pair solved alone (tests/test_gpu_sor.py).
+    Algorithmic bytes per sweep: 56 B/px (HS), 80 B/px (Brox) -- SURVEY 8(d)."""
+    import torch
     out = {}
-    for name, fn, size, bpp, kw in (
-            ("hs_cfg3", ctx.hs_pyramidal, (1920, 1080), 56.0, dict(alpha=20.0, nscales=5, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150)),
-            ("brox_cfg4", ctx.brox_spatial, (1280, 720), 80.0, dict(alpha=50.0, gamma=10.0, nscales=6, nu=0.5, TOL=1e-4, inner=1, outer=15))):
-        I1, I2 = synth.pair("P0", size[0], size[1])
-        fn(I1, I2, **kw)                                 # warm (arena, clocks)
+    solo = ofx_mod.Ofx(local, ofx_mod.F64)
+    ctxs = [ofx_mod.Ofx(local, ofx_mod.F64) for _ in range(2)]
+    for c in ctxs:
+        c.set_option("lockstep", 16)
+    NB = 32
+    for name, host_fn, batch_fn, size, bpp, kw in (
+            ("hs_cfg3", solo.hs_pyramidal, ofx_mod.hs_batch_dev, (1920, 1080), 56.0,
+             dict(alpha=20.0, nscales=5, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150)),
+            ("brox_cfg4", solo.brox_spatial, ofx_mod.brox_batch_dev, (1280, 720), 80.0,
+             dict(alpha=50.0, gamma=10.0, nscales=6, nu=0.5, TOL=1e-4, inner=1, outer=15))):
+        nx, ny = size
+
+        def rec(work, dt, extra):
+            mps = work / dt / 1e6
+            r = {"seconds": round(dt, 4), "mpix_sweeps_per_s": round(mps, 1), "algorithmic_gbs": round(mps * bpp / 1e3, 1),
+                 "frac_of_hbm_peak": round(mps * bpp / 1e3 / HBM_PEAK_GBS, 5)}
+            r.update(extra)
+            return r
+        I1, I2 = synth.pair("P0", nx, ny)
+        host_fn(I1, I2, **kw)                            # warm (arena, clocks)
         t0 = time.perf_counter()
-        fn(I1, I2, **kw)
+        host_fn(I1, I2, **kw)
         dt = time.perf_counter() - t0
-        st = ctx.stats()
-        mps = st.work_pix_iters / dt / 1e6
-        out[name] = {"size": "%dx%d" % size, "seconds": round(dt, 4), "sweeps": int(st.iterations().sum()),
-                     "mpix_sweeps_per_s": round(mps, 1), "algorithmic_gbs": round(mps * bpp / 1e3, 1),
-                     "frac_of_hbm_peak": round(mps * bpp / 1e3 / HBM_PEAK_GBS, 5), "bytes_per_pixel_sweep": bpp,
-                     "mode": "exact (reference sweep order, bit-identical), one pair per call, host arrays in/out"}
-    ctx.close()
+        st = solo.stats()
+        one = rec(st.work_pix_iters, dt, {"sweeps": int(st.iterations().sum()), "pair": "P0, host arrays in/out"})
+        ins = [synth.pair_device("P0" if k == 0 else "P1", nx, ny, k, dev) for k in range(NB)]
+        flo = torch.empty((NB, ny, nx, 2), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        args = ([t[0].data_ptr() for t in ins], [t[1].data_ptr() for t in ins], [flo[k].data_ptr() for k in range(NB)], nx, ny)
+        batch_fn(ctxs, *args, **kw)                      # warm
+        t0 = time.perf_counter()
+        work = batch_fn(ctxs, *args, **kw)
+        dt = time.perf_counter() - t0
+        out[name] = {"size": "%dx%d" % size, "bytes_per_pixel_sweep": bpp,
+                     "mode": "exact (reference sweep order, bit-identical to the reference)",
+                     "one_pair": one,
+                     "batch": rec(sum(work), dt, {"pairs": NB, "contexts": 2, "lockstep_group": 16, "ms_per_pair": round(dt / NB * 1e3, 2),
+                                                  "pairs_desc": "P0 + 31 P1 variants, device-resident"})}
+        del ins, flo
+    for c in ctxs + [solo]:
+        c.close()
     return out
 
 
@@ -496,7 +524,7 @@ def main():
 
     sor = None
     if rank == 0 and world == 1 and not a.no_sor:
-        sor = sor_leg(ofx_mod, synth, local)
+        sor = sor_leg(ofx_mod, synth, local, dev)
         log("sor leg done")
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
