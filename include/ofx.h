@@ -95,8 +95,9 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         of the pipelined schedule per launch; 2 = the same schedule, one launch per time step;
  *                         0 = colour-ordered sweeps (much faster, result drifts by ~1e-5..1e-3 px)
  *   "sor_batch"      sweeps in flight per batch in the exact modes (default 32 / 64)
- *   "sor_window"     time steps per launch of sor_exact = 1 (default 8)
- *   "sor_rows"       rows per workgroup (row block of a sweep) of sor_exact = 1 (default 64)
+ *   "sor_window"     time steps per launch of sor_exact = 1 (default 8; 4 for Brox in lockstep groups of >= 4 pairs)
+ *   "sor_rows"       rows per workgroup (row block of a sweep) of sor_exact = 1 (default 64; 125 in lockstep groups
+ *                         of >= 4 pairs)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
  *   "store_a"        TV-L1, fused pairs: a loop that stops on the first iteration of a pair needs the state between the
  *                         two iterations; 1 (default) = a launch also stores it when the previous error is within 1.5x

@@ -357,9 +357,13 @@ static int sor_window_loop(ofx_ctx *ctx, int G, int size, int ny, double TOL, in
     // is set; take(g, n) makes snapshot n - 1 of problem g its current state.  All problems start together, so the
     // ones still sweeping have all run the same number of full batches.
     if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "sor group of %d problems", G);
+    // Measured on MI355X with the hyperplane-major layout (profiles/r02_e_sor_geometry_sweep.jsonl): a lone solve wants
+    // many small workgroups (64 rows: more row blocks in flight along the latency chain), a lockstep group has enough
+    // workgroups anyway and runs 6-10 % faster with 125 rows (+ the 3 border items = two full waves); 8 steps per launch,
+    // 4 for the 4-neighbour stencil in a group (its sweeps are spaced C = 2 apart, so the 2 K lag dominates the pipeline).
     SorWin w;
-    w.K = ctx->sor_window > 0 ? ctx->sor_window : 8;
-    w.R = ctx->sor_rows > 0 ? ctx->sor_rows : 64;
+    w.K = ctx->sor_window > 0 ? ctx->sor_window : ((G >= 4 && C <= 2) ? 4 : 8);
+    w.R = ctx->sor_rows > 0 ? ctx->sor_rows : (G >= 4 ? 125 : 64);
     if (w.R < 2) w.R = 2;
     if (w.R > 1021) w.R = 1021;                                  // R + 3 threads per workgroup
     const int B = ofx_cdiv(ny, w.R);
