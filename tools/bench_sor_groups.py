@@ -20,6 +20,10 @@ CONFIGS = [("hs_cfg3", (640, 360) if small else (1920, 1080), 56.0,
             dict(alpha=50.0, gamma=10.0, nscales=4 if small else 6, nu=0.5, TOL=1e-4, inner=1, outer=15))]
 GRID = [(1, 1), (1, 4), (1, 16), (2, 16), (4, 16)]           # (contexts, pairs per group)
 NPAIRS = 16                                                  # every grid point solves the SAME first 16 pairs (x contexts > 1: 16 per context)
+for a in sys.argv[1:]:
+    if a.startswith("--grid="):                              # e.g. --grid=1x16,2x16
+        GRID = [tuple(int(x) for x in g.split("x")) for g in a.split("=")[1].split(",")]
+nowarm = "--no-warm" in sys.argv
 for name, (nx, ny), bpp, kw in CONFIGS:
     if only and name not in only:
         continue
@@ -34,7 +38,8 @@ for name, (nx, ny), bpp, kw in CONFIGS:
             c.set_option("lockstep", G)
         n = max(NPAIRS, nctx * G)
         args = ([t[0].data_ptr() for t in ins[:n]], [t[1].data_ptr() for t in ins[:n]], [flo[k].data_ptr() for k in range(n)], nx, ny)
-        fn(ctxs, *args, **kw)                                  # warm (arena, snapshots, clocks)
+        if not nowarm:
+            fn(ctxs, *args, **kw)                              # warm (arena, snapshots, clocks)
         t0 = time.perf_counter()
         work = fn(ctxs, *args, **kw)
         dt = time.perf_counter() - t0

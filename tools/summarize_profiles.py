@@ -4,8 +4,9 @@ usage: tools/summarize_profiles.py <tag>      e.g. r01_final"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "final")
-DST = os.path.join(ROOT, "profiles")
+SRC = os.environ.get("OFX_PROF_SRC") or os.path.join(ROOT, "gpurun_out", "final")
+DST = os.environ.get("OFX_PROF_DST") or os.path.join(ROOT, "profiles")
+os.makedirs(DST, exist_ok=True)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 
 shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, tag + "_bench.json"))
@@ -22,7 +23,7 @@ def newest(pattern):
 
 stats = list(csv.DictReader(open(newest(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0])))
 trace = list(csv.DictReader(open(newest(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv"))[0])))
-out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu --streams 1 --lockstep 1   (MI355X, f64, 1920x1080 P1)",
+out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu --no-4k --no-sor --streams 1 --lockstep 1   (MI355X, f64, 1920x1080 P1)",
        "# the run contains the reference-semantics steps (eps=0.01) AND the fixed-work passes (300 iterations / warp)",
        "# kernel | calls | total ms | average us | % of GPU time", ""]
 for r in stats:
