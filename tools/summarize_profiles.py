@@ -92,6 +92,16 @@ for sz in ("1920x1080", "3840x2160"):
                           "clock_ghz": vals["GRBM_GUI_ACTIVE"] / 8 / (vals["launch_us_fetch"] * 1e-6) / 1e9,
                           "launch_us": vals["launch_us_fetch"], "valu_insts_per_launch": vals["SQ_INSTS_VALU"],
                           "waves": vals["SQ_WAVES"]}
+for sz, ceil in (("1920x1080", "arithmetic alone 92 % of the production time, memory traffic alone 61 % -> VALU-bound (working set inside the 256 MiB Infinity Cache)"),
+                 ("3840x2160", "arithmetic alone 81 % of the production time, memory traffic alone 70 % -> neither hides the other (4 waves per SIMD at 128 VGPRs)")):
+    if "detail_" + sz not in pm:
+        continue
+    d, tr = pm["detail_" + sz], pm["bytes_per_launch_f64_" + sz]
+    rate = tr / (d["launch_us"] * 1e-6) / 1e12
+    pm["limiter_f64_" + sz] = ("co-limited by FP64 issue and memory: VALU active %.0f %% of the launch, counter traffic %.0f MB per launch = %.2f TB/s = %.0f %% "
+                               "of the 8 TB/s peak (at the launch time of the counter run, %.0f us, clock %.2f GHz); ceiling variants of the kernel "
+                               "(profiles/r02_a_iter2_ceilings_alu_mem.txt, measured once in round 2): " % (100 * d["valu_active_fraction"], tr / 1e6, rate,
+                                                                                                      100 * rate / 8, d["launch_us"], d["clock_ghz"])) + ceil
 json.dump(pm, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 # the committed bench line carries the traffic measured in THIS collection (bench.py reads the previous file)
 key = "bytes_per_launch_%s_%s" % (bench["dtype"], bench["roofline"]["kernel"].split("@ ")[1].split(" ")[0])
