@@ -98,3 +98,49 @@ def test_batch_entry_point(ofx_mod, orc, synth):
     ctxs[0].set_option("lockstep", 0)
     for c in ctxs:
         c.close()
+
+
+def test_group_size_reports_errors_and_honours_the_memory_budget(ofx_mod):
+    """ofx_tvl1_batch_group_size returns -status on error (not a positive status that reads as a group size),
+    and its memory cap uses the real footprint of a pair (26 elements per pixel and level): option mem_budget"""
+    L = ofx_mod.lib()
+    ctxs = [ofx_mod.Ofx(0, ofx_mod.F64) for _ in range(2)]
+    arr = (C.c_void_p * 2)(*[c.h.value for c in ctxs])
+    assert L.ofx_tvl1_batch_group_size(arr, 2, 8, 0, 48, 3, 0.5) == -1              # nx = 0 -> -OFX_ERR_ARG
+    assert L.ofx_tvl1_batch_group_size(arr, 2, 8, 64, 48, 8, 0.5) == -2             # pyramid too deep -> -OFX_ERR_SIGMA
+    assert L.ofx_tvl1_batch_group_size(None, 2, 8, 64, 48, 3, 0.5) == -1
+    with pytest.raises(ofx_mod.OfxError) as e:
+        ofx_mod.tvl1_batch_group_size(ctxs, 8, 64, 48, 8, 0.5)
+    assert e.value.status == -2
+    # the batch call maps the negative group size back to the status
+    import torch
+    t = torch.zeros((48, 64), dtype=torch.float64, device="cuda")
+    f = torch.zeros((48, 64, 2), dtype=torch.float32, device="cuda")
+    with pytest.raises(ofx_mod.OfxError) as e:
+        ofx_mod.tvl1_batch_dev(ctxs, [t.data_ptr()] * 4, [t.data_ptr()] * 4, [f.data_ptr()] * 4, 64, 48, nscales=8)
+    assert e.value.status == 2
+    # 1920x1080, 5 scales: one pair = 26 * 8 B * 2.76 Mpix = 575 MB of level arrays; a budget of 3 GB for 2 contexts
+    # leaves (1.5 GB - temporaries) / 575 MB = 2 pairs per group, 1.2 GB just one
+    size = lambda: ofx_mod.tvl1_batch_group_size(ctxs, 64, 1920, 1080, 5, 0.5)
+    assert size() == 16
+    for budget, want in ((3.0e9, 2), (1.2e9, 1), (40e9, 16)):
+        ctxs[0].set_option("mem_budget", budget)
+        assert size() == want, budget
+    ctxs[0].set_option("mem_budget", 0)
+    for c in ctxs:
+        c.close()
+
+
+def test_failed_context_creation_cleans_up(ofx_mod):
+    """a failing ofx_ctx_create must not leak; creating and destroying many contexts must not either"""
+    import torch
+    L = ofx_mod.lib()
+    h = C.c_void_p()
+    assert L.ofx_ctx_create(C.byref(h), 99, 0) == 5 and not h.value                 # no such device
+    assert L.ofx_ctx_create(C.byref(h), 0, 7) == 1 and not h.value                  # bad precision
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        c = ofx_mod.Ofx(0, ofx_mod.F64)
+        c.tvl1_multiscale(np.zeros((48, 64)), np.zeros((48, 64)), nscales=2)
+        c.close()
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20
