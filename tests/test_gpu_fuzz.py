@@ -129,3 +129,49 @@ def test_brox_temporal_random_configurations(gpu64, orc, synth, seed):
     ug, vg = gpu64.brox_temporal(I, **kw)
     assert np.array_equal(gpu64.stats().iterations(), it_r), (nx, ny, frames, kw)
     assert np.abs(ug - ur).max() < 1e-10 and np.abs(vg - vr).max() < 1e-10, (nx, ny, frames, kw)
+
+
+FUZZ_SOR_GROUPS = int(os.environ.get("OFX_FUZZ_SOR_GROUPS", "3"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_SOR_GROUPS))
+def test_sor_random_lockstep_groups(gpu64, orc, synth, seed):
+    """Horn-Schunck and Brox lockstep groups of random size / geometry on hyperplane-major arrays: every pair's sweep table
+    equals the oracle's (reference sweep order) and its .flo payload the oracle's flow cast to float32"""
+    import torch
+    rng = np.random.default_rng((900 if FUZZ_SEED == 2026 else 4000 * FUZZ_SEED) + seed)
+    nx, ny, G = int(rng.integers(20, 120)), int(rng.integers(16, 90)), int(rng.integers(2, 17))
+    ns = 2 if min(nx, ny) >= 40 else 1
+    pairs = [synth.pair("P0" if k % 4 == 3 else "P1", nx, ny, k) for k in range(G)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in pairs]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in pairs]
+    flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ptr = lambda ts: [t.data_ptr() for t in ts]
+    for name, val in (("sor_window", int(rng.choice([0, 3, 8]))), ("sor_rows", int(rng.choice([0, 9, 61]))),
+                      ("sor_batch", int(rng.choice([0, 7, 40])))):
+        gpu64.set_option(name, val)
+    try:
+        hk = dict(alpha=float(rng.choice([7.0, 20.0])), nscales=ns, zfactor=0.5, warps=int(rng.integers(1, 4)),
+                  TOL=float(rng.choice([1e-4, 1e-3])), maxiter=int(rng.choice([6, 150])))
+        st = gpu64.hs_group_dev(ptr(d0), ptr(d1), [flo[k].data_ptr() for k in range(G)], nx, ny, **hk)
+        gpu64.synchronize()
+        got = flo.cpu().numpy().copy()
+        for k in range(G):
+            uo, vo, it = orc.hs_pyramidal(pairs[k][0], pairs[k][1], **hk)
+            assert np.array_equal(st[k].iterations(), it), ("hs", k, G, nx, ny, hk)
+            assert np.abs(got[k][..., 0] - uo).max() < 1e-6 and np.array_equal(got[k], np.stack([uo, vo], axis=-1).astype(np.float32)), ("hs", k, G, nx, ny)
+        bk = dict(alpha=float(rng.choice([50.0, 18.0])), gamma=float(rng.choice([10.0, 0.0])), nscales=ns, nu=0.5, TOL=1e-4,
+                  inner=int(rng.integers(1, 3)), outer=int(rng.integers(1, 4)))
+        st = gpu64.brox_group_dev(ptr(d0), ptr(d1), [flo[k].data_ptr() for k in range(G)], nx, ny, **bk)
+        gpu64.synchronize()
+        got = flo.cpu().numpy().copy()
+        for k in range(G):
+            uo, vo, it = orc.brox_spatial(pairs[k][0], pairs[k][1], **bk)
+            assert np.array_equal(st[k].iterations(), it), ("brox", k, G, nx, ny, bk)
+            assert np.abs(got[k][..., 0] - uo).max() < 1e-6, ("brox", k, G, nx, ny)
+            # the flows agree to < 1e-11; their float32 casts can only differ where a value sits on a rounding boundary
+            assert np.mean(got[k] != np.stack([uo, vo], axis=-1).astype(np.float32)) < 1e-3, ("brox", k, G, nx, ny)
+    finally:
+        for name in ("sor_window", "sor_rows", "sor_batch"):
+            gpu64.set_option(name, 0)
