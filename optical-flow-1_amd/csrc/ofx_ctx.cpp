@@ -74,6 +74,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->sor_batch = 0;
     ctx->sor_window = 0;
     ctx->sor_rows = 0;
+    ctx->sor_spw = 0;
     ctx->mem_budget = 0;
     ctx->poll_seq = 0;
     ctx->errmsg[0] = 0;
@@ -164,6 +165,11 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "sor_rows")) {
         if (value < 0 || value > 4096) return ofx_fail(ctx, OFX_ERR_ARG, "sor_rows out of range");
         ctx->sor_rows = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "sor_spw")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return ofx_fail(ctx, OFX_ERR_ARG, "sor_spw must be 0, 1, 2 or 4");
+        ctx->sor_spw = (int) value;
         return OFX_OK;
     }
     if (!strcmp(name, "sor_window")) {

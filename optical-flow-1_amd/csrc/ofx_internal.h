@@ -66,6 +66,7 @@ struct ofx_ctx {
     int sor_batch;      // sweeps in flight per batch in exact mode (0 = default)
     int sor_window;     // time steps per launch of the windowed exact mode (0 = 8)
     int sor_rows;       // rows per block (workgroup) of a sweep in the windowed exact mode (0 = 64)
+    int sor_spw;        // sweeps per workgroup of the windowed exact kernels (0 = automatic: 1 alone, 2 in lockstep groups)
     double mem_budget;  // bytes all contexts of a batch may use for level arrays (0 = half of the free device memory)
     unsigned long long poll_seq;
 

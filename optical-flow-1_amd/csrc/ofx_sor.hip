@@ -141,35 +141,55 @@ static int op_skew(ofx_ctx *ctx, const V *src, V *dst, int nx, int ny, int c, in
 // up-left, up-right, bottom-left, bottom-right / up, left, bottom, right, with ONE quirk kept for
 // bit-exactness: the bottom-right corner lists its diagonal taps bottom pair first (:222-228).
 // Returns the squared update (:70).
+// operands of one update, loaded first so that several independent updates can have their loads in flight together
+struct HsOps {
+    double2 p1, p2, p3, p4, p5, p6, p7, p8, c, a;
+    double  dif;
+};
 template <typename T, class Acc>
-OFX_DEV double hs_point_acc(const Acc &acc, const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif, int i,
-                            int j, int nx, int ny, double alpha2)
+OFX_DEV HsOps hs_point_load(const Acc &acc, const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif, int i, int j,
+                            int nx, int ny)
 {
     const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
     const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
     const size_t p = acc.lay.idx(i, j);
-    double2 p1 = acc.get(iu, jl), p2 = acc.get(iu, jr);
-    double2 p3 = acc.get(id, jl), p4 = acc.get(id, jr);
+    HsOps o;
+    o.p1 = acc.get(iu, jl); o.p2 = acc.get(iu, jr);
+    o.p3 = acc.get(id, jl); o.p4 = acc.get(id, jr);
     if (i == ny - 1 && j == nx - 1) {
-        const double2 a1 = p1, a2 = p2;
-        p1 = p3; p2 = p4; p3 = a1; p4 = a2;
+        const double2 a1 = o.p1, a2 = o.p2;
+        o.p1 = o.p3; o.p2 = o.p4; o.p3 = a1; o.p4 = a2;
     }
-    const double2 p5 = acc.get(iu, j), p6 = acc.get(i, jl);
-    const double2 p7 = acc.get(id, j), p8 = acc.get(i, jr);
-    const double2 c = acc.get(i, j);
-    const double2 a = ldw2(A + p);
-    const double dif = ldw(Dif + p);
+    o.p5 = acc.get(iu, j); o.p6 = acc.get(i, jl);
+    o.p7 = acc.get(id, j); o.p8 = acc.get(i, jr);
+    o.c = acc.get(i, j);
+    o.a = ldw2(A + p);
+    o.dif = ldw(Dif + p);
+    return o;
+}
+template <typename T, class Acc>
+OFX_DEV double hs_point_finish(const Acc &acc, const HsOps &o, int i, int j, double alpha2)
+{
+    const double2 a = o.a;
+    const double dif = o.dif;
     const double w = HS_SOR_W;
     const double Au = dif * a.x, Av = dif * a.y;                              // :133-134
     const double Du = a.x * a.x + alpha2, Dv = a.y * a.y + alpha2;            // :135-136
     const double D = a.x * a.y;                                               // :137
-    const double ula = 1. / 12. * (p1.x + p2.x + p3.x + p4.x) + 1. / 6. * (p5.x + p6.x + p7.x + p8.x);
-    const double vla = 1. / 12. * (p1.y + p2.y + p3.y + p4.y) + 1. / 6. * (p5.y + p6.y + p7.y + p8.y);
-    const double uk = c.x, vk = c.y;
+    const double ula = 1. / 12. * (o.p1.x + o.p2.x + o.p3.x + o.p4.x) + 1. / 6. * (o.p5.x + o.p6.x + o.p7.x + o.p8.x);
+    const double vla = 1. / 12. * (o.p1.y + o.p2.y + o.p3.y + o.p4.y) + 1. / 6. * (o.p5.y + o.p6.y + o.p7.y + o.p8.y);
+    const double uk = o.c.x, vk = o.c.y;
     const double un = rnd_to<T>((1.0 - w) * uk + w * (Au - D * vk + alpha2 * ula) / Du);   // :66
     const double vn = rnd_to<T>((1.0 - w) * vk + w * (Av - D * un + alpha2 * vla) / Dv);   // :67
     acc.put(i, j, make_double2(un, vn));
     return (un - uk) * (un - uk) + (vn - vk) * (vn - vk);                     // :70
+}
+template <typename T, class Acc>
+OFX_DEV double hs_point_acc(const Acc &acc, const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif, int i,
+                            int j, int nx, int ny, double alpha2)
+{
+    const HsOps o = hs_point_load<T>(acc, A, Dif, i, j, nx, ny);
+    return hs_point_finish<T>(acc, o, i, j, alpha2);
 }
 
 template <typename T, bool COH = false, bool SNAP = false>
@@ -306,39 +326,74 @@ OFX_DEV int sor_border_block(int i, int ny, int R)
     return r / R;
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void k_hs_window(typename Pix<T>::v2 *Ug, typename Pix<T>::v2 *snap,
+// SPW consecutive sweeps of one row block share a workgroup: their updates are independent (lag_s steps apart), so their
+// loads are issued together and ONE store drain + barrier per step serves all of them -- the per-step latency, not
+// arithmetic or bandwidth, is what bounds a lockstep group (profiles/r02_f_sor_counters.txt).
+template <typename T, int SPW, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_hs_window(typename Pix<T>::v2 *Ug, typename Pix<T>::v2 *snap,
                                                     const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Difg,
-                                                    double *__restrict__ errg, SorWin w, SorGrp grp, int nx, int ny,
+                                                    double *__restrict__ errg, SorWin w, SorGrp grp, int s_cnt, int nx, int ny,
                                                     double alpha2)
 {
-    const int b = blockIdx.x, s = w.s_first + blockIdx.y, g = blockIdx.z;
+    const int b = blockIdx.x, s0 = w.s_first + blockIdx.y * SPW, g = blockIdx.z;
     if (!((grp.runmask >> g) & 1u)) return;                      // this pair's solve has already stopped
     const int qmax = 2 * ny + nx - 2;
-    const int q_first = w.tau0 - w.lag_s * s - w.lag_b * b;
-    if (q_first > qmax || q_first + w.K - 1 < 0) return;         // this (sweep, block) has no step in the window
+    int q_first[SPW];
+    bool live[SPW], any = false;
+#pragma unroll
+    for (int u = 0; u < SPW; u++) {
+        q_first[u] = w.tau0 - w.lag_s * (s0 + u) - w.lag_b * b;
+        live[u] = (s0 + u < w.s_first + s_cnt) && !(q_first[u] > qmax || q_first[u] + w.K - 1 < 0);
+        any = any || live[u];
+    }
+    if (!any) return;                                            // none of these (sweep, block) units has a step in the window
     typename Pix<T>::v2 *U = Ug + g * grp.npix;
     const typename Pix<T>::v2 *__restrict__ A = Ag + g * grp.npix;
     const T *__restrict__ Dif = Difg + g * grp.npix;
     double *__restrict__ err = errg + (size_t) g * grp.err_stride;
-    typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) s * grp.npix;
     const int r = sor_window_item(w, b, threadIdx.x, ny);
-    double e = 0.0;
-    for (int q = q_first; q < q_first + w.K; q++) {
-        if (q >= 0 && q <= qmax && r >= 0) {
-            int i, j;
-            if (r == ny + 2) {
+    double e[SPW];
+#pragma unroll
+    for (int u = 0; u < SPW; u++) e[u] = 0.0;
+    for (int k = 0; k < w.K; k++) {
+        bool have[SPW];
+        int pi[SPW], pj[SPW];
+        HsOps ops[SPW];
+#pragma unroll
+        for (int u = 0; u < SPW; u++) {                          // all loads of this step first ...
+            const int q = q_first[u] + k;
+            have[u] = live[u] && q >= 0 && q <= qmax && r >= 0 && r != ny + 2 && hs_plane_item(r, q, nx, ny, 0, pi[u], pj[u]) &&
+                      (r < ny || sor_border_block(pi[u], ny, w.R) == b);
+            if (SPW > 1 && have[u]) {
+                const UGlobal<T, OFX_SOR_COH != 0, true, LaySkew> acc = {U, snap + g * grp.snap_stride + (size_t) (s0 + u) * grp.npix,
+                                                                         LaySkew{ny, HS_PLANE_C_SKEW}};
+                ops[u] = hs_point_load<T>(acc, A, Dif, pi[u], pj[u], nx, ny);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SPW; u++) {                          // ... then the updates
+            typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) (s0 + u) * grp.npix;
+            if (have[u]) {
+                const UGlobal<T, OFX_SOR_COH != 0, true, LaySkew> acc = {U, mysnap, LaySkew{ny, HS_PLANE_C_SKEW}};
+                // one sweep per workgroup: load and update in one go (the compiler interleaves them in 66 VGPRs = 7 waves
+                // per SIMD; holding every operand first would take 106)
+                if (SPW > 1) e[u] += hs_point_finish<T>(acc, ops[u], pi[u], pj[u], alpha2);
+                else e[u] += hs_point_acc<T>(acc, A, Dif, pi[u], pj[u], nx, ny, alpha2);
+            }
+            const int q = q_first[u] + k;
+            if (live[u] && r == ny + 2 && q >= 0 && q <= qmax) {  // the corner item: up to four pixels, one after the other
+                int i, j;
                 for (int corner = 0; corner < 4; corner++)
                     if (hs_plane_item(r, q, nx, ny, corner, i, j) && sor_border_block(i, ny, w.R) == b)
-                        e += hs_point_skew<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
-            } else if (hs_plane_item(r, q, nx, ny, 0, i, j) && (r < ny || sor_border_block(i, ny, w.R) == b)) {
-                e += hs_point_skew<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
+                        e[u] += hs_point_skew<T, OFX_SOR_COH != 0, true>(U, A, Dif, i, j, nx, ny, alpha2, mysnap);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this step's stores have reached L2 ...
         __syncthreads();                                       // ... before any wave of the workgroup reads them
     }
-    loop_accumulate(err, s, e, b * 4 + (threadIdx.x >> 6));
+#pragma unroll
+    for (int u = 0; u < SPW; u++)
+        if (live[u]) loop_accumulate(err, s0 + u, e[u], b * 4 + (threadIdx.x >> 6));
 }
 
 // Batch driver of the windowed exact mode.  launch(w, blocks, sweeps) enqueues one window over `blocks` row
@@ -515,6 +570,13 @@ static int sor_pick_batch(const ofx_ctx *ctx, size_t npix, size_t elem_bytes, in
     if (b > maxiter) b = maxiter;
     return b < 1 ? 1 : b;
 }
+// sweeps per workgroup of the windowed kernels: option "sor_spw" (1, 2 or 4), else 1 for a lone solve (the chain of
+// dependent steps is what counts there) and 2 in a lockstep group (more work per store drain + barrier)
+static int sor_pick_spw(const ofx_ctx *ctx, int G)
+{
+    if (ctx->sor_spw == 1 || ctx->sor_spw == 2 || ctx->sor_spw == 4) return ctx->sor_spw;
+    return G >= 4 ? 2 : 1;
+}
 static int sor_window_threads(int n_items)
 {
     const int t = ofx_cdiv(n_items, 64) * 64;
@@ -614,8 +676,23 @@ static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L, const HsParams &P, i
             const size_t snap_stride = ps * L.snap_planes;
             auto window = [&](const SorWin &w, int blocks, int sweeps, unsigned runmask, int err_stride) -> int {
                 const SorGrp grp = {runmask, err_stride, ps, snap_stride};
-                hipLaunchKernelGGL(k_hs_window<T>, dim3(blocks, sweeps, G), dim3(sor_window_threads(w.R + 3)), 0, ctx->stream,
-                                   L.Us, L.Snap, L.As, (const T *) L.Difs, ctx->d_err, w, grp, nx, ny, alpha2);
+                const int spw = sor_pick_spw(ctx, G);
+                const dim3 grid(blocks, ofx_cdiv(sweeps, spw), G), blk(sor_window_threads(w.R + 3));
+                // workgroups of up to 128 threads (the default geometries) are compiled without the 128-VGPR cap that a
+                // 1024-thread bound implies: two sweeps per workgroup keep their operands in registers instead of spilling
+#define OFX_HS_WIN(SPW_, MAXT_)                                                                                          \
+    hipLaunchKernelGGL((k_hs_window<T, SPW_, MAXT_>), grid, blk, 0, ctx->stream, L.Us, L.Snap, L.As, (const T *) L.Difs, \
+                       ctx->d_err, w, grp, sweeps, nx, ny, alpha2)
+                if (blk.x <= 128) {
+                    if (spw == 4) OFX_HS_WIN(4, 128);
+                    else if (spw == 2) OFX_HS_WIN(2, 128);
+                    else OFX_HS_WIN(1, 128);
+                } else {
+                    if (spw == 4) OFX_HS_WIN(4, 1024);
+                    else if (spw == 2) OFX_HS_WIN(2, 1024);
+                    else OFX_HS_WIN(1, 1024);
+                }
+#undef OFX_HS_WIN
                 OFX_LAUNCH_CHECK(ctx);
                 return OFX_OK;
             };
@@ -1078,27 +1155,52 @@ __global__ void k_brox_coeff(const T *__restrict__ I1, const typename Pix<T>::v2
     stn(Dm + i, Duv);
 }
 
-// SOR update of one pixel, src/brox_optic_flow_spatial.cpp:129-172; returns the squared update (:166)
+// SOR update of one pixel, src/brox_optic_flow_spatial.cpp:129-172, in two halves (operands first, see HsOps);
+// returns the squared update (:166)
+struct BroxOps {
+    Psi4    s;
+    double2 c, dn, up, rt, lf;
+    double4 co;
+    double  D;
+};
 template <typename T, class Acc>
-OFX_DEV double brox_point_acc(const Acc &acc, const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
-                              const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha)
+OFX_DEV BroxOps brox_point_load(const Acc &acc, const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
+                                const T *__restrict__ Psis, int i, int j, int nx, int ny)
 {
     const size_t p = acc.lay.idx(i, j);
-    const Psi4 s = brox_psi4_lay(Psis, acc.lay, i, j, nx, ny);
+    BroxOps o;
+    o.s = brox_psi4_lay(Psis, acc.lay, i, j, nx, ny);
     // a missing neighbour is addressed as the pixel itself (offset 0) with psi = 0, :332-388
-    const double2 c = acc.get(i, j);
-    const double2 dn = (i < ny - 1) ? acc.get(i + 1, j) : c, up = (i > 0) ? acc.get(i - 1, j) : c;
-    const double2 rt = (j < nx - 1) ? acc.get(i, j + 1) : c, lf = (j > 0) ? acc.get(i, j - 1) : c;
-    const double4 co = ldw4(CO + p);
-    const double D = ldw(Dm + p);
+    o.c = acc.get(i, j);
+    o.dn = (i < ny - 1) ? acc.get(i + 1, j) : o.c;
+    o.up = (i > 0) ? acc.get(i - 1, j) : o.c;
+    o.rt = (j < nx - 1) ? acc.get(i, j + 1) : o.c;
+    o.lf = (j > 0) ? acc.get(i, j - 1) : o.c;
+    o.co = ldw4(CO + p);
+    o.D = ldw(Dm + p);
+    return o;
+}
+template <typename T, class Acc>
+OFX_DEV double brox_point_finish(const Acc &acc, const BroxOps &o, int i, int j, double alpha)
+{
+    const Psi4 s = o.s;
+    const double4 co = o.co;
+    const double D = o.D;
     const double w = BROX_SOR_W;
-    const double div_du = s.p1 * dn.x + s.p2 * up.x + s.p3 * rt.x + s.p4 * lf.x;      // :153-154
-    const double div_dv = s.p1 * dn.y + s.p2 * up.y + s.p3 * rt.y + s.p4 * lf.y;      // :155-156
-    const double duk = c.x, dvk = c.y;
+    const double div_du = s.p1 * o.dn.x + s.p2 * o.up.x + s.p3 * o.rt.x + s.p4 * o.lf.x;      // :153-154
+    const double div_dv = s.p1 * o.dn.y + s.p2 * o.up.y + s.p3 * o.rt.y + s.p4 * o.lf.y;      // :155-156
+    const double duk = o.c.x, dvk = o.c.y;
     const double dun = rnd_to<T>((1. - w) * duk + w * (co.x - D * dvk + alpha * div_du) / co.z);   // :162
     const double dvn = rnd_to<T>((1. - w) * dvk + w * (co.y - D * dun + alpha * div_dv) / co.w);   // :163
     acc.put(i, j, make_double2(dun, dvn));
     return (dun - duk) * (dun - duk) + (dvn - dvk) * (dvn - dvk);                     // :166
+}
+template <typename T, class Acc>
+OFX_DEV double brox_point_acc(const Acc &acc, const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
+                              const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha)
+{
+    const BroxOps o = brox_point_load<T>(acc, CO, Dm, Psis, i, j, nx, ny);
+    return brox_point_finish<T>(acc, o, i, j, alpha);
 }
 
 template <typename T, bool COH = false, bool SNAP = false>
@@ -1176,41 +1278,71 @@ __global__ __launch_bounds__(64) void k_brox_plane(typename Pix<T>::v2 *__restri
     loop_accumulate(err, s, e, blockIdx.x);
 }
 
-// windowed exact mode (see k_hs_window): K steps per launch, one workgroup per (sweep, row block)
-template <typename T>
-__global__ __launch_bounds__(1024) void k_brox_window(typename Pix<T>::v2 *DUg, typename Pix<T>::v2 *snap,
+// windowed exact mode (see k_hs_window): K steps per launch, one workgroup per (SPW sweeps, row block)
+template <typename T, int SPW, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_brox_window(typename Pix<T>::v2 *DUg, typename Pix<T>::v2 *snap,
                                                       const typename Pix<T>::v4 *__restrict__ COg, const T *__restrict__ Dmg,
                                                       const T *__restrict__ Psisg, double *__restrict__ errg, SorWin w,
-                                                      SorGrp grp, int nx, int ny, double alpha)
+                                                      SorGrp grp, int s_cnt, int nx, int ny, double alpha)
 {
-    const int b = blockIdx.x, s = w.s_first + blockIdx.y, g = blockIdx.z;
+    const int b = blockIdx.x, s0 = w.s_first + blockIdx.y * SPW, g = blockIdx.z;
     if (!((grp.runmask >> g) & 1u)) return;
     const int qmax = ny + nx - 2;
-    const int q_first = w.tau0 - w.lag_s * s - w.lag_b * b;
-    if (q_first > qmax || q_first + w.K - 1 < 0) return;
+    int q_first[SPW];
+    bool live[SPW], any = false;
+#pragma unroll
+    for (int u = 0; u < SPW; u++) {
+        q_first[u] = w.tau0 - w.lag_s * (s0 + u) - w.lag_b * b;
+        live[u] = (s0 + u < w.s_first + s_cnt) && !(q_first[u] > qmax || q_first[u] + w.K - 1 < 0);
+        any = any || live[u];
+    }
+    if (!any) return;
     typename Pix<T>::v2 *DU = DUg + g * grp.npix;
     const typename Pix<T>::v4 *__restrict__ CO = COg + g * grp.npix;
     const T *__restrict__ Dm = Dmg + g * grp.npix;
     const T *__restrict__ Psis = Psisg + g * grp.npix;
     double *__restrict__ err = errg + (size_t) g * grp.err_stride;
-    typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) s * grp.npix;
     const int r = sor_window_item(w, b, threadIdx.x, ny);
-    double e = 0.0;
-    for (int q = q_first; q < q_first + w.K; q++) {
-        if (q >= 0 && q <= qmax && r >= 0) {
-            int i, j;
-            if (r == ny + 2) {
+    double e[SPW];
+#pragma unroll
+    for (int u = 0; u < SPW; u++) e[u] = 0.0;
+    for (int k = 0; k < w.K; k++) {
+        bool have[SPW];
+        int pi[SPW], pj[SPW];
+        BroxOps ops[SPW];
+#pragma unroll
+        for (int u = 0; u < SPW; u++) {
+            const int q = q_first[u] + k;
+            have[u] = live[u] && q >= 0 && q <= qmax && r >= 0 && r != ny + 2 && brox_plane_item(r, q, nx, ny, 0, pi[u], pj[u]) &&
+                      (r < ny || sor_border_block(pi[u], ny, w.R) == b);
+            if (SPW > 1 && have[u]) {
+                const UGlobal<T, OFX_SOR_COH != 0, true, LaySkew> acc = {DU, snap + g * grp.snap_stride + (size_t) (s0 + u) * grp.npix,
+                                                                         LaySkew{ny, BROX_PLANE_C_SKEW}};
+                ops[u] = brox_point_load<T>(acc, CO, Dm, Psis, pi[u], pj[u], nx, ny);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SPW; u++) {
+            typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) (s0 + u) * grp.npix;
+            if (have[u]) {
+                const UGlobal<T, OFX_SOR_COH != 0, true, LaySkew> acc = {DU, mysnap, LaySkew{ny, BROX_PLANE_C_SKEW}};
+                if (SPW > 1) e[u] += brox_point_finish<T>(acc, ops[u], pi[u], pj[u], alpha);
+                else e[u] += brox_point_acc<T>(acc, CO, Dm, Psis, pi[u], pj[u], nx, ny, alpha);
+            }
+            const int q = q_first[u] + k;
+            if (live[u] && r == ny + 2 && q >= 0 && q <= qmax) {
+                int i, j;
                 for (int corner = 0; corner < 4; corner++)
                     if (brox_plane_item(r, q, nx, ny, corner, i, j) && sor_border_block(i, ny, w.R) == b)
-                        e += brox_point_skew<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
-            } else if (brox_plane_item(r, q, nx, ny, 0, i, j) && (r < ny || sor_border_block(i, ny, w.R) == b)) {
-                e += brox_point_skew<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
+                        e[u] += brox_point_skew<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    loop_accumulate(err, s, e, b * 4 + (threadIdx.x >> 6));
+#pragma unroll
+    for (int u = 0; u < SPW; u++)
+        if (live[u]) loop_accumulate(err, s0 + u, e[u], b * 4 + (threadIdx.x >> 6));
 }
 
 // u += du, v += dv, :398-401
@@ -1326,9 +1458,21 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
                 const size_t snap_stride = ps * L.snap_planes;
                 auto window = [&](const SorWin &w, int blocks, int sweeps, unsigned runmask, int err_stride) -> int {
                     const SorGrp grp = {runmask, err_stride, ps, snap_stride};
-                    hipLaunchKernelGGL(k_brox_window<T>, dim3(blocks, sweeps, G), dim3(sor_window_threads(w.R + 3)), 0,
-                                       ctx->stream, L.DUs, L.Snap, L.COs, (const T *) L.Dms, (const T *) L.Psiss, ctx->d_err, w,
-                                       grp, nx, ny, P.alpha);
+                    const int spw = sor_pick_spw(ctx, G);
+                    const dim3 grid(blocks, ofx_cdiv(sweeps, spw), G), blk(sor_window_threads(w.R + 3));
+#define OFX_BROX_WIN(SPW_, MAXT_)                                                                                        \
+    hipLaunchKernelGGL((k_brox_window<T, SPW_, MAXT_>), grid, blk, 0, ctx->stream, L.DUs, L.Snap, L.COs, (const T *) L.Dms, \
+                       (const T *) L.Psiss, ctx->d_err, w, grp, sweeps, nx, ny, P.alpha)
+                    if (blk.x <= 128) {
+                        if (spw == 4) OFX_BROX_WIN(4, 128);
+                        else if (spw == 2) OFX_BROX_WIN(2, 128);
+                        else OFX_BROX_WIN(1, 128);
+                    } else {
+                        if (spw == 4) OFX_BROX_WIN(4, 1024);
+                        else if (spw == 2) OFX_BROX_WIN(2, 1024);
+                        else OFX_BROX_WIN(1, 1024);
+                    }
+#undef OFX_BROX_WIN
                     OFX_LAUNCH_CHECK(ctx);
                     return OFX_OK;
                 };

@@ -149,7 +149,7 @@ def test_sor_random_lockstep_groups(gpu64, orc, synth, seed):
     torch.cuda.synchronize()
     ptr = lambda ts: [t.data_ptr() for t in ts]
     for name, val in (("sor_window", int(rng.choice([0, 3, 8]))), ("sor_rows", int(rng.choice([0, 9, 61]))),
-                      ("sor_batch", int(rng.choice([0, 7, 40])))):
+                      ("sor_batch", int(rng.choice([0, 7, 40]))), ("sor_spw", int(rng.choice([0, 1, 2, 4])))):
         gpu64.set_option(name, val)
     try:
         hk = dict(alpha=float(rng.choice([7.0, 20.0])), nscales=ns, zfactor=0.5, warps=int(rng.integers(1, 4)),
@@ -173,5 +173,5 @@ def test_sor_random_lockstep_groups(gpu64, orc, synth, seed):
             # the flows agree to < 1e-11; their float32 casts can only differ where a value sits on a rounding boundary
             assert np.mean(got[k] != np.stack([uo, vo], axis=-1).astype(np.float32)) < 1e-3, ("brox", k, G, nx, ny)
     finally:
-        for name in ("sor_window", "sor_rows", "sor_batch"):
+        for name in ("sor_window", "sor_rows", "sor_batch", "sor_spw"):
             gpu64.set_option(name, 0)

@@ -365,20 +365,37 @@ def test_sor_groups_with_small_batches_and_windows(gpu64, synth):
     kw = dict(alpha=10.0, nscales=2, zfactor=0.5, warps=3, TOL=1e-5, maxiter=90)
     pairs, d0, d1, flo = _group_inputs(synth, G, nx, ny)
     want = [gpu64.hs_pyramidal(p[0], p[1], **kw) + (gpu64.stats().iterations().copy(),) for p in pairs]
-    for batch, window, rows in ((5, 3, 16), (9, 8, 64), (300, 5, 7)):
-        for name, val in (("sor_batch", batch), ("sor_window", window), ("sor_rows", rows)):
+    for batch, window, rows, spw in ((5, 3, 16, 1), (9, 8, 64, 2), (300, 5, 7, 4), (7, 8, 125, 2), (64, 4, 200, 4)):
+        for name, val in (("sor_batch", batch), ("sor_window", window), ("sor_rows", rows), ("sor_spw", spw)):
             gpu64.set_option(name, val)
         try:
             st = gpu64.hs_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1],
                                     [flo[k].data_ptr() for k in range(G)], nx, ny, **kw)
             gpu64.synchronize()
         finally:
-            for name in ("sor_batch", "sor_window", "sor_rows"):
+            for name in ("sor_batch", "sor_window", "sor_rows", "sor_spw"):
                 gpu64.set_option(name, 0)
         got = flo.cpu().numpy()
         for k in range(G):
             assert np.array_equal(st[k].iterations(), want[k][2]), (batch, k)
             assert np.array_equal(got[k], np.stack(want[k][:2], axis=-1).astype(np.float32)), (batch, k)
+    # the same for Brox (several sweeps per workgroup, odd geometries)
+    bk = dict(alpha=50.0, gamma=10.0, nscales=2, nu=0.5, TOL=1e-4, inner=1, outer=3)
+    wantb = [gpu64.brox_spatial(p[0], p[1], **bk) + (gpu64.stats().iterations().copy(),) for p in pairs]
+    for batch, window, rows, spw in ((6, 3, 16, 2), (300, 4, 125, 4), (9, 8, 61, 1)):
+        for name, val in (("sor_batch", batch), ("sor_window", window), ("sor_rows", rows), ("sor_spw", spw)):
+            gpu64.set_option(name, val)
+        try:
+            st = gpu64.brox_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1],
+                                      [flo[k].data_ptr() for k in range(G)], nx, ny, **bk)
+            gpu64.synchronize()
+        finally:
+            for name in ("sor_batch", "sor_window", "sor_rows", "sor_spw"):
+                gpu64.set_option(name, 0)
+        got = flo.cpu().numpy()
+        for k in range(G):
+            assert np.array_equal(st[k].iterations(), wantb[k][2]), (batch, k)
+            assert np.array_equal(got[k], np.stack(wantb[k][:2], axis=-1).astype(np.float32)), (batch, k)
 
 
 def test_sor_batch_entry_points(ofx_mod, synth):

@@ -11,6 +11,7 @@ cnt = collections.OrderedDict()
 name = None
 meta_name = None
 vg = {}
+scr = {}
 for ln in open(sys.argv[1]):
     m = re.match(r'^(_Z\w+):', ln)
     if m:
@@ -23,6 +24,9 @@ for ln in open(sys.argv[1]):
     m = re.match(r'^\s+\.vgpr_count:\s+(\d+)', ln)
     if m and meta_name:
         vg[meta_name] = int(m.group(1))
+    m = re.match(r'^\s+\.private_segment_fixed_size:\s+(\d+)', ln)
+    if m and meta_name:
+        scr[meta_name] = int(m.group(1))
     m = re.match(r'^\s+([a-z_0-9]+)\s', ln)
     if not m or name is None:
         continue
@@ -42,7 +46,7 @@ for ln in open(sys.argv[1]):
 for n, c in cnt.items():
     if not c['total']:
         continue
-    print("%-64s vgpr %3s total %5d valu %5d f64 %5d trans %3d div_aux %3d loads %3d stores %3d lds %3d" % (
-        n[:64], vg.get(n, '?'), c['total'], c['valu'], c['f64'], c['trans'], c['div_aux'], c['loads'], c['stores'], c['lds']))
+    print("%-64s vgpr %3s scratch %4s total %5d valu %5d f64 %5d trans %3d div_aux %3d loads %3d stores %3d lds %3d" % (
+        n[:64], vg.get(n, '?'), scr.get(n, '?'), c['total'], c['valu'], c['f64'], c['trans'], c['div_aux'], c['loads'], c['stores'], c['lds']))
 PY
 rm -f /tmp/isa_$$.s

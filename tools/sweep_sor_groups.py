@@ -18,14 +18,16 @@ for name, (nx, ny), fn, kw in CONFIGS:
     ctx = ofx.Ofx(0, ofx.F64)
     ctx.set_option("lockstep", G)
     args = ([t[0].data_ptr() for t in ins], [t[1].data_ptr() for t in ins], [flo[k].data_ptr() for k in range(G)], nx, ny)
-    for rows in (61, 64, 125, 29):
-        for window in (4, 8, 16):
+    for rows, window, spw in [(r_, w_, 1) for r_ in (61, 64, 125, 29) for w_ in (4, 8, 16)] if "--geometry" in sys.argv else \
+            [(125, w_, p_) for p_ in (1, 2, 4) for w_ in (4, 8)] + [(61, 8, 2), (253, 8, 1), (253, 8, 2)]:
+        if True:
             ctx.set_option("sor_rows", rows)
             ctx.set_option("sor_window", window)
+            ctx.set_option("sor_spw", spw)
             fn([ctx], *args, **kw)
             t0 = time.perf_counter()
             work = fn([ctx], *args, **kw)
             dt = time.perf_counter() - t0
-            print(json.dumps({"config": name, "group": G, "sor_rows": rows, "sor_window": window, "seconds": round(dt, 3),
+            print(json.dumps({"config": name, "group": G, "sor_rows": rows, "sor_window": window, "sor_spw": spw, "seconds": round(dt, 3),
                               "mpix_sweeps_per_s": round(sum(work) / dt / 1e6, 1)}), flush=True)
     ctx.close()
