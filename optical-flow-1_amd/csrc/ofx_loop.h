@@ -78,8 +78,24 @@ static inline int ofx_loop_finalize(ofx_ctx *ctx, const LoopSpec &L, int start, 
 // state (L.afac, or bit g of amask0 for a loop that stopped in its very first launch) need no redo: took_alt[g] = 1
 // tells the caller to continue from that stored state.  Returns the reference's n and error per problem.
 template <class LaunchFn, class RedoFn>
+static int ofx_run_loop_group_impl(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn launch, RedoFn redo, int *n_out,
+                                   double *err_out, float *ms_out, unsigned amask0, int *took_alt);
+
+// An error return must not leave launches or a poll of this loop in flight: the next API call resets the arena these
+// kernels work in.  (Stream order already protects the next call's own kernels; the drain makes it hold for anything
+// else the caller does with the context.)
+template <class LaunchFn, class RedoFn>
 static int ofx_run_loop_group(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn launch, RedoFn redo, int *n_out,
                               double *err_out, float *ms_out, unsigned amask0 = 0, int *took_alt = nullptr)
+{
+    const int s = ofx_run_loop_group_impl(ctx, L, G, launch, redo, n_out, err_out, ms_out, amask0, took_alt);
+    if (s != OFX_OK) (void) hipStreamSynchronize(ctx->stream);
+    return s;
+}
+
+template <class LaunchFn, class RedoFn>
+static int ofx_run_loop_group_impl(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn launch, RedoFn redo, int *n_out,
+                                   double *err_out, float *ms_out, unsigned amask0, int *took_alt)
 {
     if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "loop group of %d problems", G);
     const int per = L.max_iter + 1;                      // +1: scratch slot for the redo's error
@@ -132,10 +148,7 @@ static int ofx_run_loop_group(ofx_ctx *ctx, const LoopSpec &L, int G, LaunchFn l
             break;
         }
     }
-    if (!stop) {
-        (void) hipStreamSynchronize(ctx->stream);       // nothing of this loop may still be in flight when the arena is reused
-        return ofx_fail(ctx, OFX_ERR_HIP, "iteration loop ended without a final state");
-    }
+    if (!stop) return ofx_fail(ctx, OFX_ERR_HIP, "iteration loop ended without a final state");
     int redo_k[OFX_MAX_GROUP];
     bool any_redo = false;
     for (int g = 0; g < G; g++) {
