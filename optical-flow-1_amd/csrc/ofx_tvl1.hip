@@ -104,6 +104,28 @@ OFX_DEV double2 tvl1_primal(double2 u, double2 a, double r, double2 p1, double2 
     return make_double2(rnd_to<T>(v1 + theta * div1), rnd_to<T>(v2 + theta * div2));
 }
 
+#ifdef OFX_DIV_SHARED
+// 1 / d refined exactly as the compiler refines it inside an f64 division (v_rcp_f64 + two Newton steps in FMA)
+OFX_DEV double rcp_refined(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+// n / d from the refined reciprocal: quotient estimate, remainder, correction (v_div_fmas without scaling = this FMA),
+// v_div_fixup for zeros / infinities / NaNs and the sign
+OFX_DEV double div_by_rcp(double n, double d, double r)
+{
+    double q = n * r;
+    const double rem = __builtin_fma(-d, q, n);
+    q = __builtin_fma(rem, r, q);
+    return __builtin_amdgcn_div_fixup(q, d, n);
+}
+#endif
+
 // Stage "dual" at one pixel: forward gradient of the NEW u (src/operators.cpp:86-125) and the dual
 // update (src/tvl1flow.cpp:169-181).  un = new u here, r1/r2 = new u1/u2 of the right pixel, dn = new u
 // of the pixel below.
@@ -130,10 +152,37 @@ OFX_DEV void tvl1_dual(double2 p1, double2 p2, double2 un, double r1, double r2,
         const double g2 = hypot_ref(u2x, u2y);
         const double ng1 = 1.0 + taut * g1;
         const double ng2 = 1.0 + taut * g2;
+#ifdef OFX_DIV_SHARED
+        // EXPERIMENT (tools/ab_div_shared.sh; measured and NOT enabled): the four IEEE quotients with the
+        // reciprocal refinement shared per denominator.  The sequence is the compiler's own f64 division with its
+        // v_div_scale steps removed, which are the identity unless a numerator is tiny / huge or the denominator huge:
+        // a wave-uniform guard on the results sends every other case (and nothing else) to the compiler's division.
+        const double n1x = p1.x + taut * u1x, n1y = p1.y + taut * u1y, n2x = p2.x + taut * u2x, n2y = p2.y + taut * u2y;
+        const double r1 = rcp_refined(ng1), r2 = rcp_refined(ng2);
+        q1.x = div_by_rcp(n1x, ng1, r1);
+        q1.y = div_by_rcp(n1y, ng1, r1);
+        q2.x = div_by_rcp(n2x, ng2, r2);
+        q2.y = div_by_rcp(n2y, ng2, r2);
+        const double lo = fmin(fmin(fabs(q1.x), fabs(q1.y)), fmin(fabs(q2.x), fabs(q2.y)));
+        const double hi = fmax(fmax(fabs(q1.x), fabs(q1.y)), fmax(fabs(q2.x), fabs(q2.y)));
+        bool ok = lo >= 0x1p-900 && hi <= 0x1p600 && fmax(ng1, ng2) <= 0x1p50;
+        if (!__all(ok)) {                                   // rare: a zero numerator (exact with v_div_fixup), or a real outlier
+            ok = fmax(ng1, ng2) <= 0x1p50 && hi <= 0x1p600 && (n1x == 0.0 || fabs(q1.x) >= 0x1p-900) &&
+                 (n1y == 0.0 || fabs(q1.y) >= 0x1p-900) && (n2x == 0.0 || fabs(q2.x) >= 0x1p-900) &&
+                 (n2y == 0.0 || fabs(q2.y) >= 0x1p-900);
+            if (!__all(ok)) {
+                q1.x = n1x / ng1;
+                q1.y = n1y / ng1;
+                q2.x = n2x / ng2;
+                q2.y = n2y / ng2;
+            }
+        }
+#else
         q1.x = (p1.x + taut * u1x) / ng1;
         q1.y = (p1.y + taut * u1y) / ng1;
         q2.x = (p2.x + taut * u2x) / ng2;
         q2.y = (p2.y + taut * u2y) / ng2;
+#endif
     } else {
         const double g1 = sqrt(u1x * u1x + u1y * u1y);
         const double g2 = sqrt(u2x * u2x + u2y * u2y);
