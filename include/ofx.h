@@ -98,8 +98,8 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *   "sor_window"     time steps per launch of sor_exact = 1 (default 8; 4 for Brox in lockstep groups of >= 4 pairs)
  *   "sor_rows"       rows per workgroup (row block of a sweep) of sor_exact = 1 (default 64; 125 in lockstep groups
  *                         of >= 4 pairs)
- *   "sor_spw"        consecutive sweeps of a row block that share a workgroup in sor_exact = 1 (1, 2 or 4; default 0 =
- *                         1 for a lone solve, 2 in lockstep groups of >= 4 pairs)
+ *   "sor_spw"        consecutive sweeps of a row block that share a workgroup in sor_exact = 1 (1, 2 or 4; default 0 = 1,
+ *                         the fastest measured; results do not depend on it)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
  *   "store_a"        TV-L1, fused pairs: a loop that stops on the first iteration of a pair needs the state between the
  *                         two iterations; 1 (default) = a launch also stores it when the previous error is within 1.5x

@@ -570,12 +570,16 @@ static int sor_pick_batch(const ofx_ctx *ctx, size_t npix, size_t elem_bytes, in
     if (b > maxiter) b = maxiter;
     return b < 1 ? 1 : b;
 }
-// sweeps per workgroup of the windowed kernels: option "sor_spw" (1, 2 or 4), else 1 for a lone solve (the chain of
-// dependent steps is what counts there) and 2 in a lockstep group (more work per store drain + barrier)
+// sweeps per workgroup of the windowed kernels: option "sor_spw" (1, 2 or 4), default 1.  Measured with 16 pairs in
+// lockstep (profiles/r02_i_sor_sweeps_per_workgroup.jsonl): 2 / 4 sweeps per workgroup -- their loads issued together,
+// one store drain + barrier per step for all of them -- run at 0.66x / 0.47x the throughput of 1 (HS 23.9k -> 15.7k ->
+// 11.2k Mpix*sweeps/s): the operands of two updates take 151 VGPRs = 3 waves per SIMD instead of 8 at 64, and the
+// per-step latency is hidden by resident waves, not by instruction-level parallelism inside one.
 static int sor_pick_spw(const ofx_ctx *ctx, int G)
 {
+    (void) G;
     if (ctx->sor_spw == 1 || ctx->sor_spw == 2 || ctx->sor_spw == 4) return ctx->sor_spw;
-    return G >= 4 ? 2 : 1;
+    return 1;
 }
 static int sor_window_threads(int n_items)
 {
@@ -683,11 +687,10 @@ static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L, const HsParams &P, i
 #define OFX_HS_WIN(SPW_, MAXT_)                                                                                          \
     hipLaunchKernelGGL((k_hs_window<T, SPW_, MAXT_>), grid, blk, 0, ctx->stream, L.Us, L.Snap, L.As, (const T *) L.Difs, \
                        ctx->d_err, w, grp, sweeps, nx, ny, alpha2)
-                if (blk.x <= 128) {
+                if (blk.x <= 128 && spw > 1) {
                     if (spw == 4) OFX_HS_WIN(4, 128);
-                    else if (spw == 2) OFX_HS_WIN(2, 128);
-                    else OFX_HS_WIN(1, 128);
-                } else {
+                    else OFX_HS_WIN(2, 128);
+                } else {                                         // one sweep per workgroup: the 64-VGPR build, 8 waves per SIMD
                     if (spw == 4) OFX_HS_WIN(4, 1024);
                     else if (spw == 2) OFX_HS_WIN(2, 1024);
                     else OFX_HS_WIN(1, 1024);
@@ -1463,10 +1466,9 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
 #define OFX_BROX_WIN(SPW_, MAXT_)                                                                                        \
     hipLaunchKernelGGL((k_brox_window<T, SPW_, MAXT_>), grid, blk, 0, ctx->stream, L.DUs, L.Snap, L.COs, (const T *) L.Dms, \
                        (const T *) L.Psiss, ctx->d_err, w, grp, sweeps, nx, ny, P.alpha)
-                    if (blk.x <= 128) {
+                    if (blk.x <= 128 && spw > 1) {
                         if (spw == 4) OFX_BROX_WIN(4, 128);
-                        else if (spw == 2) OFX_BROX_WIN(2, 128);
-                        else OFX_BROX_WIN(1, 128);
+                        else OFX_BROX_WIN(2, 128);
                     } else {
                         if (spw == 4) OFX_BROX_WIN(4, 1024);
                         else if (spw == 2) OFX_BROX_WIN(2, 1024);
