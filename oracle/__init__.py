@@ -203,6 +203,14 @@ class _Lib:
         self._fn("median_filtering", None, _dp, C.c_int, C.c_int, C.c_int)(out, nx, ny, wsize)
         return out
 
+    def rof_box(self, u, f, P1, P2, g, lam, omega, n_iter):
+        """Scalar_ROF_BoxCellCentered -> (u, P1, P2)"""
+        ny, nx = u.shape
+        u, P1, P2 = _f64(u).copy(), _f64(P1).copy(), _f64(P2).copy()
+        self._fn("rof_box", None, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int)(
+            u, _f64(f), P1, P2, _f64(g), lam, omega, nx, ny, n_iter)
+        return u, P1, P2
+
     def occ_solver_v(self, u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, grad1, grad3, alpha, theta, lam):
         """Solver_wrt_v -> (v1, v2, Vfwd_1, Vfwd_2, Vbck_1, Vbck_2)"""
         ny, nx = u1.shape
@@ -218,6 +226,15 @@ class Oracle(_Lib):
     """Our C restatement (oracle/ofx_oracle.c)."""
     prefix = "orc_"
     kind = "port"
+
+    def occ_solver_u(self, v1, v2, chi, g, theta, beta, p=None, n_iter=10):
+        """Solver_wrt_u with the four dual planes as explicit state -> (u1, u2, [p11, p12, p21, p22]); p defaults to zero"""
+        ny, nx = v1.shape
+        u1, u2 = np.empty((ny, nx)), np.empty((ny, nx))
+        p = [np.zeros((ny, nx)) for _ in range(4)] if p is None else [_f64(a).copy() for a in p]
+        self._fn("occ_solver_u", None, *([_dp] * 6), C.c_double, C.c_double, C.c_int, C.c_int, *([_dp] * 4), C.c_int)(
+            u1, u2, _f64(v1), _f64(v2), _f64(chi), _f64(g), theta, beta, nx, ny, *p, n_iter)
+        return u1, u2, p
 
     def occ_solver_chi(self, u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, Vf1, Vf2, Vb1, Vb2, g, lam, theta, alpha,
                        beta, tau_chi, tau_eta, eta1=None, eta2=None, n_iter=100):
@@ -333,6 +350,15 @@ class Ref(_Lib):
     """The compiled reference itself (oracle/_ref/libofref.so via oracle/ref_shim.cpp)."""
     prefix = "ref_"
     kind = "reference"
+
+    def occ_solver_u(self, v1, v2, chi, g, theta, beta, fresh=True):
+        """One call of the reference's Solver_wrt_u -> (u1, u2).  fresh: zero dual planes (oracle/ref_shim.cpp); otherwise
+        the ones the previous call left in the function's statics."""
+        ny, nx = v1.shape
+        u1, u2 = np.empty((ny, nx)), np.empty((ny, nx))
+        self._fn("occ_solver_u", None, *([_dp] * 6), C.c_double, C.c_double, C.c_int, C.c_int, C.c_int)(
+            u1, u2, _f64(v1), _f64(v2), _f64(chi), _f64(g), theta, beta, nx, ny, int(fresh))
+        return u1, u2
 
     def occ_solver_chi(self, u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, Vf1, Vf2, Vb1, Vb2, g, lam, theta, alpha,
                        beta, tau_chi, tau_eta, fresh=True):

@@ -1740,3 +1740,148 @@ void orc_occ_solver_chi(const double *u1, const double *u2, double *chi, const d
     }
     free(chix); free(chiy); free(geta1); free(geta2); free(div_eta); free(div_u);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/tvl1occflow_tv_rof_box.cpp:22-645 Scalar_ROF_BoxCellCentered: nIter times { alfa = |grad u| / (lambda g) per cell;
+ * one in-place box relaxation sweep over the cells in lexicographic order; u = lambda f + lambda div P }.
+ * Staggered (2 ny + 1) x (2 nx + 1) grid as in the reference: cell (ci, cj) has its centre at (2 ci + 1, 2 cj + 1), its
+ * dual values on the four edges around it; P of the south / east edge of a cell is the in/out state initialP1 / initialP2,
+ * the edges on the image border stay as initialised.  Nine cell kinds (corners, sides, inner), each with the
+ * reference's own closed-form solve of its 2x2 / 3x3 / 4x4 system -- the expressions below keep its association order
+ * (note: only the north side writes the free terms with the F term first).  nx, ny >= 2. */
+#define SG(i, j) ((size_t) (i) * nxs + (j))
+void orc_rof_box(double *u, const double *f, double *P1, double *P2, const double *g, double lambda, double omega, int nx,
+                 int ny, int n_iter)
+{
+    const int nxs = 2 * nx + 1, nys = 2 * ny + 1;
+    const size_t ns = (size_t) nxs * nys;
+    double *P = dalloc(ns), *F = dalloc(ns), *AL = dalloc(ns);
+    double *ux = dalloc((size_t) nx * ny), *uy = dalloc((size_t) nx * ny);
+    for (size_t k = 0; k < ns; k++) P[k] = F[k] = AL[k] = 0.0;
+    for (int ci = 0, q = 0; ci < ny; ci++)                                               /* :123-135 */
+        for (int cj = 0; cj < nx; cj++, q++) {
+            const int i = 2 * ci + 1, j = 2 * cj + 1;
+            F[SG(i, j)] = f[q];
+            P[SG(i + 1, j)] = P1[q];
+            P[SG(i, j + 1)] = P2[q];
+        }
+    for (int i = 2; i <= nys - 3; i += 2)                                                /* :142-150 */
+        for (int j = 1; j <= nxs - 2; j += 2) F[SG(i, j)] = F[SG(i + 1, j)] - F[SG(i - 1, j)];
+    for (int i = 1; i <= nys - 2; i += 2)                                                /* :156-164 */
+        for (int j = 2; j <= nxs - 3; j += 2) F[SG(i, j)] = F[SG(i, j + 1)] - F[SG(i, j - 1)];
+    const double w = omega;
+    for (int iter = 1; iter <= n_iter; iter++) {
+        orc_forward_gradient(u, ux, uy, nx, ny);                                         /* :173 */
+        for (int ci = 0, q = 0; ci < ny; ci++)
+            for (int cj = 0; cj < nx; cj++, q++) {
+                const int i = 2 * ci + 1, j = 2 * cj + 1;
+                AL[SG(i + 1, j)] = sqrt(ux[q] * ux[q] + uy[q] * uy[q]) / (lambda * g[q]);    /* file-local hypot, :15-20,180 */
+                AL[SG(i, j + 1)] = AL[SG(i + 1, j)];
+            }
+        for (int ci = 0; ci < ny; ci++)
+            for (int cj = 0; cj < nx; cj++) {
+                const int i = 2 * ci + 1, j = 2 * cj + 1;
+                const int top = ci == 0, bot = ci == ny - 1, lef = cj == 0, rig = cj == nx - 1;
+                const size_t jm1 = SG(i, j - 1), jp1 = SG(i, j + 1), im1 = SG(i - 1, j), ip1 = SG(i + 1, j);
+                /* free terms; an operand that does not exist for this cell kind is never used below */
+                double W = 0, N = 0, S = 0, E = 0;
+                const int nside = top && !lef && !rig;
+                if (!lef) W = nside ? -F[jm1] - P[SG(i, j - 3)] + P[SG(i + 1, j - 2)] - P[SG(i - 1, j - 2)]
+                                    : -P[SG(i, j - 3)] + P[SG(i + 1, j - 2)] - P[SG(i - 1, j - 2)] - F[jm1];
+                if (!top) N = -P[SG(i - 3, j)] + P[SG(i - 2, j + 1)] - P[SG(i - 2, j - 1)] - F[im1];
+                if (!bot) S = nside ? -F[ip1] - P[SG(i + 3, j)] - P[SG(i + 2, j + 1)] + P[SG(i + 2, j - 1)]
+                                    : -P[SG(i + 3, j)] - P[SG(i + 2, j + 1)] + P[SG(i + 2, j - 1)] - F[ip1];
+                if (!rig) E = nside ? -F[jp1] - P[SG(i, j + 3)] - P[SG(i + 1, j + 2)] + P[SG(i - 1, j + 2)]
+                                    : -P[SG(i, j + 3)] - P[SG(i + 1, j + 2)] + P[SG(i - 1, j + 2)] - F[jp1];
+                const double b0 = lef ? 0.0 : -2 - AL[jm1], b1 = top ? 0.0 : -2 - AL[im1];
+                const double b2 = bot ? 0.0 : -2 - AL[ip1], b3 = rig ? 0.0 : -2 - AL[jp1];
+                double den;
+                if (top && lef) {                                                        /* :189-218 */
+                    den = b2 * b3 - 1;
+                    const double ns_ = (1 - w) * P[ip1] + w * (S * b3 + E) / den;
+                    const double ne_ = (1 - w) * P[jp1] + w * (E * b2 + S) / den;
+                    P[ip1] = ns_; P[jp1] = ne_;
+                } else if (top && rig) {                                                 /* :265-297 */
+                    den = b0 * b2 - 1;
+                    const double nw_ = (1 - w) * P[jm1] + w * (W * b2 - S) / den;
+                    const double ns_ = (1 - w) * P[ip1] + w * (S * b0 - W) / den;
+                    P[jm1] = nw_; P[ip1] = ns_;
+                } else if (top) {                                                        /* :220-263 */
+                    den = b0 * b2 * b3 - b0 - b2 - b3 - 2;
+                    const double nw_ = (1 - w) * P[jm1] + w * (W * b2 * b3 - E * b2 - S * b3 - W - E - S) / den;
+                    const double ns_ = (1 - w) * P[ip1] + w * (S * b0 * b3 - W * b3 + E * b0 - W + E - S) / den;
+                    const double ne_ = (1 - w) * P[jp1] + w * (E * b0 * b2 - W * b2 + S * b0 - W - E + S) / den;
+                    P[jm1] = nw_; P[ip1] = ns_; P[jp1] = ne_;
+                } else if (bot && lef) {                                                 /* :518-541 */
+                    den = b3 * b1 - 1;
+                    const double nn_ = (1 - w) * P[im1] + w * (b3 * N - E) / den;
+                    const double ne_ = (1 - w) * P[jp1] + w * (b1 * E - N) / den;
+                    P[im1] = nn_; P[jp1] = ne_;
+                } else if (bot && rig) {                                                 /* :589-613 */
+                    den = b0 * b1 - 1;
+                    const double nw_ = (1 - w) * P[jm1] + w * (W * b1 + N) / den;
+                    const double nn_ = (1 - w) * P[im1] + w * (N * b0 + W) / den;
+                    P[jm1] = nw_; P[im1] = nn_;
+                } else if (bot) {                                                        /* :543-587 */
+                    den = b0 * b1 * b3 - b0 - b1 - b3 - 2;
+                    const double nw_ = (1 - w) * P[jm1] + w * (W * b1 * b3 - E + N - E * b1 - W + N * b3) / den;
+                    const double nn_ = (1 - w) * P[im1] + w * (N * b0 * b3 + W - E - N - E * b0 + W * b3) / den;
+                    const double ne_ = (1 - w) * P[jp1] + w * (E * b0 * b1 - N - W - W * b1 - N * b0 - E) / den;
+                    P[jm1] = nw_; P[im1] = nn_; P[jp1] = ne_;
+                } else if (lef) {                                                        /* :301-361 */
+                    den = b1 * b2 * b3 - (b1 + b2 + b3) - 2;
+                    const double nn_ = (1 - w) * P[im1] + w * (b2 * b3 * N - E * b2 - S * b3 - N - S - E) / den;
+                    const double ns_ = (1 - w) * P[ip1] + w * (b1 * b3 * S + E * b1 - N * b3 - N - S + E) / den;
+                    const double ne_ = (1 - w) * P[jp1] + w * (b1 * b2 * E - N * b2 + S * b1 - N + S - E) / den;
+                    P[im1] = nn_; P[ip1] = ns_; P[jp1] = ne_;
+                } else if (rig) {                                                        /* :468-514 */
+                    den = (b0 * b1 * b2) + (-b0 - b1 - b2 - 2);
+                    const double nw_ = (1 - w) * P[jm1] + w * (W * b1 * b2 - S + N - S * b1 - W + N * b2) / den;
+                    const double nn_ = (1 - w) * P[im1] + w * (N * b0 * b2 + W - S - N - S * b0 + W * b2) / den;
+                    const double ns_ = (1 - w) * P[ip1] + w * (S * b0 * b1 - N - W - W * b1 - N * b0 - S) / den;
+                    P[jm1] = nw_; P[im1] = nn_; P[ip1] = ns_;
+                } else {                                                                 /* inner cell, Gauss elimination :440-463 */
+                    const double a = 1 / b0;
+                    const double b = -(b0 + 1) / (b0 * b1 - 1);
+                    const double alf = 1 + a;
+                    const double gam = -a + b * alf;
+                    const double x = N + a * W;
+                    const double y = -a * W + b * x;
+                    const double c = (1 - gam) / (b2 + gam);
+                    P[jp1] = (1 - w) * P[jp1] + w * (E + y + c * (S + y)) / (b3 + gam + c * (gam - 1));
+                    P[ip1] = (1 - w) * P[ip1] + w * (S + y + P[jp1] * (1 - gam)) / (b2 + gam);
+                    P[im1] = (1 - w) * P[im1] + w * (x - alf * (P[jp1] + P[ip1])) / (b1 - a);
+                    P[jm1] = (1 - w) * P[jm1] + w * (W + P[im1] - P[ip1] - P[jp1]) / (b0);
+                }
+            }
+        for (int ci = 0, q = 0; ci < ny; ci++)                                           /* :616-640 */
+            for (int cj = 0; cj < nx; cj++, q++) {
+                const int i = 2 * ci + 1, j = 2 * cj + 1;
+                u[q] = lambda * f[q] + lambda * (P[SG(i + 1, j)] - P[SG(i - 1, j)] + P[SG(i, j + 1)] - P[SG(i, j - 1)]);
+                P1[q] = P[SG(i + 1, j)];
+                P2[q] = P[SG(i, j + 1)];
+            }
+    }
+    free(P); free(F); free(AL); free(ux); free(uy);
+}
+#undef SG
+
+#define OCC_OMEGA 1.25             /* src/tvl1occflow_constants.h:28 */
+/* src/tvl1occflow_solvers.cpp:150-216 Solver_wrt_u with the four dual planes as EXPLICIT in/out state (the reference
+ * keeps them in function-local statics, zeroed when the width changes); n_iter = its MAX_ITERATIONS_U (10) */
+void orc_occ_solver_u(double *u1, double *u2, const double *v1, const double *v2, const double *chi, const double *g,
+                      double theta, double beta, int nx, int ny, double *p11, double *p12, double *p21, double *p22, int n_iter)
+{
+    const size_t n = (size_t) nx * ny;
+    double *chix = dalloc(n), *chiy = dalloc(n), *f1 = dalloc(n), *f2 = dalloc(n);
+    orc_forward_gradient(chi, chix, chiy, nx, ny);
+    for (size_t i = 0; i < n; i++) {
+        f1[i] = v1[i] / theta + beta * chix[i];
+        f2[i] = v2[i] / theta + beta * chiy[i];
+        u1[i] = v1[i] + theta * beta * chix[i];
+        u2[i] = v2[i] + theta * beta * chiy[i];
+    }
+    orc_rof_box(u1, f1, p11, p12, g, theta, OCC_OMEGA, nx, ny, n_iter);
+    orc_rof_box(u2, f2, p21, p22, g, theta, OCC_OMEGA, nx, ny, n_iter);
+    free(chix); free(chiy); free(f1); free(f2);
+}

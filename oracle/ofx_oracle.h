@@ -108,6 +108,11 @@ void orc_occ_solver_v(const double *u1, const double *u2, double *v1, double *v2
                       const double *I1wy, const double *I_1wx, const double *I_1wy, const double *rho1_c,
                       const double *rho3_c, double *Vfwd_1, double *Vfwd_2, double *Vbck_1, double *Vbck_2,
                       const double *grad1, const double *grad3, double alpha, double theta, double lambda, int nx, int ny);
+/* tvl1occflow_tv_rof_box.cpp:22-645 and tvl1occflow_solvers.cpp:150-216 (dual planes as explicit state) */
+void orc_rof_box(double *u, const double *f, double *P1, double *P2, const double *g, double lambda, double omega, int nx,
+                 int ny, int n_iter);
+void orc_occ_solver_u(double *u1, double *u2, const double *v1, const double *v2, const double *chi, const double *g,
+                      double theta, double beta, int nx, int ny, double *p11, double *p12, double *p21, double *p22, int n_iter);
 void orc_occ_solver_chi(const double *u1, const double *u2, double *chi, const double *I1wx, const double *I1wy,
                         const double *I_1wx, const double *I_1wy, const double *rho1_c, const double *rho3_c,
                         const double *Vfwd_1, const double *Vfwd_2, const double *Vbck_1, const double *Vbck_2,

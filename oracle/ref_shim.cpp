@@ -22,6 +22,7 @@
 #include "brox_optic_flow.h"
 #include "brox_spatial_mask.h"
 #include "tvl1occflow_solvers.h"
+#include "tvl1occflow_tv_rof_box.h"
 
 #include <cstdlib>
 #include <new>
@@ -204,6 +205,28 @@ void ref_occ_solver_v(const double *u1, const double *u2, double *v1, double *v2
                  I_1wy, rho1_c, rho3_c, Vfwd_1, Vfwd_2, Vbck_1, Vbck_2, grad1, grad3, alpha, theta, lambda, nx, ny);
 }
 
+void ref_rof_box(double *u, const double *f, double *P1, double *P2, const double *g, double lambda, double omega, int nx,
+                 int ny, int n_iter)
+{ Scalar_ROF_BoxCellCentered(u, f, P1, P2, g, lambda, omega, nx, ny, n_iter); }
+
+// One call of the reference's Solver_wrt_u (10 box-relaxation iterations per flow component).  Its dual planes are
+// function-local statics, zeroed whenever nx differs from the previous call's: `fresh` != 0 first makes a dummy call
+// with another width, so that the real call starts from p = 0; fresh == 0 continues with what the previous call left.
+void ref_occ_solver_u(double *u1, double *u2, const double *v1, const double *v2, const double *chi, const double *g,
+                      double theta, double beta, int nx, int ny, int fresh)
+{
+    static int last_nx = 0;                      // the width the function's statics are sized for (0 = never called)
+    if (fresh) {
+        int dn = 3;
+        while (dn == nx || dn == last_nx) dn++;  // a width that forces a re-allocation now AND at the real call
+        double z[25 * 6] = {0};
+        for (int k = 0; k < 25; k++) z[5 * 25 + k] = 1.0;            // g = 1
+        Solver_wrt_u(z, z + 25, z + 50, z + 75, z + 100, z + 125, theta, beta, dn, dn);
+    }
+    Solver_wrt_u(u1, u2, v1, v2, chi, g, theta, beta, nx, ny);
+    last_nx = nx;
+}
+
 // One call of the reference's Solver_wrt_chi (MAX_ITERATIONS_CHI = 100 iterations).  Its dual variable lives in
 // function-local statics that are re-allocated -- zero-filled, see operator new[] above -- whenever nx differs from the
 // previous call's: `fresh` != 0 first makes a dummy call with another width, so that the real call starts from eta = 0;
@@ -214,15 +237,18 @@ void ref_occ_solver_chi(const double *u1, const double *u2, double *chi, const d
                         const double *g, double lambda, double theta, double alpha, double beta, double tau_chi,
                         double tau_eta, int nx, int ny, int fresh)
 {
+    static int last_nx = 0;                      // the width the function's statics are sized for (0 = never called)
     if (fresh) {
-        const int dn = (nx == 3) ? 4 : 3;
-        double z[16 * 14] = {0};
+        int dn = 3;
+        while (dn == nx || dn == last_nx) dn++;  // a width that forces a re-allocation now AND at the real call
+        double z[25 * 14] = {0};
         double *a = z;
-        Solver_wrt_chi(a, a + 16, a + 32, a + 48, a + 64, a + 80, a + 96, a + 112, a + 128, a + 144, a + 160, a + 176,
-                       a + 192, a + 208, lambda, theta, alpha, beta, tau_chi, tau_eta, dn, dn);
+        Solver_wrt_chi(a, a + 25, a + 50, a + 75, a + 100, a + 125, a + 150, a + 175, a + 200, a + 225, a + 250, a + 275,
+                       a + 300, a + 325, lambda, theta, alpha, beta, tau_chi, tau_eta, dn, dn);
     }
     Solver_wrt_chi(u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, Vfwd_1, Vfwd_2, Vbck_1, Vbck_2, g, lambda, theta,
                    alpha, beta, tau_chi, tau_eta, nx, ny);
+    last_nx = nx;
 }
 
 } // extern "C"

@@ -176,3 +176,25 @@ def test_occlusion_solvers(orc, ref):
         c_ref2 = ref.occ_solver_chi(*args_c2, fresh=False)
         c_orc2, _, _ = orc.occ_solver_chi(*args_c2, eta1=e1, eta2=e2)
         assert np.array_equal(c_ref2, c_orc2)
+
+
+def test_rof_box_and_solver_wrt_u(orc, ref):
+    """Scalar_ROF_BoxCellCentered (nine cell kinds, in-place relaxation sweep) and Solver_wrt_u: restatement == reference"""
+    rng = np.random.default_rng(8)
+    for nx, ny in ((2, 2), (3, 2), (2, 5), (7, 6), (19, 13), (33, 9)):
+        u = rng.standard_normal((ny, nx))
+        f = u / 0.3 + rng.standard_normal((ny, nx)) * 0.2
+        P1, P2 = rng.standard_normal((ny, nx)) * 0.1, rng.standard_normal((ny, nx)) * 0.1
+        g = 1.0 / (1.0 + rng.random((ny, nx)) * 3)
+        for n_iter in (1, 4):
+            for a, b in zip(orc.rof_box(u, f, P1, P2, g, 0.3, 1.25, n_iter), ref.rof_box(u, f, P1, P2, g, 0.3, 1.25, n_iter)):
+                assert np.array_equal(a, b), (nx, ny, n_iter)
+        v1, v2 = rng.standard_normal((ny, nx)), rng.standard_normal((ny, nx))
+        chi = np.clip(rng.random((ny, nx)) * 1.4 - 0.2, 0, 1)
+        r1, r2 = ref.occ_solver_u(v1, v2, chi, g, 0.3, 0.15, fresh=True)
+        o1, o2, p = orc.occ_solver_u(v1, v2, chi, g, 0.3, 0.15)
+        assert np.array_equal(r1, o1) and np.array_equal(r2, o2), (nx, ny)
+        # a second call continues with the dual planes the first one left
+        r1, r2 = ref.occ_solver_u(v2, v1, chi, g, 0.3, 0.15, fresh=False)
+        o1, o2, _ = orc.occ_solver_u(v2, v1, chi, g, 0.3, 0.15, p=p)
+        assert np.array_equal(r1, o1) and np.array_equal(r2, o2), (nx, ny)
