@@ -283,6 +283,17 @@ int ofx_solver_wrt_v(ofx_ctx *ctx, const double *u1, const double *u2, double *v
                      const double *rho1_c, const double *rho3_c, double *Vfwd_1, double *Vfwd_2, double *Vbck_1,
                      double *Vbck_2, const double *grad1, const double *grad3, double alpha, double theta, double lambda,
                      int nx, int ny);
+/* Scalar_ROF_BoxCellCentered (src/tvl1occflow_tv_rof_box.h:52-55): nIter x { alfa from u; one in-place box-relaxation sweep in
+ * the reference's cell order (executed on hyperplanes, bit-identical); u = lambda f + lambda div P }.  u: in = seed, out =
+ * result; initialP1 / initialP2: in/out dual values on the south / east cell edges.  nx, ny >= 2. */
+int ofx_scalar_rof_box_cell_centered(ofx_ctx *ctx, double *u, const double *f, double *initialP1, double *initialP2,
+                                     const double *g_function, double lambda, double omega, int nx, int ny, int nIter);
+/* Solver_wrt_u (src/tvl1occflow_solvers.cpp:150-216); the reference's argument order, followed by its four dual planes as
+ * explicit in/out state (the reference keeps them in function-local statics, zeroed when the image width changes) and the
+ * iteration count per flow component (the reference's MAX_ITERATIONS_U = 10) */
+int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const double *v1, const double *v2, const double *chi,
+                     const double *g, double theta, double beta, int nx, int ny, double *p11, double *p12, double *p21,
+                     double *p22, int n_iter);
 /* Solver_wrt_chi (src/tvl1occflow_solvers.cpp:218-337); the reference's argument order, followed by the dual variable
  * (eta1, eta2) as explicit in/out state -- zero it for what the reference computes on a zero-filled heap -- and the
  * iteration count (the reference's MAX_ITERATIONS_CHI = 100) */

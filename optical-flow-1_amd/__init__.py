@@ -128,6 +128,8 @@ def lib():
         "ofx_image_normalization_4": (_i, [_vp] + [_dp] * 8 + [_i]),
         "ofx_me_median_filtering": (_i, [_vp, _dp, _i, _i, _i]),
         "ofx_solver_wrt_v": (_i, [_vp] + [_dp] * 17 + [_d, _d, _d, _i, _i]),
+        "ofx_scalar_rof_box_cell_centered": (_i, [_vp, _dp, _dp, _dp, _dp, _dp, _d, _d, _i, _i, _i]),
+        "ofx_solver_wrt_u": (_i, [_vp] + [_dp] * 6 + [_d, _d, _i, _i] + [_dp] * 4 + [_i]),
         "ofx_solver_wrt_chi": (_i, [_vp] + [_dp] * 14 + [_d] * 6 + [_i, _i, _dp, _dp, _i]),
         "ofx_hs_classic": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _d]),
         "ofx_brox_temporal": (_i, [_vp, _dp, _dp, _dp, _i, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
@@ -479,3 +481,18 @@ class Ofx:
                                            _f64(rho1_c), _f64(rho3_c), _f64(Vf1), _f64(Vf2), _f64(Vb1), _f64(Vb2), _f64(g), lam,
                                            theta, alpha, beta, tau_chi, tau_eta, nx, ny, eta1, eta2, n_iter))
         return chi, eta1, eta2
+
+    def rof_box(self, u, f, P1, P2, g, lam, omega, n_iter):
+        """Scalar_ROF_BoxCellCentered -> (u, P1, P2)"""
+        ny, nx = u.shape
+        u, P1, P2 = _f64(u).copy(), _f64(P1).copy(), _f64(P2).copy()
+        self._ck(self.L.ofx_scalar_rof_box_cell_centered(self.h, u, _f64(f), P1, P2, _f64(g), lam, omega, nx, ny, n_iter))
+        return u, P1, P2
+
+    def occ_solver_u(self, v1, v2, chi, g, theta, beta, p=None, n_iter=10):
+        """Solver_wrt_u with the four dual planes as explicit state -> (u1, u2, [p11, p12, p21, p22]); p defaults to zero"""
+        ny, nx = v1.shape
+        u1, u2 = np.empty((ny, nx)), np.empty((ny, nx))
+        p = [np.zeros((ny, nx)) for _ in range(4)] if p is None else [_f64(a).copy() for a in p]
+        self._ck(self.L.ofx_solver_wrt_u(self.h, u1, u2, _f64(v1), _f64(v2), _f64(chi), _f64(g), theta, beta, nx, ny, *p, n_iter))
+        return u1, u2, p

@@ -441,3 +441,253 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
     OFX_TRY(d.out(di[15], eta2, n));
     return d.sync();
 }
+
+// ---- Scalar_ROF_BoxCellCentered (src/tvl1occflow_tv_rof_box.cpp:22-645) and Solver_wrt_u (tvl1occflow_solvers.cpp:150-216) --------
+// nIter times { alfa = |grad u| / (lambda g) per cell;  ONE in-place box-relaxation sweep over the cells in lexicographic
+// order;  u = lambda f + lambda div P }.  The sweep is a sequential recurrence: each cell solves the 2x2 / 3x3 / 4x4 system of
+// the dual values on its own edges from the edges of its eight neighbours.  Like the SOR sweeps (ofx_sor.hip) it is
+// executed on hyperplanes without changing an operand: cell (ci, cj) runs at step pos = 2 ci + cj, so that the cells it
+// must follow (W, NW, N, NE) are done and the ones it must precede (E, SW, S, SE) are not; the cells of one step touch
+// disjoint edges.  A sweep is cut into row blocks of R rows, one workgroup each, block b running K steps behind block b - 1;
+// a launch executes K steps of every block, so everything a workgroup reads from another one was written in an earlier
+// launch, and inside a workgroup consecutive steps are separated by a store drain + barrier.
+// Cell-centred storage instead of the reference's (2 ny + 1) x (2 nx + 1) staggered grid: Ps / Pe = dual value on the
+// south / east edge of a cell (the in/out state initialP1 / initialP2; a cell's north / west edge is the south / east
+// edge of its neighbour, 0 on the image border), Fs / Fe = differences of f across those edges (0 on the border), AL =
+// alfa of the cell (the reference stores the same value on both edges).
+#define ROF_K 8
+#define ROF_R 125
+struct RofArr {
+    double *Ps, *Pe;
+    const double *Fs, *Fe, *AL;
+    int nx, ny;
+    OFX_DEV double ps(int ci, int cj) const { return (ci >= 0 && cj >= 0) ? Ps[(size_t) ci * nx + cj] : 0.0; }
+    OFX_DEV double pe(int ci, int cj) const { return (ci >= 0 && cj >= 0) ? Pe[(size_t) ci * nx + cj] : 0.0; }
+};
+
+// one cell; the nine kinds keep the reference's own closed forms and association order (only the north side writes its
+// free terms with the F term first)
+OFX_DEV void rof_cell(const RofArr &a, int ci, int cj, double w)
+{
+    const int nx = a.nx, ny = a.ny;
+    const bool top = ci == 0, bot = ci == ny - 1, lef = cj == 0, rig = cj == nx - 1;
+    const size_t c = (size_t) ci * nx + cj;
+    const bool nside = top && !lef && !rig;
+    double W = 0, N = 0, S = 0, E = 0;
+    if (!lef) {
+        const double fw = a.Fe[c - 1];
+        W = nside ? -fw - a.pe(ci, cj - 2) + a.ps(ci, cj - 1) - a.ps(ci - 1, cj - 1)
+                  : -a.pe(ci, cj - 2) + a.ps(ci, cj - 1) - a.ps(ci - 1, cj - 1) - fw;
+    }
+    if (!top) N = -a.ps(ci - 2, cj) + a.pe(ci - 1, cj) - a.pe(ci - 1, cj - 1) - a.Fs[c - nx];
+    if (!bot) {
+        const double fs = a.Fs[c];
+        S = nside ? -fs - a.ps(ci + 1, cj) - a.pe(ci + 1, cj) + a.pe(ci + 1, cj - 1)
+                  : -a.ps(ci + 1, cj) - a.pe(ci + 1, cj) + a.pe(ci + 1, cj - 1) - fs;
+    }
+    if (!rig) {
+        const double fe = a.Fe[c];
+        E = nside ? -fe - a.pe(ci, cj + 1) - a.ps(ci, cj + 1) + a.ps(ci - 1, cj + 1)
+                  : -a.pe(ci, cj + 1) - a.ps(ci, cj + 1) + a.ps(ci - 1, cj + 1) - fe;
+    }
+    const double b0 = lef ? 0.0 : -2 - a.AL[c - 1], b1 = top ? 0.0 : -2 - a.AL[c - nx];
+    const double b2 = bot ? 0.0 : -2 - a.AL[c], b3 = rig ? 0.0 : -2 - a.AL[c];
+    // own edges: west = east edge of the left cell, north = south edge of the cell above
+    double *pw = lef ? nullptr : a.Pe + c - 1, *pn = top ? nullptr : a.Ps + c - nx, *psp = a.Ps + c, *pep = a.Pe + c;
+    double den;
+    if (top && lef) {
+        den = b2 * b3 - 1;
+        const double s_ = (1 - w) * *psp + w * (S * b3 + E) / den, e_ = (1 - w) * *pep + w * (E * b2 + S) / den;
+        *psp = s_; *pep = e_;
+    } else if (top && rig) {
+        den = b0 * b2 - 1;
+        const double w_ = (1 - w) * *pw + w * (W * b2 - S) / den, s_ = (1 - w) * *psp + w * (S * b0 - W) / den;
+        *pw = w_; *psp = s_;
+    } else if (top) {
+        den = b0 * b2 * b3 - b0 - b2 - b3 - 2;
+        const double w_ = (1 - w) * *pw + w * (W * b2 * b3 - E * b2 - S * b3 - W - E - S) / den;
+        const double s_ = (1 - w) * *psp + w * (S * b0 * b3 - W * b3 + E * b0 - W + E - S) / den;
+        const double e_ = (1 - w) * *pep + w * (E * b0 * b2 - W * b2 + S * b0 - W - E + S) / den;
+        *pw = w_; *psp = s_; *pep = e_;
+    } else if (bot && lef) {
+        den = b3 * b1 - 1;
+        const double n_ = (1 - w) * *pn + w * (b3 * N - E) / den, e_ = (1 - w) * *pep + w * (b1 * E - N) / den;
+        *pn = n_; *pep = e_;
+    } else if (bot && rig) {
+        den = b0 * b1 - 1;
+        const double w_ = (1 - w) * *pw + w * (W * b1 + N) / den, n_ = (1 - w) * *pn + w * (N * b0 + W) / den;
+        *pw = w_; *pn = n_;
+    } else if (bot) {
+        den = b0 * b1 * b3 - b0 - b1 - b3 - 2;
+        const double w_ = (1 - w) * *pw + w * (W * b1 * b3 - E + N - E * b1 - W + N * b3) / den;
+        const double n_ = (1 - w) * *pn + w * (N * b0 * b3 + W - E - N - E * b0 + W * b3) / den;
+        const double e_ = (1 - w) * *pep + w * (E * b0 * b1 - N - W - W * b1 - N * b0 - E) / den;
+        *pw = w_; *pn = n_; *pep = e_;
+    } else if (lef) {
+        den = b1 * b2 * b3 - (b1 + b2 + b3) - 2;
+        const double n_ = (1 - w) * *pn + w * (b2 * b3 * N - E * b2 - S * b3 - N - S - E) / den;
+        const double s_ = (1 - w) * *psp + w * (b1 * b3 * S + E * b1 - N * b3 - N - S + E) / den;
+        const double e_ = (1 - w) * *pep + w * (b1 * b2 * E - N * b2 + S * b1 - N + S - E) / den;
+        *pn = n_; *psp = s_; *pep = e_;
+    } else if (rig) {
+        den = (b0 * b1 * b2) + (-b0 - b1 - b2 - 2);
+        const double w_ = (1 - w) * *pw + w * (W * b1 * b2 - S + N - S * b1 - W + N * b2) / den;
+        const double n_ = (1 - w) * *pn + w * (N * b0 * b2 + W - S - N - S * b0 + W * b2) / den;
+        const double s_ = (1 - w) * *psp + w * (S * b0 * b1 - N - W - W * b1 - N * b0 - S) / den;
+        *pw = w_; *pn = n_; *psp = s_;
+    } else {                                             // inner cell: Gauss elimination, each value from the new ones before it
+        const double aa = 1 / b0;
+        const double bb = -(b0 + 1) / (b0 * b1 - 1);
+        const double alf = 1 + aa;
+        const double gam = -aa + bb * alf;
+        const double x = N + aa * W;
+        const double y = -aa * W + bb * x;
+        const double cc = (1 - gam) / (b2 + gam);
+        const double e_ = (1 - w) * *pep + w * (E + y + cc * (S + y)) / (b3 + gam + cc * (gam - 1));
+        const double s_ = (1 - w) * *psp + w * (S + y + e_ * (1 - gam)) / (b2 + gam);
+        const double n_ = (1 - w) * *pn + w * (x - alf * (e_ + s_)) / (b1 - aa);
+        const double w_ = (1 - w) * *pw + w * (W + n_ - s_ - e_) / (b0);
+        *pep = e_; *psp = s_; *pn = n_; *pw = w_;
+    }
+}
+
+// K steps [tau0, tau0 + K) of every row block of one sweep
+__global__ __launch_bounds__(128) void k_rof_window(RofArr a, int tau0, double w)
+{
+    const int b = blockIdx.x, ci = b * ROF_R + (int) threadIdx.x;
+    const int qmax = 2 * (a.ny - 1) + a.nx - 1;
+    const int q_first = tau0 - ROF_K * b;
+    if (q_first > qmax || q_first + ROF_K - 1 < 0) return;
+    for (int q = q_first; q < q_first + ROF_K; q++) {
+        const int cj = q - 2 * ci;
+        if ((int) threadIdx.x < ROF_R && ci < a.ny && q >= 0 && cj >= 0 && cj < a.nx) rof_cell(a, ci, cj, w);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// edge differences of f (once per call), :137-164
+__global__ void k_rof_fdiff(const double *__restrict__ f, double *__restrict__ Fs, double *__restrict__ Fe, int nx, int ny)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t c = (size_t) i * nx + j;
+    Fs[c] = (i < ny - 1) ? f[c + nx] - f[c] : 0.0;
+    Fe[c] = (j < nx - 1) ? f[c + 1] - f[c] : 0.0;
+}
+// alfa = hypot(forward gradient of u) / (lambda g) with the file-local hypot = sqrt(x x + y y), :15-20,173-187
+__global__ void k_rof_alfa(const double *__restrict__ u, const double *__restrict__ g, double *__restrict__ AL, int nx, int ny,
+                           double lambda)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t c = (size_t) i * nx + j;
+    const double ux = (j < nx - 1) ? u[c + 1] - u[c] : 0.0, uy = (i < ny - 1) ? u[c + nx] - u[c] : 0.0;
+    AL[c] = sqrt(ux * ux + uy * uy) / (lambda * g[c]);
+}
+// u = lambda f + lambda (P_south - P_north + P_east - P_west), :616-640
+__global__ void k_rof_u(const double *__restrict__ f, const double *__restrict__ Ps, const double *__restrict__ Pe,
+                        double *__restrict__ u, int nx, int ny, double lambda)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t c = (size_t) i * nx + j;
+    const double pn = i > 0 ? Ps[c - nx] : 0.0, pw = j > 0 ? Pe[c - 1] : 0.0;
+    u[c] = lambda * f[c] + lambda * (Ps[c] - pn + Pe[c] - pw);
+}
+
+// device arrays in place: u (in: seed, out: result), Ps / Pe (in/out state)
+static int rof_box_dev(ofx_ctx *ctx, double *u, const double *f, double *Ps, double *Pe, const double *g, double lambda,
+                       double omega, int nx, int ny, int n_iter)
+{
+    const size_t n = (size_t) nx * ny;
+    double *Fs, *Fe, *AL;
+    OFX_TRY(ofx_alloc(ctx, n, &Fs));
+    OFX_TRY(ofx_alloc(ctx, n, &Fe));
+    OFX_TRY(ofx_alloc(ctx, n, &AL));
+    const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), block(64, 4);
+    hipLaunchKernelGGL(k_rof_fdiff, grid, block, 0, ctx->stream, f, Fs, Fe, nx, ny);
+    OFX_LAUNCH_CHECK(ctx);
+    const RofArr a = {Ps, Pe, Fs, Fe, AL, nx, ny};
+    const int B = ofx_cdiv(ny, ROF_R), qmax = 2 * (ny - 1) + nx - 1;
+    const long total = (long) qmax + 1 + (long) ROF_K * (B - 1);
+    for (int it = 0; it < n_iter; it++) {
+        hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, (const double *) u, g, AL, nx, ny, lambda);
+        for (long tau0 = 0; tau0 < total; tau0 += ROF_K)
+            hipLaunchKernelGGL(k_rof_window, dim3(B), dim3(128), 0, ctx->stream, a, (int) tau0, omega);
+        hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, f, (const double *) Ps, (const double *) Pe, u, nx, ny, lambda);
+        OFX_LAUNCH_CHECK(ctx);
+    }
+    return OFX_OK;
+}
+
+extern "C" int ofx_scalar_rof_box_cell_centered(ofx_ctx *ctx, double *u, const double *f, double *initialP1, double *initialP2,
+                                                const double *g_function, double lambda, double omega, int nx, int ny,
+                                                int nIter)
+{
+    OFX_ENTER(ctx);
+    if (!u || !f || !initialP1 || !initialP2 || !g_function) return ofx_fail(ctx, OFX_ERR_ARG, "rof_box: NULL pointer");
+    if (nx < 2 || ny < 2 || (long long) nx * ny > 0x3fffffffLL) return ofx_fail(ctx, OFX_ERR_ARG, "rof_box: bad size %dx%d", nx, ny);
+    if (nIter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "rof_box: nIter=%d", nIter);
+    Dev d{ctx};
+    const size_t n = (size_t) nx * ny;
+    double *du, *df, *dp1, *dp2, *dg;
+    OFX_TRY(d.in(u, &du, n));
+    OFX_TRY(d.in(f, &df, n));
+    OFX_TRY(d.in(initialP1, &dp1, n));
+    OFX_TRY(d.in(initialP2, &dp2, n));
+    OFX_TRY(d.in(g_function, &dg, n));
+    OFX_TRY(rof_box_dev(ctx, du, df, dp1, dp2, dg, lambda, omega, nx, ny, nIter));
+    OFX_TRY(d.out(du, u, n));
+    OFX_TRY(d.out(dp1, initialP1, n));
+    OFX_TRY(d.out(dp2, initialP2, n));
+    return d.sync();
+}
+
+#define OCC_OMEGA 1.25             // src/tvl1occflow_constants.h:28
+// f = v / theta + beta grad(chi), u = v + theta beta grad(chi) (tvl1occflow_solvers.cpp:192-203)
+__global__ void k_occ_u_init(const double *__restrict__ v1, const double *__restrict__ v2, const double *__restrict__ chi,
+                             double *__restrict__ f1, double *__restrict__ f2, double *__restrict__ u1, double *__restrict__ u2,
+                             int nx, int ny, double theta, double beta)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t c = (size_t) i * nx + j;
+    const double chix = (j < nx - 1) ? chi[c + 1] - chi[c] : 0.0, chiy = (i < ny - 1) ? chi[c + nx] - chi[c] : 0.0;
+    f1[c] = v1[c] / theta + beta * chix;
+    f2[c] = v2[c] / theta + beta * chiy;
+    u1[c] = v1[c] + theta * beta * chix;
+    u2[c] = v2[c] + theta * beta * chiy;
+}
+
+extern "C" int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const double *v1, const double *v2, const double *chi,
+                                const double *g, double theta, double beta, int nx, int ny, double *p11, double *p12,
+                                double *p21, double *p22, int n_iter)
+{
+    OFX_ENTER(ctx);
+    if (!u1 || !u2 || !v1 || !v2 || !chi || !g || !p11 || !p12 || !p21 || !p22) return ofx_fail(ctx, OFX_ERR_ARG, "solver_wrt_u: NULL pointer");
+    if (nx < 2 || ny < 2 || (long long) nx * ny > 0x3fffffffLL) return ofx_fail(ctx, OFX_ERR_ARG, "solver_wrt_u: bad size %dx%d", nx, ny);
+    if (n_iter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "solver_wrt_u: n_iter=%d", n_iter);
+    Dev d{ctx};
+    const size_t n = (size_t) nx * ny;
+    double *dv1, *dv2, *dchi, *dg, *dp[4], *f1, *f2, *du1, *du2;
+    OFX_TRY(d.in(v1, &dv1, n));
+    OFX_TRY(d.in(v2, &dv2, n));
+    OFX_TRY(d.in(chi, &dchi, n));
+    OFX_TRY(d.in(g, &dg, n));
+    double *hp[4] = {p11, p12, p21, p22};
+    for (int k = 0; k < 4; k++) OFX_TRY(d.in(hp[k], &dp[k], n));
+    OFX_TRY(ofx_alloc(ctx, n, &f1));
+    OFX_TRY(ofx_alloc(ctx, n, &f2));
+    OFX_TRY(ofx_alloc(ctx, n, &du1));
+    OFX_TRY(ofx_alloc(ctx, n, &du2));
+    hipLaunchKernelGGL(k_occ_u_init, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, (const double *) dv1,
+                       (const double *) dv2, (const double *) dchi, f1, f2, du1, du2, nx, ny, theta, beta);
+    OFX_LAUNCH_CHECK(ctx);
+    OFX_TRY(rof_box_dev(ctx, du1, f1, dp[0], dp[1], dg, theta, OCC_OMEGA, nx, ny, n_iter));
+    OFX_TRY(rof_box_dev(ctx, du2, f2, dp[2], dp[3], dg, theta, OCC_OMEGA, nx, ny, n_iter));
+    OFX_TRY(d.out(du1, u1, n));
+    OFX_TRY(d.out(du2, u2, n));
+    for (int k = 0; k < 4; k++) OFX_TRY(d.out(dp[k], hp[k], n));
+    return d.sync();
+}

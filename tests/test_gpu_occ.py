@@ -72,3 +72,32 @@ def test_occlusion_solvers_bitexact(gpu64, orc, nx, ny):
     c1, a1, a2 = gpu64.occ_solver_chi(*args_c, n_iter=37)
     c2, _, _ = gpu64.occ_solver_chi(u1, u2, c1, *args_c[3:], eta1=a1, eta2=a2, n_iter=63)
     assert np.array_equal(c2, co)
+
+
+@pytest.mark.parametrize("nx,ny", [(2, 2), (3, 2), (2, 5), (7, 6), (19, 13), (33, 140), (300, 131), (130, 260)])
+def test_rof_box_and_solver_wrt_u_bitexact(gpu64, ofx_mod, orc, nx, ny):
+    """the in-place box-relaxation sweep of Scalar_ROF_BoxCellCentered runs on hyperplanes of row blocks (K steps per
+    launch): every dual value and u bit-identical to the sequential sweep, for all nine cell kinds, one and several row
+    blocks (ny > 125), and Solver_wrt_u on top of it with the dual planes carried from call to call"""
+    rng = np.random.default_rng(nx * 1000 + ny)
+    u = rng.standard_normal((ny, nx))
+    f = u / 0.3 + rng.standard_normal((ny, nx)) * 0.2
+    P1, P2 = rng.standard_normal((ny, nx)) * 0.1, rng.standard_normal((ny, nx)) * 0.1
+    g = 1.0 / (1.0 + rng.random((ny, nx)) * 3)
+    for n_iter in (1, 3):
+        for a, b in zip(gpu64.rof_box(u, f, P1, P2, g, 0.3, 1.25, n_iter), orc.rof_box(u, f, P1, P2, g, 0.3, 1.25, n_iter)):
+            assert np.array_equal(a, b), (nx, ny, n_iter)
+    v1, v2 = rng.standard_normal((ny, nx)), rng.standard_normal((ny, nx))
+    chi = np.clip(rng.random((ny, nx)) * 1.4 - 0.2, 0, 1)
+    n_it = 10 if nx * ny < 20000 else 3
+    g1, g2, gp = gpu64.occ_solver_u(v1, v2, chi, g, 0.3, 0.15, n_iter=n_it)          # from zero dual planes, as the reference
+    o1, o2, op = orc.occ_solver_u(v1, v2, chi, g, 0.3, 0.15, n_iter=n_it)
+    assert np.array_equal(g1, o1) and np.array_equal(g2, o2)
+    for a, b in zip(gp, op):
+        assert np.array_equal(a, b)
+    g1, g2, _ = gpu64.occ_solver_u(v2, v1, chi, g, 0.3, 0.15, p=gp, n_iter=2)        # state carried over
+    o1, o2, _ = orc.occ_solver_u(v2, v1, chi, g, 0.3, 0.15, p=op, n_iter=2)
+    assert np.array_equal(g1, o1) and np.array_equal(g2, o2)
+    if (nx, ny) == (2, 2):
+        with pytest.raises(ofx_mod.OfxError):
+            gpu64.rof_box(np.zeros((1, 5)), np.zeros((1, 5)), np.zeros((1, 5)), np.zeros((1, 5)), np.ones((1, 5)), 0.3, 1.25, 1)
