@@ -227,6 +227,20 @@ class Oracle(_Lib):
     prefix = "orc_"
     kind = "port"
 
+    def tvl1occ_multiscale(self, I_1, I0, I1, filtI0=None, lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=3, zfactor=0.5,
+                           warps=2, epsilon=0.01, verbose=0):
+        """TV-L1 with occlusions (zero-filled-heap semantics) -> (u1, u2, chi, outer-iteration table [scale][warp])"""
+        ny, nx = I0.shape
+        filtI0 = I0 if filtI0 is None else filtI0
+        u1, u2, chi = np.zeros((ny, nx)), np.zeros((ny, nx)), np.zeros((ny, nx))
+        iters = (C.c_int * (warps * nscales))()
+        rc = self._fn("tvl1occ_multiscale", C.c_int, *([_dp] * 7), C.c_int, C.c_int, *([C.c_double] * 4), C.c_int, C.c_double,
+                      C.c_int, C.c_double, C.c_int, _ip)(_f64(I_1), _f64(I0), _f64(I1), _f64(filtI0), u1, u2, chi, nx, ny, lam,
+                                                          alpha, beta, theta, nscales, zfactor, warps, epsilon, verbose, iters)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return u1, u2, chi, np.array(list(iters)).reshape(nscales, warps)
+
     def occ_solver_u(self, v1, v2, chi, g, theta, beta, p=None, n_iter=10):
         """Solver_wrt_u with the four dual planes as explicit state -> (u1, u2, [p11, p12, p21, p22]); p defaults to zero"""
         ny, nx = v1.shape
@@ -350,6 +364,17 @@ class Ref(_Lib):
     """The compiled reference itself (oracle/_ref/libofref.so via oracle/ref_shim.cpp)."""
     prefix = "ref_"
     kind = "reference"
+
+    def tvl1occ_multiscale(self, I_1, I0, I1, filtI0=None, lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=3, zfactor=0.5,
+                           warps=2, epsilon=0.01, verbose=0):
+        """the reference's Dual_TVL1_optic_flow_multiscale (tvl1occflow.h) on a zero-filled heap -> (u1, u2, chi)"""
+        ny, nx = I0.shape
+        filtI0 = I0 if filtI0 is None else filtI0
+        u1, u2, chi = np.zeros((ny, nx)), np.zeros((ny, nx)), np.zeros((ny, nx))
+        self._fn("tvl1occ_multiscale", None, *([_dp] * 7), C.c_int, C.c_int, *([C.c_double] * 4), C.c_int, C.c_double, C.c_int,
+                 C.c_double, C.c_int)(_f64(I_1), _f64(I0), _f64(I1), _f64(filtI0), u1, u2, chi, nx, ny, lam, alpha, beta, theta,
+                                      nscales, zfactor, warps, epsilon, verbose)
+        return u1, u2, chi
 
     def occ_solver_u(self, v1, v2, chi, g, theta, beta, fresh=True):
         """One call of the reference's Solver_wrt_u -> (u1, u2).  fresh: zero dual planes (oracle/ref_shim.cpp); otherwise

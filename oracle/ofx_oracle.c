@@ -1885,3 +1885,142 @@ void orc_occ_solver_u(double *u1, double *u2, const double *v1, const double *v2
     orc_rof_box(u2, f2, p21, p22, g, theta, OCC_OMEGA, nx, ny, n_iter);
     free(chix); free(chiy); free(f1); free(f2);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* src/tvl1occflow.cpp: TV-L1 with occlusions, single scale (:144-329) and multiscale (:337-481), as the reference computes
+ * it on a ZERO-FILLED heap: the dual planes of Solver_wrt_u and the dual variable of Solver_wrt_chi are function-local
+ * statics there, re-created (zero) whenever the image width differs from the previous call's -- i.e. once per pyramid
+ * level -- and kept across the warps and outer iterations of a level.  Here they are per-level arrays.
+ * Constants: src/tvl1occflow_constants.h:26-41. */
+#define OCC_EXT_MAX_ITERATIONS 20
+#define OCC_MAX_ITERATIONS_CHI 100
+#define OCC_MAX_ITERATIONS_U 10
+#define OCC_G_FACTOR 0.05
+#define OCC_TAU_ETA 0.15
+#define OCC_TAU_CHI 0.15
+#define OCC_PRESMOOTHING_SIGMA 0.8
+
+/* iters (optional): outer iterations of every warp; state: 6 planes p11 p12 p21 p22 eta1 eta2 of this level */
+void orc_tvl1occ_single_scale(const double *I_1, const double *I0, const double *I1, const double *filtI0, double *u1,
+                              double *u2, double *chi, int nx, int ny, double lambda, double alpha, double beta,
+                              double theta, int warps, double epsilon, int verbose, double *state, int *iters)
+{
+    const size_t n = (size_t) nx * ny;
+    double *buf = dalloc(26 * n), *q = buf;
+    double *I1x = q, *I1y = (q += n), *I1w = (q += n), *I1wx = (q += n), *I1wy = (q += n), *I_1x = (q += n), *I_1y = (q += n);
+    double *I_1w = (q += n), *I_1wx = (q += n), *I_1wy = (q += n), *rho1_c = (q += n), *rho3_c = (q += n), *v1 = (q += n);
+    double *v2 = (q += n), *v11 = (q += n), *v12 = (q += n), *v31 = (q += n), *v32 = (q += n), *gp1 = (q += n), *gp2 = (q += n);
+    double *grad1 = (q += n), *grad3 = (q += n), *g = (q += n), *u1prev = (q += n), *u2prev = (q += n), *Ix = (q += n);
+    double *Iy = dalloc(n);
+    orc_centered_gradient(filtI0, Ix, Iy, nx, ny);                                   /* choosed_g, choice 2, :96-133 */
+    for (size_t i = 0; i < n; i++) {
+        const double gggrad = sqrt(Ix[i] * Ix[i] + Iy[i] * Iy[i]);
+        const double aux = 1. + OCC_G_FACTOR * gggrad;
+        g[i] = 1. / aux;
+    }
+    orc_centered_gradient(I1, I1x, I1y, nx, ny);
+    orc_centered_gradient(I_1, I_1x, I_1y, nx, ny);
+    for (size_t i = 0; i < n; i++) {
+        u1prev[i] = u1[i];
+        u2prev[i] = u2[i];
+        v1[i] = v2[i] = v11[i] = v12[i] = v31[i] = v32[i] = 0.0;
+    }
+    for (int w = 0; w < warps; w++) {
+        orc_bicubic_warp(I1, u1, u2, I1w, nx, ny, 0);                                 /* border_out defaults to false */
+        orc_bicubic_warp(I1x, u1, u2, I1wx, nx, ny, 0);
+        orc_bicubic_warp(I1y, u1, u2, I1wy, nx, ny, 0);
+        for (size_t i = 0; i < n; i++) { gp1[i] = -u1[i]; gp2[i] = -u2[i]; }
+        orc_bicubic_warp(I_1, gp1, gp2, I_1w, nx, ny, 0);
+        orc_bicubic_warp(I_1x, gp1, gp2, I_1wx, nx, ny, 0);
+        orc_bicubic_warp(I_1y, gp1, gp2, I_1wy, nx, ny, 0);
+        for (size_t i = 0; i < n; i++) {                                              /* :232-248 */
+            grad1[i] = (I1wx[i] * I1wx[i] + I1wy[i] * I1wy[i]);
+            grad3[i] = (I_1wx[i] * I_1wx[i] + I_1wy[i] * I_1wy[i]);
+            rho1_c[i] = (I1w[i] - I1wx[i] * u1[i] - I1wy[i] * u2[i] - I0[i]);
+            rho3_c[i] = (I_1w[i] + I_1wx[i] * u1[i] + I_1wy[i] * u2[i] - I0[i]);
+        }
+        int it = 0;
+        double error = INFINITY;
+        while (error > epsilon && it < OCC_EXT_MAX_ITERATIONS) {                      /* :255-277 */
+            it++;
+            orc_occ_solver_v(u1, u2, v1, v2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, v11, v12, v31, v32, grad1, grad3,
+                             alpha, theta, lambda, nx, ny);
+            orc_occ_solver_u(u1, u2, v1, v2, chi, g, theta, beta, nx, ny, state, state + n, state + 2 * n, state + 3 * n,
+                             OCC_MAX_ITERATIONS_U);
+            orc_median_filtering(u1, nx, ny, 3);
+            orc_median_filtering(u2, nx, ny, 3);
+            orc_occ_solver_chi(u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, v11, v12, v31, v32, g, lambda, theta,
+                               alpha, beta, OCC_TAU_CHI, OCC_TAU_ETA, nx, ny, state + 4 * n, state + 5 * n, OCC_MAX_ITERATIONS_CHI);
+            error = 0.0;                                                              /* L2error, :62-80 */
+            for (size_t i = 0; i < n; i++) {
+                error += (u1[i] - u1prev[i]) * (u1[i] - u1prev[i]) + (u2[i] - u2prev[i]) * (u2[i] - u2prev[i]);
+                u1prev[i] = u1[i];
+                u2prev[i] = u2[i];
+            }
+            error /= (int) n;
+        }
+        if (verbose) fprintf(stderr, "Warping: %d, Iterations: %d, Error: %e\n", w, it, error);
+        if (iters) iters[w] = it;
+    }
+    free(buf);
+    free(Iy);
+}
+
+/* returns 1 for "GaussianSmooth: sigma too large"; iters (optional): [scale][warp], scale 0 = finest */
+int orc_tvl1occ_multiscale(const double *I_1, const double *I0, const double *I1, const double *filtI0, double *u1, double *u2,
+                           double *chi, int nxx, int nyy, double lambda, double alpha, double beta, double theta, int nscales,
+                           double zfactor, int warps, double epsilon, int verbose, int *iters)
+{
+    if (nscales < 1 || nscales > 64) return 2;
+    double *Im[64], *Ic[64], *Ip[64], *If[64], *U1[64], *U2[64], *CH[64];
+    int nx[64], ny[64], rc = 0;
+    const size_t size = (size_t) nxx * nyy;
+    nx[0] = nxx; ny[0] = nyy;
+    Im[0] = dalloc(size); Ic[0] = dalloc(size); Ip[0] = dalloc(size); If[0] = dalloc(size);
+    U1[0] = u1; U2[0] = u2; CH[0] = chi;
+    /* :382-395: image_normalization_4 is called, and its output immediately overwritten by the raw images */
+    for (size_t i = 0; i < size; i++) {
+        Im[0][i] = I_1[i]; Ic[0][i] = I0[i]; Ip[0][i] = I1[i]; If[0][i] = filtI0[i];
+        u1[i] = u2[i] = chi[i] = 0.0;
+    }
+    rc |= orc_gaussian(Im[0], nxx, nyy, OCC_PRESMOOTHING_SIGMA);
+    rc |= orc_gaussian(Ic[0], nxx, nyy, OCC_PRESMOOTHING_SIGMA);
+    rc |= orc_gaussian(Ip[0], nxx, nyy, OCC_PRESMOOTHING_SIGMA);
+    rc |= orc_gaussian(If[0], nxx, nyy, OCC_PRESMOOTHING_SIGMA);
+    int built = 1;
+    for (int s = 1; s < nscales && !rc; s++, built++) {
+        orc_zoom_size(nx[s - 1], ny[s - 1], &nx[s], &ny[s], zfactor);
+        const size_t sz = (size_t) nx[s] * ny[s];
+        Im[s] = dalloc(sz); Ic[s] = dalloc(sz); Ip[s] = dalloc(sz); If[s] = dalloc(sz);
+        U1[s] = dalloc(sz); U2[s] = dalloc(sz); CH[s] = dalloc(sz);
+        for (size_t i = 0; i < sz; i++) U1[s][i] = U2[s][i] = CH[s][i] = 0.0;
+        rc |= orc_zoom_out(Im[s - 1], Im[s], nx[s - 1], ny[s - 1], zfactor);          /* order of :421-424 */
+        rc |= orc_zoom_out(Ic[s - 1], Ic[s], nx[s - 1], ny[s - 1], zfactor);
+        rc |= orc_zoom_out(If[s - 1], If[s], nx[s - 1], ny[s - 1], zfactor);
+        rc |= orc_zoom_out(Ip[s - 1], Ip[s], nx[s - 1], ny[s - 1], zfactor);
+    }
+    for (int s = nscales - 1; s >= 0 && !rc; s--) {
+        const size_t sz = (size_t) nx[s] * ny[s];
+        double *state = dalloc(6 * sz);
+        for (size_t i = 0; i < 6 * sz; i++) state[i] = 0.0;
+        orc_tvl1occ_single_scale(Im[s], Ic[s], Ip[s], If[s], U1[s], U2[s], CH[s], nx[s], ny[s], lambda, alpha, beta, theta,
+                                 warps, epsilon, verbose, state, iters ? iters + s * warps : NULL);
+        free(state);
+        if (s) {
+            orc_zoom_in(U1[s], U1[s - 1], nx[s], ny[s], nx[s - 1], ny[s - 1]);
+            orc_zoom_in(U2[s], U2[s - 1], nx[s], ny[s], nx[s - 1], ny[s - 1]);
+            orc_zoom_in(CH[s], CH[s - 1], nx[s], ny[s], nx[s - 1], ny[s - 1]);
+            for (size_t i = 0; i < (size_t) nx[s - 1] * ny[s - 1]; i++) {
+                U1[s - 1][i] *= (double) 1.0 / zfactor;
+                U2[s - 1][i] *= (double) 1.0 / zfactor;
+            }
+        } else {
+            for (size_t i = 0; i < sz; i++) CH[0][i] = (CH[0][i] > OCC_THR_CHI);     /* Threshold, :82-92 */
+        }
+    }
+    for (int s = 0; s < built; s++) {
+        free(Im[s]); free(Ic[s]); free(Ip[s]); free(If[s]);
+        if (s) { free(U1[s]); free(U2[s]); free(CH[s]); }
+    }
+    return rc ? 1 : 0;
+}

@@ -119,6 +119,15 @@ void orc_occ_solver_chi(const double *u1, const double *u2, double *chi, const d
                         const double *g, double lambda, double theta, double alpha, double beta, double tau_chi,
                         double tau_eta, int nx, int ny, double *eta1, double *eta2, int n_iter);
 
+
+/* tvl1occflow.cpp:144-481 as the reference computes it on a zero-filled heap (per-level dual state, see ofx_oracle.c) */
+void orc_tvl1occ_single_scale(const double *I_1, const double *I0, const double *I1, const double *filtI0, double *u1,
+                              double *u2, double *chi, int nx, int ny, double lambda, double alpha, double beta,
+                              double theta, int warps, double epsilon, int verbose, double *state, int *iters);
+int orc_tvl1occ_multiscale(const double *I_1, const double *I0, const double *I1, const double *filtI0, double *u1, double *u2,
+                           double *chi, int nxx, int nyy, double lambda, double alpha, double beta, double theta, int nscales,
+                           double zfactor, int warps, double epsilon, int verbose, int *iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,7 @@
 #include "brox_spatial_mask.h"
 #include "tvl1occflow_solvers.h"
 #include "tvl1occflow_tv_rof_box.h"
+#include "tvl1occflow.h"
 
 #include <cstdlib>
 #include <new>
@@ -209,46 +210,66 @@ void ref_rof_box(double *u, const double *f, double *P1, double *P2, const doubl
                  int ny, int n_iter)
 { Scalar_ROF_BoxCellCentered(u, f, P1, P2, g, lambda, omega, nx, ny, n_iter); }
 
-// One call of the reference's Solver_wrt_u (10 box-relaxation iterations per flow component).  Its dual planes are
-// function-local statics, zeroed whenever nx differs from the previous call's: `fresh` != 0 first makes a dummy call
-// with another width, so that the real call starts from p = 0; fresh == 0 continues with what the previous call left.
+// ---- the two stateful solvers ---------------------------------------------------------------------------------------
+// Solver_wrt_u keeps its four dual planes, Solver_wrt_chi its dual variable, in function-local statics that are
+// re-allocated (and thereby zeroed: Solver_wrt_u does it itself, Solver_wrt_chi through operator new[] above) only when nx
+// differs from the previous call's.  occ_reset() forces that for the NEXT call of width nx, whatever ran before: a first
+// dummy call on 2 x 2 (the smallest image: if the statics happen to be 2 wide already they hold at least 4 values), a
+// second one on a width that is neither 2 nor nx.
+static void occ_reset_u(int nx, double theta, double beta)
+{
+    double z[10 * 6] = {0};
+    for (int k = 0; k < 10; k++) z[5 * 10 + k] = 1.0;                // g = 1
+    const int w = (nx == 3) ? 5 : 3;
+    Solver_wrt_u(z, z + 10, z + 20, z + 30, z + 40, z + 50, theta, beta, 2, 2);
+    Solver_wrt_u(z, z + 10, z + 20, z + 30, z + 40, z + 50, theta, beta, w, 2);
+}
+static void occ_reset_chi(int nx)
+{
+    double z[10 * 14] = {0};
+    double *a = z;
+    const int w = (nx == 3) ? 5 : 3;
+    for (int pass = 0; pass < 2; pass++)
+        Solver_wrt_chi(a, a + 10, a + 20, a + 30, a + 40, a + 50, a + 60, a + 70, a + 80, a + 90, a + 100, a + 110, a + 120,
+                       a + 130, 0.15, 0.3, 0.01, 0.15, 0.15, 0.15, pass ? w : 2, 2);
+}
+
+// One call of the reference's Solver_wrt_u (10 box-relaxation iterations per flow component).  fresh != 0: start from
+// zero dual planes; fresh == 0: continue with what the previous call (same nx) left.
 void ref_occ_solver_u(double *u1, double *u2, const double *v1, const double *v2, const double *chi, const double *g,
                       double theta, double beta, int nx, int ny, int fresh)
 {
-    static int last_nx = 0;                      // the width the function's statics are sized for (0 = never called)
-    if (fresh) {
-        int dn = 3;
-        while (dn == nx || dn == last_nx) dn++;  // a width that forces a re-allocation now AND at the real call
-        double z[25 * 6] = {0};
-        for (int k = 0; k < 25; k++) z[5 * 25 + k] = 1.0;            // g = 1
-        Solver_wrt_u(z, z + 25, z + 50, z + 75, z + 100, z + 125, theta, beta, dn, dn);
-    }
+    if (fresh) occ_reset_u(nx, theta, beta);
     Solver_wrt_u(u1, u2, v1, v2, chi, g, theta, beta, nx, ny);
-    last_nx = nx;
 }
 
-// One call of the reference's Solver_wrt_chi (MAX_ITERATIONS_CHI = 100 iterations).  Its dual variable lives in
-// function-local statics that are re-allocated -- zero-filled, see operator new[] above -- whenever nx differs from the
-// previous call's: `fresh` != 0 first makes a dummy call with another width, so that the real call starts from eta = 0;
-// fresh == 0 continues with the eta the previous call left (same nx).
+// One call of the reference's Solver_wrt_chi (MAX_ITERATIONS_CHI = 100 iterations); fresh as above (dual variable = 0)
 void ref_occ_solver_chi(const double *u1, const double *u2, double *chi, const double *I1wx, const double *I1wy,
                         const double *I_1wx, const double *I_1wy, const double *rho1_c, const double *rho3_c,
                         const double *Vfwd_1, const double *Vfwd_2, const double *Vbck_1, const double *Vbck_2,
                         const double *g, double lambda, double theta, double alpha, double beta, double tau_chi,
                         double tau_eta, int nx, int ny, int fresh)
 {
-    static int last_nx = 0;                      // the width the function's statics are sized for (0 = never called)
-    if (fresh) {
-        int dn = 3;
-        while (dn == nx || dn == last_nx) dn++;  // a width that forces a re-allocation now AND at the real call
-        double z[25 * 14] = {0};
-        double *a = z;
-        Solver_wrt_chi(a, a + 25, a + 50, a + 75, a + 100, a + 125, a + 150, a + 175, a + 200, a + 225, a + 250, a + 275,
-                       a + 300, a + 325, lambda, theta, alpha, beta, tau_chi, tau_eta, dn, dn);
-    }
+    if (fresh) occ_reset_chi(nx);
     Solver_wrt_chi(u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, Vfwd_1, Vfwd_2, Vbck_1, Vbck_2, g, lambda, theta,
                    alpha, beta, tau_chi, tau_eta, nx, ny);
-    last_nx = nx;
+}
+
+// The whole TV-L1-with-occlusions solve (src/tvl1occflow.h): the statics of both solvers are reset first, so that the
+// coarsest level starts from zero dual state whatever ran before -- every finer level resets them itself (its width
+// differs from the previous level's).  Together with the zero-filling operator new[] this makes the reference program
+// deterministic: "what it computes on a zero-filled heap".
+void ref_tvl1occ_multiscale(const double *I_1, const double *I0, const double *I1, const double *filtI0, double *u1, double *u2,
+                            double *chi, int nxx, int nyy, double lambda, double alpha, double beta, double theta, int nscales,
+                            double zfactor, int warps, double epsilon, int verbose)
+{
+    int nxc = nxx, nyc = nyy;
+    for (int s = 1; s < nscales; s++) zoom_size(nxc, nyc, &nxc, &nyc, zfactor);
+    occ_reset_u(nxc, theta, beta);
+    occ_reset_chi(nxc);
+    Dual_TVL1_optic_flow_multiscale(const_cast<double *>(I_1), const_cast<double *>(I0), const_cast<double *>(I1),
+                                    const_cast<double *>(filtI0), u1, u2, chi, nxx, nyy, lambda, alpha, beta, theta, nscales,
+                                    zfactor, warps, epsilon, verbose != 0);
 }
 
 } // extern "C"
