@@ -303,6 +303,18 @@ int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *u2, double 
                        const double *Vbck_2, const double *g, double lambda, double theta, double alpha, double beta,
                        double tau_chi, double tau_eta, int nx, int ny, double *eta1, double *eta2, int n_iter);
 
+/* The whole TV-L1-with-occlusions solve (replaces Dual_TVL1_optic_flow_multiscale, src/tvl1occflow.h / tvl1occflow.cpp:337-481;
+ * the single-scale loop :144-329 runs on the device per level): I_1 / I0 / I1 = previous, current, next frame, filtI0 = the image
+ * g = 1 / (1 + 0.05 |grad filtI0|) is taken from (the CLI passes I0 when no smoothed image is given); u1 / u2 / chi are outputs
+ * (chi thresholded at 0.75 to {0, 1} as the reference does).  Host planes of nxx * nyy doubles; everything in between --
+ * pyramids, warps, the three sub-solvers, the median, the stopping test -- stays on the device.  Double arithmetic and storage
+ * whatever the context's precision.  The reference keeps the dual variables of Solver_wrt_u / Solver_wrt_chi in statics it
+ * allocates uninitialised once per level; this entry point implements the zero-initialised reading.
+ * ofx_get_stats: iters[scale][warp] = outer iterations, error = last L2 error. */
+int ofx_tvl1occ_multiscale(ofx_ctx *ctx, const double *I_1, const double *I0, const double *I1, const double *filtI0, double *u1,
+                           double *u2, double *chi, int nxx, int nyy, double lambda, double alpha, double beta, double theta,
+                           int nscales, double zfactor, int warps, double epsilon, int verbose);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,7 @@ def lib():
         "ofx_scalar_rof_box_cell_centered": (_i, [_vp, _dp, _dp, _dp, _dp, _dp, _d, _d, _i, _i, _i]),
         "ofx_solver_wrt_u": (_i, [_vp] + [_dp] * 6 + [_d, _d, _i, _i] + [_dp] * 4 + [_i]),
         "ofx_solver_wrt_chi": (_i, [_vp] + [_dp] * 14 + [_d] * 6 + [_i, _i, _dp, _dp, _i]),
+        "ofx_tvl1occ_multiscale": (_i, [_vp] + [_dp] * 7 + [_i, _i, _d, _d, _d, _d, _i, _d, _i, _d, _i]),
         "ofx_hs_classic": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _d]),
         "ofx_brox_temporal": (_i, [_vp, _dp, _dp, _dp, _i, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
     }
@@ -488,6 +489,16 @@ class Ofx:
         u, P1, P2 = _f64(u).copy(), _f64(P1).copy(), _f64(P2).copy()
         self._ck(self.L.ofx_scalar_rof_box_cell_centered(self.h, u, _f64(f), P1, P2, _f64(g), lam, omega, nx, ny, n_iter))
         return u, P1, P2
+
+    def tvl1occ_multiscale(self, I_1, I0, I1, filtI0=None, lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=3, zfactor=0.5,
+                           warps=2, epsilon=0.01, verbose=0):
+        """Dual_TVL1_optic_flow_multiscale with occlusions (src/tvl1occflow.h) -> (u1, u2, chi); stats() has the outer iterations"""
+        ny, nx = I0.shape
+        filtI0 = I0 if filtI0 is None else filtI0
+        u1, u2, chi = np.empty((ny, nx)), np.empty((ny, nx)), np.empty((ny, nx))
+        self._ck(self.L.ofx_tvl1occ_multiscale(self.h, _f64(I_1), _f64(I0), _f64(I1), _f64(filtI0), u1, u2, chi, nx, ny, lam, alpha,
+                                               beta, theta, nscales, zfactor, warps, epsilon, verbose))
+        return u1, u2, chi
 
     def occ_solver_u(self, v1, v2, chi, g, theta, beta, p=None, n_iter=10):
         """Solver_wrt_u with the four dual planes as explicit state -> (u1, u2, [p11, p12, p21, p22]); p defaults to zero"""

@@ -551,9 +551,13 @@ OFX_DEV void rof_cell(const RofArr &a, int ci, int cj, double w)
     }
 }
 
-// K steps [tau0, tau0 + K) of every row block of one sweep
-__global__ __launch_bounds__(128) void k_rof_window(RofArr a, int tau0, double w)
+// K steps [tau0, tau0 + K) of every row block of one sweep; blockIdx.y = which of the (independent) problems
+struct RofSet {
+    RofArr a[2];
+};
+__global__ __launch_bounds__(128) void k_rof_window(RofSet s, int tau0, double w)
 {
+    const RofArr &a = s.a[blockIdx.y];
     const int b = blockIdx.x, ci = b * ROF_R + (int) threadIdx.x;
     const int qmax = 2 * (a.ny - 1) + a.nx - 1;
     const int q_first = tau0 - ROF_K * b;
@@ -576,46 +580,56 @@ __global__ void k_rof_fdiff(const double *__restrict__ f, double *__restrict__ F
     Fe[c] = (j < nx - 1) ? f[c + 1] - f[c] : 0.0;
 }
 // alfa = hypot(forward gradient of u) / (lambda g) with the file-local hypot = sqrt(x x + y y), :15-20,173-187
-__global__ void k_rof_alfa(const double *__restrict__ u, const double *__restrict__ g, double *__restrict__ AL, int nx, int ny,
-                           double lambda)
+struct RofPt {
+    const double *u[2], *f[2], *Ps[2], *Pe[2];
+    double *AL[2], *uo[2];
+};
+__global__ void k_rof_alfa(RofPt a, const double *__restrict__ g, int nx, int ny, double lambda)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
     if (j >= nx || i >= ny) return;
     const size_t c = (size_t) i * nx + j;
+    const double *u = a.u[k];
     const double ux = (j < nx - 1) ? u[c + 1] - u[c] : 0.0, uy = (i < ny - 1) ? u[c + nx] - u[c] : 0.0;
-    AL[c] = sqrt(ux * ux + uy * uy) / (lambda * g[c]);
+    a.AL[k][c] = sqrt(ux * ux + uy * uy) / (lambda * g[c]);
 }
 // u = lambda f + lambda (P_south - P_north + P_east - P_west), :616-640
-__global__ void k_rof_u(const double *__restrict__ f, const double *__restrict__ Ps, const double *__restrict__ Pe,
-                        double *__restrict__ u, int nx, int ny, double lambda)
+__global__ void k_rof_u(RofPt a, int nx, int ny, double lambda)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
     if (j >= nx || i >= ny) return;
     const size_t c = (size_t) i * nx + j;
+    const double *Ps = a.Ps[k], *Pe = a.Pe[k];
     const double pn = i > 0 ? Ps[c - nx] : 0.0, pw = j > 0 ? Pe[c - 1] : 0.0;
-    u[c] = lambda * f[c] + lambda * (Ps[c] - pn + Pe[c] - pw);
+    a.uo[k][c] = lambda * a.f[k][c] + lambda * (Ps[c] - pn + Pe[c] - pw);
 }
 
-// device arrays in place: u (in: seed, out: result), Ps / Pe (in/out state)
-static int rof_box_dev(ofx_ctx *ctx, double *u, const double *f, double *Ps, double *Pe, const double *g, double lambda,
-                       double omega, int nx, int ny, int n_iter)
+// nc = 1 | 2 independent problems sharing g, lambda and the size (the two flow components of Solver_wrt_u), every launch
+// serving both.  Device arrays in place: u[k] (in: seed, out: result), Ps[k] / Pe[k] (in/out state); scratch = 3 nc planes.
+static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *const *f, double *const *Ps, double *const *Pe,
+                       const double *g, double lambda, double omega, int nx, int ny, int n_iter, double *scratch)
 {
     const size_t n = (size_t) nx * ny;
-    double *Fs, *Fe, *AL;
-    OFX_TRY(ofx_alloc(ctx, n, &Fs));
-    OFX_TRY(ofx_alloc(ctx, n, &Fe));
-    OFX_TRY(ofx_alloc(ctx, n, &AL));
-    const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), block(64, 4);
-    hipLaunchKernelGGL(k_rof_fdiff, grid, block, 0, ctx->stream, f, Fs, Fe, nx, ny);
-    OFX_LAUNCH_CHECK(ctx);
-    const RofArr a = {Ps, Pe, Fs, Fe, AL, nx, ny};
+    const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), nc), block(64, 4);
+    RofSet set;
+    RofPt pt;
+    for (int k = 0; k < 2; k++) {
+        const int c = k < nc ? k : 0;
+        double *Fs = scratch + (3 * c) * n, *Fe = scratch + (3 * c + 1) * n, *AL = scratch + (3 * c + 2) * n;
+        if (k < nc) {
+            hipLaunchKernelGGL(k_rof_fdiff, dim3(grid.x, grid.y), block, 0, ctx->stream, f[c], Fs, Fe, nx, ny);
+            OFX_LAUNCH_CHECK(ctx);
+        }
+        set.a[k] = RofArr{Ps[c], Pe[c], Fs, Fe, AL, nx, ny};
+        pt.u[k] = u[c]; pt.f[k] = f[c]; pt.Ps[k] = Ps[c]; pt.Pe[k] = Pe[c]; pt.AL[k] = AL; pt.uo[k] = u[c];
+    }
     const int B = ofx_cdiv(ny, ROF_R), qmax = 2 * (ny - 1) + nx - 1;
     const long total = (long) qmax + 1 + (long) ROF_K * (B - 1);
     for (int it = 0; it < n_iter; it++) {
-        hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, (const double *) u, g, AL, nx, ny, lambda);
+        hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
         for (long tau0 = 0; tau0 < total; tau0 += ROF_K)
-            hipLaunchKernelGGL(k_rof_window, dim3(B), dim3(128), 0, ctx->stream, a, (int) tau0, omega);
-        hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, f, (const double *) Ps, (const double *) Pe, u, nx, ny, lambda);
+            hipLaunchKernelGGL(k_rof_window, dim3(B, nc), dim3(128), 0, ctx->stream, set, (int) tau0, omega);
+        hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, pt, nx, ny, lambda);
         OFX_LAUNCH_CHECK(ctx);
     }
     return OFX_OK;
@@ -637,7 +651,10 @@ extern "C" int ofx_scalar_rof_box_cell_centered(ofx_ctx *ctx, double *u, const d
     OFX_TRY(d.in(initialP1, &dp1, n));
     OFX_TRY(d.in(initialP2, &dp2, n));
     OFX_TRY(d.in(g_function, &dg, n));
-    OFX_TRY(rof_box_dev(ctx, du, df, dp1, dp2, dg, lambda, omega, nx, ny, nIter));
+    double *scratch;
+    OFX_TRY(ofx_alloc(ctx, 3 * n, &scratch));
+    const double *fs[1] = {df};
+    OFX_TRY(rof_box_dev(ctx, 1, &du, fs, &dp1, &dp2, dg, lambda, omega, nx, ny, nIter, scratch));
     OFX_TRY(d.out(du, u, n));
     OFX_TRY(d.out(dp1, initialP1, n));
     OFX_TRY(d.out(dp2, initialP2, n));
@@ -684,10 +701,320 @@ extern "C" int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const doub
     hipLaunchKernelGGL(k_occ_u_init, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, (const double *) dv1,
                        (const double *) dv2, (const double *) dchi, f1, f2, du1, du2, nx, ny, theta, beta);
     OFX_LAUNCH_CHECK(ctx);
-    OFX_TRY(rof_box_dev(ctx, du1, f1, dp[0], dp[1], dg, theta, OCC_OMEGA, nx, ny, n_iter));
-    OFX_TRY(rof_box_dev(ctx, du2, f2, dp[2], dp[3], dg, theta, OCC_OMEGA, nx, ny, n_iter));
+    double *scratch;
+    OFX_TRY(ofx_alloc(ctx, 6 * n, &scratch));
+    double *us[2] = {du1, du2}, *ps[2] = {dp[0], dp[2]}, *pe[2] = {dp[1], dp[3]};
+    const double *fs[2] = {f1, f2};
+    OFX_TRY(rof_box_dev(ctx, 2, us, fs, ps, pe, dg, theta, OCC_OMEGA, nx, ny, n_iter, scratch));
     OFX_TRY(d.out(du1, u1, n));
     OFX_TRY(d.out(du2, u2, n));
     for (int k = 0; k < 4; k++) OFX_TRY(d.out(dp[k], hp[k], n));
     return d.sync();
+}
+
+// ==== TV-L1 with occlusions, the whole solve (src/tvl1occflow.cpp:144-329 single scale, :337-481 multiscale) ===================
+// Device-resident from the four uploaded images to the three downloaded planes.  The reference keeps the dual planes of
+// Solver_wrt_u and the dual variable of Solver_wrt_chi in function-local statics that it re-creates -- with operator
+// new[], uninitialised -- whenever the image width changes, i.e. once per pyramid level; its results are therefore only
+// defined on a heap that hands out zeros.  That is the semantics implemented here (state zeroed per level) and pinned by
+// the oracle against the reference built with a zero-filling operator new[] (oracle/ref_shim.cpp).
+#define OCC_EXT_MAX_ITERATIONS 20  // src/tvl1occflow_constants.h:35
+#define OCC_MAX_ITERATIONS_CHI 100 // :37
+#define OCC_MAX_ITERATIONS_U 10    // :36
+#define OCC_G_FACTOR 0.05          // :30
+#define OCC_TAU_ETA 0.15           // :26
+#define OCC_TAU_CHI 0.15           // :27
+#define OCC_PRESMOOTHING_SIGMA 0.8 // :34
+#define OCC_ERR_BLOCKS 256
+
+// g = 1 / (1 + G_FACTOR |grad filtI0|), choosed_g choice 2 (:96-133); Ix, Iy = centred gradient
+__global__ void k_occ_g(const double *__restrict__ Ix, const double *__restrict__ Iy, double *__restrict__ g, int size)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    const double gggrad = sqrt(Ix[i] * Ix[i] + Iy[i] * Iy[i]);
+    g[i] = 1. / (1. + OCC_G_FACTOR * gggrad);
+}
+
+// the six warps of one warping step and what is derived from them (:214-248), one thread per pixel: I1, I1x, I1y sampled at
+// x + u, I_1, I_1x, I_1y at x - u (border_out = false), grad = |warped gradient|^2, rho_c = the constant part of the
+// linearised residual.  The warped intensities themselves are not used again and stay in registers.
+struct OccPrep {
+    const double *I0, *I1, *I1x, *I1y, *I_1, *I_1x, *I_1y, *u1, *u2;
+    double *I1wx, *I1wy, *I_1wx, *I_1wy, *grad1, *grad3, *rho1_c, *rho3_c;
+};
+OFX_DEV double occ_sample(const double *__restrict__ in, const BicubicTaps &t, int nx)
+{
+    double c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        c[q] = cubic_cell(in[(size_t) t.row[0] * nx + t.col[q]], in[(size_t) t.row[1] * nx + t.col[q]],
+                          in[(size_t) t.row[2] * nx + t.col[q]], in[(size_t) t.row[3] * nx + t.col[q]], t.fy);
+    return cubic_cell(c[0], c[1], c[2], c[3], t.fx);
+}
+__global__ void k_occ_prepare(OccPrep a, int nx, int ny)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t p = (size_t) i * nx + j;
+    const double u1 = a.u1[p], u2 = a.u2[p], i0 = a.I0[p];
+    {
+        const BicubicTaps t = bicubic_taps(j + u1, i + u2, nx, ny);
+        const double w = occ_sample(a.I1, t, nx), wx = occ_sample(a.I1x, t, nx), wy = occ_sample(a.I1y, t, nx);
+        a.I1wx[p] = wx;
+        a.I1wy[p] = wy;
+        a.grad1[p] = (wx * wx + wy * wy);
+        a.rho1_c[p] = (w - wx * u1 - wy * u2 - i0);
+    }
+    {
+        const BicubicTaps t = bicubic_taps(j + (-u1), i + (-u2), nx, ny);
+        const double w = occ_sample(a.I_1, t, nx), wx = occ_sample(a.I_1x, t, nx), wy = occ_sample(a.I_1y, t, nx);
+        a.I_1wx[p] = wx;
+        a.I_1wy[p] = wy;
+        a.grad3[p] = (wx * wx + wy * wy);
+        a.rho3_c[p] = (w + wx * u1 + wy * u2 - i0);
+    }
+}
+
+// 3 x 3 median of both flow components in one launch (blockIdx.z)
+__global__ void k_median3_pair(const double *__restrict__ in0, const double *__restrict__ in1, double *__restrict__ out0,
+                               double *__restrict__ out1, int nx, int ny)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= nx || y >= ny) return;
+    const double *in = blockIdx.z ? in1 : in0;
+    double *out = blockIdx.z ? out1 : out0;
+    double win[9];
+    int n = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            int x0 = x + dx, y0 = y + dy;
+            if (x0 < 0) x0 = -x0 - 1;
+            if (x0 >= nx) x0 = 2 * nx - x0 - 1;
+            if (y0 < 0) y0 = -y0 - 1;
+            if (y0 >= ny) y0 = 2 * ny - y0 - 1;
+            win[n++] = in[(size_t) y0 * nx + x0];
+        }
+#pragma unroll
+    for (int a = 0; a <= 4; a++) {
+#pragma unroll
+        for (int b = a + 1; b < 9; b++) {
+            const double lo = fmin(win[a], win[b]), hi = fmax(win[a], win[b]);
+            win[a] = lo;
+            win[b] = hi;
+        }
+    }
+    out[(size_t) y * nx + x] = win[4];
+}
+
+// L2error (:62-80): sum of the squared change of (u1, u2), fixed summation tree (block partials, then one block); the
+// previous-iterate planes are refreshed in the same pass
+__global__ __launch_bounds__(256) void k_occ_err_partial(const double *__restrict__ u1, const double *__restrict__ u2,
+                                                         double *__restrict__ u1p, double *__restrict__ u2p, int size,
+                                                         double *__restrict__ part)
+{
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < (size_t) size; i += (size_t) OCC_ERR_BLOCKS * 256) {
+        const double a = u1[i], b = u2[i], d1 = a - u1p[i], d2 = b - u2p[i];
+        acc += d1 * d1 + d2 * d2;
+        u1p[i] = a;
+        u2p[i] = b;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int) threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void k_occ_err_final(const double *__restrict__ part, double *__restrict__ out)
+{
+    __shared__ double sh[256];
+    sh[threadIdx.x] = threadIdx.x < OCC_ERR_BLOCKS ? part[threadIdx.x] : 0.0;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int) threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+__global__ void k_occ_scale2(double *__restrict__ a, double *__restrict__ b, size_t n, double s)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        a[i] *= s;
+        b[i] *= s;
+    }
+}
+__global__ void k_occ_threshold(double *__restrict__ chi, size_t n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) chi[i] = (chi[i] > OCC_THR_CHI);
+}
+
+namespace {
+
+struct OccParams {
+    double lambda, alpha, beta, theta, epsilon;
+    int warps, verbose;
+};
+// work planes of a solve, allocated once at the finest level's size
+struct OccWork {
+    double *I1x, *I1y, *I_1x, *I_1y, *I1wx, *I1wy, *I_1wx, *I_1wy, *rho1_c, *rho3_c, *grad1, *grad3, *v1, *v2, *vf1, *vf2, *vb1,
+        *vb2, *g, *u1p, *u2p, *f1, *f2, *t1, *t2, *divu, *state, *rof, *part;
+    int alloc(ofx_ctx *ctx, size_t n)
+    {
+        double **planes[] = {&I1x, &I1y, &I_1x, &I_1y, &I1wx, &I1wy, &I_1wx, &I_1wy, &rho1_c, &rho3_c, &grad1, &grad3, &v1,
+                             &v2, &vf1, &vf2, &vb1, &vb2, &g, &u1p, &u2p, &f1, &f2, &t1, &t2, &divu};
+        for (auto p : planes) OFX_TRY(ofx_alloc(ctx, n, p));
+        OFX_TRY(ofx_alloc(ctx, 6 * n, &state));
+        OFX_TRY(ofx_alloc(ctx, 6 * n, &rof));
+        return ofx_alloc(ctx, OCC_ERR_BLOCKS + 1, &part);
+    }
+};
+
+// one level, arrays on the device, u1 / u2 / chi in place; the level's dual state is zeroed here
+int occ_single_scale_dev(ofx_ctx *ctx, const double *I_1, const double *I0, const double *I1, const double *filtI0, double *u1,
+                         double *u2, double *chi, int nx, int ny, const OccParams &P, const OccWork &W, int scale)
+{
+    const size_t n = (size_t) nx * ny;
+    const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), block(64, 4);
+    const int g1 = occ_grid1d(n);
+    hipStream_t st = ctx->stream;
+    OFX_HIP(ctx, hipMemsetAsync(W.state, 0, 6 * n * sizeof(double), st));
+    double *eta1 = W.state + 4 * n, *eta2 = W.state + 5 * n;
+    OFX_TRY(op_centered_gradient<double>(ctx, filtI0, W.t1, W.t2, nx, ny));
+    hipLaunchKernelGGL(k_occ_g, dim3(g1), dim3(256), 0, st, (const double *) W.t1, (const double *) W.t2, W.g, (int) n);
+    OFX_TRY(op_centered_gradient<double>(ctx, I1, W.I1x, W.I1y, nx, ny));
+    OFX_TRY(op_centered_gradient<double>(ctx, I_1, W.I_1x, W.I_1y, nx, ny));
+    OFX_HIP(ctx, hipMemcpyAsync(W.u1p, u1, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    OFX_HIP(ctx, hipMemcpyAsync(W.u2p, u2, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    const OccPrep prep = {I0, I1, W.I1x, W.I1y, I_1, W.I_1x, W.I_1y, u1, u2, W.I1wx, W.I1wy, W.I_1wx, W.I_1wy, W.grad1, W.grad3,
+                          W.rho1_c, W.rho3_c};
+    const OccV av = {u1, u2, chi, W.I1wx, W.I1wy, W.I_1wx, W.I_1wy, W.rho1_c, W.rho3_c, W.grad1, W.grad3,
+                     W.v1, W.v2, W.vf1, W.vf2, W.vb1, W.vb2};
+    const OccChi ac = {u1, u2, W.I1wx, W.I1wy, W.I_1wx, W.I_1wy, W.rho1_c, W.rho3_c, W.vf1, W.vf2, W.vb1, W.vb2, W.g, eta1, eta2,
+                       W.divu, chi};
+    double *us[2] = {u1, u2}, *ps[2] = {W.state, W.state + 2 * n}, *pe[2] = {W.state + n, W.state + 3 * n};
+    const double *fs[2] = {W.f1, W.f2};
+    double *h_err = reinterpret_cast<double *>(ctx->h_state);        // pinned
+    for (int w = 0; w < P.warps; w++) {
+        hipLaunchKernelGGL(k_occ_prepare, grid, block, 0, st, prep, nx, ny);
+        OFX_LAUNCH_CHECK(ctx);
+        int it = 0;
+        double error = INFINITY;
+        while (error > P.epsilon && it < OCC_EXT_MAX_ITERATIONS) {
+            it++;
+            hipLaunchKernelGGL(k_occ_v, dim3(g1), dim3(256), 0, st, av, (int) n, P.alpha, P.theta, P.lambda);
+            hipLaunchKernelGGL(k_occ_u_init, grid, block, 0, st, (const double *) W.v1, (const double *) W.v2, (const double *) chi,
+                               W.f1, W.f2, u1, u2, nx, ny, P.theta, P.beta);
+            OFX_LAUNCH_CHECK(ctx);
+            OFX_TRY(rof_box_dev(ctx, 2, us, fs, ps, pe, W.g, P.theta, OCC_OMEGA, nx, ny, OCC_MAX_ITERATIONS_U, W.rof));
+            hipLaunchKernelGGL(k_median3_pair, dim3(grid.x, grid.y, 2), block, 0, st, (const double *) u1, (const double *) u2, W.t1,
+                               W.t2, nx, ny);
+            OFX_HIP(ctx, hipMemcpyAsync(u1, W.t1, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            OFX_HIP(ctx, hipMemcpyAsync(u2, W.t2, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_occ_divu, grid, block, 0, st, (const double *) u1, (const double *) u2, W.divu, nx, ny);
+            for (int k = 0; k < OCC_MAX_ITERATIONS_CHI; k++) {
+                hipLaunchKernelGGL(k_occ_eta, grid, block, 0, st, (const double *) chi, (const double *) W.g, eta1, eta2, nx, ny,
+                                   OCC_TAU_ETA);
+                hipLaunchKernelGGL(k_occ_chi, grid, block, 0, st, ac, nx, ny, P.lambda, P.theta, P.alpha, P.beta, OCC_TAU_CHI);
+            }
+            hipLaunchKernelGGL(k_occ_err_partial, dim3(OCC_ERR_BLOCKS), dim3(256), 0, st, (const double *) u1, (const double *) u2,
+                               W.u1p, W.u2p, (int) n, W.part);
+            hipLaunchKernelGGL(k_occ_err_final, dim3(1), dim3(256), 0, st, (const double *) W.part, W.part + OCC_ERR_BLOCKS);
+            OFX_LAUNCH_CHECK(ctx);
+            OFX_HIP(ctx, hipMemcpyAsync(h_err, W.part + OCC_ERR_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, st));
+            OFX_HIP(ctx, hipStreamSynchronize(st));
+            error = *h_err / (int) n;
+        }
+        if (P.verbose) fprintf(stderr, "Warping: %d, Iterations: %d, Error: %e\n", w, it, error);     // :292-296
+        ofx_stats &S = ctx->stats;
+        if (scale < OFX_MAX_SCALES && w < OFX_MAX_SOLVES) {
+            S.iters[scale][w] = it;
+            S.error[scale][w] = error;
+        }
+        S.work_pix_iters += (double) it * (double) n;
+    }
+    return OFX_OK;
+}
+
+}   // namespace
+
+extern "C" int ofx_tvl1occ_multiscale(ofx_ctx *ctx, const double *I_1, const double *I0, const double *I1, const double *filtI0,
+                                      double *u1, double *u2, double *chi, int nxx, int nyy, double lambda, double alpha,
+                                      double beta, double theta, int nscales, double zfactor, int warps, double epsilon,
+                                      int verbose)
+{
+    OFX_ENTER(ctx);
+    if (!I_1 || !I0 || !I1 || !filtI0 || !u1 || !u2 || !chi) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: NULL pointer");
+    if (nxx < 2 || nyy < 2 || (long long) nxx * nyy > 0x3fffffffLL) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: bad size %dx%d", nxx, nyy);
+    if (nscales < 1 || warps < 1 || warps > OFX_MAX_SOLVES) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: nscales=%d warps=%d", nscales, warps);
+    if (!(zfactor > 0.0 && zfactor < 1.0)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: zfactor=%g", zfactor);
+    if (!(theta > 0.0) || !(lambda > 0.0)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: theta=%g lambda=%g", theta, lambda);
+    const double t0 = ofx_now_ms();
+    std::vector<int> nxs, nys;
+    OFX_TRY(op_pyramid_sizes(ctx, nxx, nyy, nscales, zfactor, nxs, nys));
+    if (nxs[nscales - 1] < 2 || nys[nscales - 1] < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: coarsest level %dx%d", nxs[nscales - 1], nys[nscales - 1]);
+    ofx_stats &S = ctx->stats;
+    S = ofx_stats{};
+    S.nscales = nscales;
+    S.nsolves = warps;
+    for (int s = 0; s < nscales && s < OFX_MAX_SCALES; s++) { S.nx[s] = nxs[s]; S.ny[s] = nys[s]; }
+    const OccParams P = {lambda, alpha, beta, theta, epsilon, warps, verbose};
+    const size_t size = (size_t) nxx * nyy;
+    OccWork W;
+    OFX_TRY(W.alloc(ctx, size));
+    struct Lv { double *im[4], *u1, *u2, *chi; };           // im: I_1, I0, I1, filtI0
+    std::vector<Lv> lv(nscales);
+    for (int s = 0; s < nscales; s++) {
+        const size_t n = (size_t) nxs[s] * nys[s];
+        for (int k = 0; k < 4; k++) OFX_TRY(ofx_alloc(ctx, n, &lv[s].im[k]));
+        OFX_TRY(ofx_alloc(ctx, n, &lv[s].u1));
+        OFX_TRY(ofx_alloc(ctx, n, &lv[s].u2));
+        OFX_TRY(ofx_alloc(ctx, n, &lv[s].chi));
+    }
+    hipStream_t st = ctx->stream;
+    // :382-395 call image_normalization_4 and then overwrite its output with the raw images: no normalisation
+    const double *host[4] = {I_1, I0, I1, filtI0};
+    for (int k = 0; k < 4; k++) {
+        OFX_HIP(ctx, hipMemcpyAsync(lv[0].im[k], host[k], size * sizeof(double), hipMemcpyHostToDevice, st));
+        OFX_TRY(op_gaussian<double>(ctx, lv[0].im[k], W.t1, nxx, nyy, OCC_PRESMOOTHING_SIGMA));
+    }
+    for (int s = 1; s < nscales; s++)
+        for (int k = 0; k < 4; k++)
+            OFX_TRY(op_zoom_out<double>(ctx, lv[s - 1].im[k], lv[s].im[k], W.t1, W.t2, nxs[s - 1], nys[s - 1], zfactor));
+    {
+        const size_t n = (size_t) nxs[nscales - 1] * nys[nscales - 1];
+        OFX_HIP(ctx, hipMemsetAsync(lv[nscales - 1].u1, 0, n * sizeof(double), st));
+        OFX_HIP(ctx, hipMemsetAsync(lv[nscales - 1].u2, 0, n * sizeof(double), st));
+        OFX_HIP(ctx, hipMemsetAsync(lv[nscales - 1].chi, 0, n * sizeof(double), st));
+    }
+    for (int s = nscales - 1; s >= 0; s--) {
+        if (verbose) fprintf(stderr, "Scale %d: %dx%d\n", s, nxs[s], nys[s]);
+        OFX_TRY(occ_single_scale_dev(ctx, lv[s].im[0], lv[s].im[1], lv[s].im[2], lv[s].im[3], lv[s].u1, lv[s].u2, lv[s].chi, nxs[s],
+                                     nys[s], P, W, s));
+        if (s) {
+            const double fx = (double) nxs[s - 1] / nxs[s], fy = (double) nys[s - 1] / nys[s];
+            const size_t n = (size_t) nxs[s - 1] * nys[s - 1];
+            OFX_TRY(op_resample<double>(ctx, lv[s].u1, lv[s - 1].u1, nxs[s], nys[s], nxs[s - 1], nys[s - 1], fx, fy));
+            OFX_TRY(op_resample<double>(ctx, lv[s].u2, lv[s - 1].u2, nxs[s], nys[s], nxs[s - 1], nys[s - 1], fx, fy));
+            OFX_TRY(op_resample<double>(ctx, lv[s].chi, lv[s - 1].chi, nxs[s], nys[s], nxs[s - 1], nys[s - 1], fx, fy));
+            hipLaunchKernelGGL(k_occ_scale2, dim3(occ_grid1d(n)), dim3(256), 0, st, lv[s - 1].u1, lv[s - 1].u2, n, (double) 1.0 / zfactor);
+        } else {
+            hipLaunchKernelGGL(k_occ_threshold, dim3(occ_grid1d(size)), dim3(256), 0, st, lv[0].chi, size);
+        }
+        OFX_LAUNCH_CHECK(ctx);
+    }
+    Dev d{ctx};
+    OFX_TRY(d.out(lv[0].u1, u1, size));
+    OFX_TRY(d.out(lv[0].u2, u2, size));
+    OFX_TRY(d.out(lv[0].chi, chi, size));
+    OFX_TRY(d.sync());
+    S.total_ms = ofx_now_ms() - t0;
+    return OFX_OK;
 }

@@ -101,3 +101,24 @@ def test_rof_box_and_solver_wrt_u_bitexact(gpu64, ofx_mod, orc, nx, ny):
     if (nx, ny) == (2, 2):
         with pytest.raises(ofx_mod.OfxError):
             gpu64.rof_box(np.zeros((1, 5)), np.zeros((1, 5)), np.zeros((1, 5)), np.zeros((1, 5)), np.ones((1, 5)), 0.3, 1.25, 1)
+
+
+def test_tvl1occ_multiscale(gpu64, synth, orc):
+    """the whole TV-L1-with-occlusions solve, device resident, against the oracle (itself pinned against the compiled reference
+    in tests/test_oracle_vs_ref.py): same outer-iteration table, flows and occlusion map bit-identical"""
+    for nx, ny, ns, warps in ((64, 48, 2, 2), (90, 70, 3, 1), (160, 120, 3, 2)):
+        seq = synth.sequence(nx, ny, 3, 1)
+        kw = dict(lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=ns, zfactor=0.5, warps=warps, epsilon=0.01)
+        uo, vo, co, it = orc.tvl1occ_multiscale(seq[0], seq[1], seq[2], **kw)
+        u, v, c = gpu64.tvl1occ_multiscale(seq[0], seq[1], seq[2], **kw)
+        st = gpu64.stats()
+        got = np.array([[st.iters[s][w] for w in range(warps)] for s in range(ns)])
+        assert np.array_equal(got, it), (nx, ny, got, it)
+        assert np.array_equal(u, uo) and np.array_equal(v, vo) and np.array_equal(c, co), (nx, ny, np.abs(u - uo).max())
+
+
+def test_tvl1occ_arguments(gpu64, ofx_mod):
+    z = np.zeros((16, 16))
+    for kw in (dict(nscales=0), dict(warps=0), dict(zfactor=1.0), dict(theta=0.0), dict(nscales=9)):
+        with pytest.raises(ofx_mod.OfxError):
+            gpu64.tvl1occ_multiscale(z, z, z, **kw)
