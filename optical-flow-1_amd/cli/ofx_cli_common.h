@@ -27,7 +27,7 @@ static ofx_ctx *cli_context(void)
 /* ---- positional, optional, silently-corrected arguments ----------------------------------------------------------------
  * All the reference's front-ends read their options the same way: positional, every trailing one optional, a value
  * outside its range is replaced (by the default, or by a given substitute) instead of rejected -- with a warning on
- * stderr only in tvl1flow and only when `verbose` (the LAST option) is set (src/tvl1flow_main.cpp:97-167,
+ * stderr only in tvl1flow (when `verbose`, the LAST option, is set) and tvl1occflow (always) (src/tvl1flow_main.cpp:97-167,
  * src/horn_schunck_pyramidal_main.cpp:93-118, src/brox_spatial_main.cpp:102-142, src/brox_temporal_main.cpp:141-177).
  * One table per program (name, kind, default, range test, substitute, warning format) drives one parser. */
 enum { CLI_INT, CLI_REAL, CLI_TEXT };
@@ -36,7 +36,8 @@ enum {                         /* when is the value out of range? */
     CLI_LE0 = 1,               /* value <= 0 */
     CLI_LT0 = 2,               /* value <  0 */
     CLI_GE1 = 4,               /* value >= 1            (may be combined with CLI_LE0) */
-    CLI_GT_QUARTER = 8         /* value > 0.25          (tvl1flow's tau) */
+    CLI_GT_QUARTER = 8,        /* value > 0.25          (tvl1flow's tau) */
+    CLI_WARN_ALWAYS = 16       /* the warning does not depend on `verbose` (tvl1occflow, all rows but theta) */
 };
 typedef struct {
     const char *name;
@@ -70,7 +71,7 @@ __attribute__((unused)) static void cli_parse(int argc, char *argv[], int first,
         const int high = ((opt[k].bad & CLI_GE1) && v >= 1) || ((opt[k].bad & CLI_GT_QUARTER) && v > 0.25);
         if (!low && !high) continue;
         out[k].num = (!low && high && opt[k].ge1_value != 0) ? opt[k].ge1_value : opt[k].def;
-        if (verbose && opt[k].warn) {
+        if ((verbose || (opt[k].bad & CLI_WARN_ALWAYS)) && opt[k].warn) {
             if (opt[k].kind == CLI_INT) fprintf(stderr, opt[k].warn, (int) out[k].num);
             else fprintf(stderr, opt[k].warn, out[k].num);
         }

@@ -3,6 +3,7 @@
 
 #include <ctype.h>
 #include <dlfcn.h>
+#include <math.h>
 #include <setjmp.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -107,6 +108,12 @@ struct ofx_png_api {
     unsigned char (*get_bit_depth)(const ofx_png_struct *, const ofx_png_info *);
     unsigned char **(*get_rows)(const ofx_png_struct *, const ofx_png_info *);
     void (*destroy_read_struct)(ofx_png_struct **, ofx_png_info **, ofx_png_info **);
+    /* writer */
+    ofx_png_struct *(*create_write_struct)(const char *, void *, void *, void *);
+    void (*set_IHDR)(const ofx_png_struct *, ofx_png_info *, uint32_t, uint32_t, int, int, int, int, int);
+    void (*set_rows)(const ofx_png_struct *, ofx_png_info *, unsigned char **);
+    void (*write_png)(ofx_png_struct *, ofx_png_info *, int, void *);
+    void (*destroy_write_struct)(ofx_png_struct **, ofx_png_info **);
 };
 
 static const struct ofx_png_api *png_api(void)
@@ -135,6 +142,11 @@ static const struct ofx_png_api *png_api(void)
     OFX_PNG_SYM(get_bit_depth, "png_get_bit_depth");
     OFX_PNG_SYM(get_rows, "png_get_rows");
     OFX_PNG_SYM(destroy_read_struct, "png_destroy_read_struct");
+    OFX_PNG_SYM(create_write_struct, "png_create_write_struct");
+    OFX_PNG_SYM(set_IHDR, "png_set_IHDR");
+    OFX_PNG_SYM(set_rows, "png_set_rows");
+    OFX_PNG_SYM(write_png, "png_write_png");
+    OFX_PNG_SYM(destroy_write_struct, "png_destroy_write_struct");
 #undef OFX_PNG_SYM
     state = 1;
     return &api;
@@ -213,6 +225,75 @@ double *ofx_read_image_double(const char *fname, int *w, int *h)
     }
     free(data);
     return out;
+}
+
+/* 8-bit gray PNG with libpng's defaults, as iio_save_image_as_png writes it (iio.cpp:2539-2606: png_set_IHDR(8, GRAY, no
+ * interlace), png_set_rows, png_write_png(PNG_TRANSFORM_IDENTITY)) -- the same bytes when both sides use the same libpng */
+static int write_png_gray8(const char *fname, const uint8_t *data, int w, int h)
+{
+    const struct ofx_png_api *P = png_api();
+    if (!P) {
+        fprintf(stderr, "PNG output needs libpng16.so.16 at run time (not found)\n");
+        return 1;
+    }
+    FILE *f = fopen(fname, "wb");
+    if (!f) return 1;
+    ofx_png_struct *pp = P->create_write_struct(P->get_libpng_ver(NULL), NULL, NULL, NULL);
+    ofx_png_info *pi = pp ? P->create_info_struct(pp) : NULL;
+    unsigned char **volatile rows = NULL;
+    int rc = 1;
+    if (pp && pi) {
+        jmp_buf *jb = P->set_longjmp_fn(pp, longjmp, sizeof(jmp_buf));
+        if (jb && !setjmp(*jb)) {
+            rows = (unsigned char **) malloc((size_t) h * sizeof(*rows));
+            if (rows) {
+                for (int i = 0; i < h; i++) rows[i] = (unsigned char *) data + (size_t) i * w;
+                P->init_io(pp, f);
+                P->set_IHDR(pp, pi, (uint32_t) w, (uint32_t) h, 8, 0 /* GRAY */, 0 /* no interlace */, 0, 0);
+                P->set_rows(pp, pi, rows);
+                P->write_png(pp, pi, 0 /* PNG_TRANSFORM_IDENTITY */, NULL);
+                rc = 0;
+            }
+        }
+    }
+    if (pp) P->destroy_write_struct(&pp, pi ? &pi : NULL);
+    free(rows);
+    if (fclose(f)) rc = 1;
+    return rc;
+}
+
+/* iio_save_image_float for a one-channel image whose samples are all integers in [0, 255] ("these floats are actually
+ * bytes", iio.cpp:3620-3636,3698-3710: converted to uint8 first): .png / .PNG -> 8-bit gray PNG (:3752-3773), any other
+ * name -> PGM, ASCII P2 up to 10000 pixels and binary P5 above (:3838-3853).  TIFF names and images with other sample
+ * values (which the reference would send through its sample conversion or libtiff) are refused: returns 2. */
+int ofx_write_gray_bytes(const char *fname, const float *x, int w, int h)
+{
+    const size_t n = (size_t) w * h;
+    if (ofx_has_suffix(fname, ".tiff") || ofx_has_suffix(fname, ".tif") || ofx_has_suffix(fname, ".TIFF") ||
+        ofx_has_suffix(fname, ".TIF") || !strncmp(fname, "TIFF:", 5))
+        return 2;
+    for (size_t i = 0; i < n; i++)
+        if (!(x[i] == floorf(x[i]) && x[i] >= 0 && x[i] < 256)) return 2;
+    uint8_t *b = (uint8_t *) malloc(n ? n : 1);
+    if (!b) return 1;
+    for (size_t i = 0; i < n; i++) b[i] = (uint8_t) x[i];
+    int rc;
+    if (!strncmp(fname, "PNG:", 4)) rc = write_png_gray8(fname + 4, b, w, h);
+    else if (ofx_has_suffix(fname, ".png") || ofx_has_suffix(fname, ".PNG")) rc = write_png_gray8(fname, b, w, h);
+    else {
+        FILE *f = fopen(fname, "w");
+        rc = f ? 0 : 1;
+        if (f && n <= 10000) {
+            fprintf(f, "P2\n%d %d\n255\n", w, h);
+            for (size_t i = 0; i < n; i++) fprintf(f, "%d\n", (int) b[i]);
+        } else if (f) {
+            fprintf(f, "P5\n%d %d\n255\n", w, h);
+            if (fwrite(b, n, 1, f) != 1) rc = 1;
+        }
+        if (f && fclose(f)) rc = 1;
+    }
+    free(b);
+    return rc;
 }
 
 int ofx_write_flo(const char *fname, const float *uv, int w, int h)

@@ -271,3 +271,53 @@ def test_tvl1flow_cli_many_scales(orc, synth, tmp_path):
     assert "nscales=35 " in r.stderr
     uo, vo, _, _ = orc.tvl1_multiscale(I0, I1, nscales=35, zfactor=0.91, warps=1)
     assert np.array_equal(read_flo(out), np.stack([uo, vo], axis=-1).astype(np.float32))
+
+
+def test_tvl1occflow_cli_is_drop_in(orc, synth, tmp_path):
+    """three frames in, .flo and a 0 / 255 occlusion map out: the flow payload equals the oracle's cast to float, the map its
+    thresholded chi; defaults, the auto-nscales rule (16-pixel floor on min(nx, ny)) and the unconditional warnings of
+    src/tvl1occflow_main.cpp"""
+    nx, ny = 96, 80
+    seq = synth.sequence(nx, ny, 3, 1)
+    names = []
+    for k in range(3):
+        write_pgm(tmp_path / ("f%d.pgm" % k), seq[k])
+        names.append(str(tmp_path / ("f%d.pgm" % k)))
+    frames = [s.astype(np.uint8).astype(np.float64) for s in seq]            # what write_pgm stores
+    exe = os.path.join(BIN, "tvl1occflow")
+    out, occ = tmp_path / "o.flo", tmp_path / "occ.pgm"
+    #            I_1 I0 I1 I0_Smoothed out outOcc nproc lambda alpha beta theta nscales zfactor nwarps epsilon verbose
+    r = subprocess.run([exe] + names + [names[1], str(out), str(occ), "1", "0.15", "0.01", "0.15", "0.3", "100", "0.5", "2",
+                                        "0.01", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # N = floor(log(80 / 16) / log(2)) + 1 = 3 (:209-213)
+    assert " nscales=3 " in r.stderr and "Scale 2: 24x20" in r.stderr
+    uo, vo, co, it = orc.tvl1occ_multiscale(frames[0], frames[1], frames[2], nscales=3, warps=2)
+    assert np.array_equal(read_flo(out), np.stack([uo, vo], axis=-1).astype(np.float32))
+    raw = open(occ, "rb").read()
+    head = b"P2\n96 80\n255\n"                                  # 7680 pixels <= 10000: ASCII (iio.cpp:3842-3849)
+    assert raw.startswith(head)
+    got = np.array(raw[len(head):].split(), dtype=np.int64).reshape(ny, nx)
+    assert np.array_equal(got, (co * 255).astype(np.int64)) and 0 < got.mean() < 255
+    printed = [int(x.split("Iterations: ")[1].split(",")[0]) for x in r.stderr.splitlines() if "Iterations:" in x]
+    assert printed == list(it[::-1].ravel())
+    # defaults (no I0_Smoothed -> I0; occlusions.png in the working directory); warnings do not wait for `verbose`, theta's does
+    r2 = subprocess.run([exe] + names + [names[1], str(tmp_path / "o2.flo"), str(tmp_path / "occ2.pgm"), "-1", "0", "-2", "0",
+                                         "0", "-4", "1.5", "0", "0"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    for word in ("nproc changed to 1", "lambda changed to 0.15", "alpha changed to 0.01", "beta changed to 0.15",
+                 "nscales changed to 100", "zfactor changed to 0.5", "nwarps changed to 2", "epsilon changed to 0.010000"):
+        assert "warning: " + word in r2.stderr, (word, r2.stderr)
+    assert "theta changed" not in r2.stderr
+    assert np.array_equal(read_flo(tmp_path / "o2.flo"), read_flo(out))
+    assert open(tmp_path / "occ2.pgm", "rb").read() == raw
+    r3 = subprocess.run([exe] + names, capture_output=True, text=True, cwd=tmp_path)
+    assert r3.returncode == 0 or "libpng16" in r3.stderr, r3.stderr
+    assert np.array_equal(read_flo(tmp_path / "flow.flo"), read_flo(out))
+    if "libpng16" not in r3.stderr:
+        assert open(tmp_path / "occlusions.png", "rb").read()[:8] == b"\x89PNG\r\n\x1a\n"
+    # usage / size mismatch (the reference computes nothing and exits 0)
+    assert subprocess.run([exe, names[0], names[1]], capture_output=True).returncode != 0
+    write_pgm(tmp_path / "small.pgm", seq[0][:40, :40])
+    r4 = subprocess.run([exe, names[0], names[1], str(tmp_path / "small.pgm"), names[1], str(tmp_path / "no.flo")], capture_output=True)
+    assert r4.returncode == 0 and not (tmp_path / "no.flo").exists()

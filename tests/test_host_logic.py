@@ -254,3 +254,57 @@ def test_bench_round_split_and_self_launch_command(monkeypatch):
     assert c[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in c and c[c.index("--nproc-per-node") + 1] == "4"
     assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-4:] == ["--gpus", "4", "--steps", "20"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_gray_byte_image_writer_pgm_and_png(io, tmp_path):
+    """iio_save_image_float on a byte-valued one-channel image (the occlusion map of tvl1occflow): P2 up to 10000 pixels, P5
+    above, 8-bit gray PNG for .png names (src/iio.cpp:3698-3710,3752-3773,3838-3853); TIFF names and non-byte samples refused"""
+    import zlib
+    io.ofx_write_gray_bytes.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_int]
+    rng = np.random.default_rng(5)
+
+    def write(path, img):
+        a = np.ascontiguousarray(img, dtype=np.float32)
+        return io.ofx_write_gray_bytes(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_float)), img.shape[1], img.shape[0])
+    small = (rng.integers(0, 2, (50, 80)) * 255).astype(np.float32)
+    assert write(tmp_path / "s.pgm", small) == 0
+    txt = (tmp_path / "s.pgm").read_text()
+    assert txt.startswith("P2\n80 50\n255\n") and txt.split("\n")[3:-1] == [str(int(v)) for v in small.ravel()]
+    big = rng.integers(0, 256, (101, 100)).astype(np.float32)
+    assert write(tmp_path / "b.whatever", big) == 0
+    raw = (tmp_path / "b.whatever").read_bytes()
+    assert raw == b"P5\n100 101\n255\n" + big.astype(np.uint8).tobytes()
+    assert write(tmp_path / "x.tiff", small) == 2 and write(tmp_path / "x.pgm", small + 0.5) == 2
+    assert write(tmp_path / "x.pgm", small - 1.0) == 2 and not (tmp_path / "x.pgm").exists()
+    r = write(tmp_path / "o.png", big)
+    if r != 0:
+        pytest.skip("libpng16 not present on this machine")
+    data = (tmp_path / "o.png").read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">IIBBBBB", data[16:29]) == (100, 101, 8, 0, 0, 0, 0)
+    idat, pos = b"", 8
+    while pos < len(data):
+        n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+        if tag == b"IDAT":
+            idat += data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(101, 101)
+    # undo the per-row filters (libpng picks them adaptively); only None(0) and Sub(1) and Up(2) etc. via generic reconstruction
+    out = np.zeros((101, 100), dtype=np.uint8)
+    for y in range(101):
+        ft, line = rows[y, 0], rows[y, 1:].astype(np.int32)
+        prev = out[y - 1].astype(np.int32) if y else np.zeros(100, dtype=np.int32)
+        cur = np.zeros(100, dtype=np.int32)
+        for x in range(100):
+            a = cur[x - 1] if x else 0
+            b, c = prev[x], (prev[x - 1] if x else 0)
+            if ft == 0: p = 0
+            elif ft == 1: p = a
+            elif ft == 2: p = b
+            elif ft == 3: p = (a + b) // 2
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            cur[x] = (line[x] + p) & 255
+        out[y] = cur
+    assert np.array_equal(out, big.astype(np.uint8))
+    assert np.array_equal(read_image(io, tmp_path / "o.png"), big.astype(np.float64))       # and through our own reader
