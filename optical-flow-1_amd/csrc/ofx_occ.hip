@@ -446,138 +446,299 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
 // nIter times { alfa = |grad u| / (lambda g) per cell;  ONE in-place box-relaxation sweep over the cells in lexicographic
 // order;  u = lambda f + lambda div P }.  The sweep is a sequential recurrence: each cell solves the 2x2 / 3x3 / 4x4 system of
 // the dual values on its own edges from the edges of its eight neighbours.  Like the SOR sweeps (ofx_sor.hip) it is
-// executed on hyperplanes without changing an operand: cell (ci, cj) runs at step pos = 2 ci + cj, so that the cells it
+// executed on hyperplanes without changing an operand: cell (ci, cj) runs at step q = 2 ci + cj, so that the cells it
 // must follow (W, NW, N, NE) are done and the ones it must precede (E, SW, S, SE) are not; the cells of one step touch
-// disjoint edges.  A sweep is cut into row blocks of R rows, one workgroup each, block b running K steps behind block b - 1;
-// a launch executes K steps of every block, so everything a workgroup reads from another one was written in an earlier
-// launch, and inside a workgroup consecutive steps are separated by a store drain + barrier.
+// disjoint edges and read nothing another cell of the step writes.
 // Cell-centred storage instead of the reference's (2 ny + 1) x (2 nx + 1) staggered grid: Ps / Pe = dual value on the
 // south / east edge of a cell (the in/out state initialP1 / initialP2; a cell's north / west edge is the south / east
 // edge of its neighbour, 0 on the image border), Fs / Fe = differences of f across those edges (0 on the border), AL =
 // alfa of the cell (the reference stores the same value on both edges).
-#define ROF_K 8
-#define ROF_R 125
-struct RofArr {
+// * Hyperplane-major arrays.  One thread owns one image row, so the 64 lanes of a wave touch 64 different rows at every step;
+//   in row-major arrays that is 64 cache lines per load instruction.  All five arrays of a sweep are therefore stored with
+//   index (2 ci + cj) ny + ci: the cells of one step are contiguous (same layout idea as LaySkew in ofx_sor.hip).
+// * A launch works from LDS.  One thread owns one row; a workgroup first brings everything its ROF_K steps will touch into
+//   LDS -- the (Ps, Pe) pairs of positions q0 - 4 .. q1 + 2 of the skewed coordinate p = 2 ci + cj and the (Fs, Fe, alfa)
+//   triples of positions q0 - 2 .. q1 + 1, per row -- with all loads in flight at once (one memory latency per launch instead of one
+//   per step), then runs its steps on LDS only: every neighbour access is an LDS access, one barrier per step, and the thread
+//   that makes the LAST update of a value (the north edge from the row below, the west edge from the next cell of the row)
+//   also stores it to global memory, without waiting for the store.  A step costs the LDS round trip plus the cell's chain
+//   of six dependent IEEE divisions.  Entries whose last update falls into a later launch (2 per row) are written back at
+//   the end.
+// * Rows are cut into blocks of ROF_R = 125, one workgroup of 128 threads each: 125 row owners + 3 threads that only bring
+//   the halo rows (two above, one below) into LDS.  Block b runs ROF_LAG steps behind block b - 1 and a launch executes
+//   ROF_K steps of every block; ROF_LAG = ROF_K + 8 guarantees that whatever a workgroup takes from global memory that
+//   another one wrote (read up to ROF_K + 2 positions ahead, stored up to 1 step late) was written by an earlier launch,
+//   and that the rows below are still untouched by the next block.
+#ifndef ROF_VAR
+#define ROF_VAR 0                    // 1, 2, 3: timing experiments of tools/rof_variants.sh, never shipped
+#endif
+#define ROF_NT 128
+#define ROF_R (ROF_NT - 3)
+#define ROF_THREADS (ROF_NT + 64)     // + one wave whose first two threads walk the image's first and last row
+#define ROF_K 24
+#define ROF_LAG (ROF_K + 8)
+#define ROF_RING (ROF_K + 7)         // positions q0 - 4 .. q1 + 2
+#define ROF_COEF (ROF_K + 3)         // positions q0 - 2 .. q1 + 1
+#define ROF_LDS_BYTES ((size_t) ROF_NT * (ROF_RING * sizeof(double2) + 3 * ROF_COEF * sizeof(double)))
+struct RofArr {                      // all five arrays hyperplane-major
     double *Ps, *Pe;
     const double *Fs, *Fe, *AL;
     int nx, ny;
-    OFX_DEV double ps(int ci, int cj) const { return (ci >= 0 && cj >= 0) ? Ps[(size_t) ci * nx + cj] : 0.0; }
-    OFX_DEV double pe(int ci, int cj) const { return (ci >= 0 && cj >= 0) ? Pe[(size_t) ci * nx + cj] : 0.0; }
+};
+static inline __host__ __device__ size_t rof_skew_elems(int nx, int ny) { return (size_t) (2 * (ny - 1) + nx) * ny; }
+OFX_DEV size_t rof_sk(int ci, int cj, int ny) { return (size_t) (2 * ci + cj) * ny + ci; }
+
+// the LDS copy of one workgroup's launch window and what a cell may do with it
+struct RofRing {
+    const RofArr &a;
+    double2 (*win)[ROF_NT];          // [position - (q0 - 4)][thread]: .x = Ps, .y = Pe
+    double (*cf)[ROF_NT];            // [k * ROF_COEF + position - (q0 - 2)][thread]: k = 0 Fs, 1 Fe, 2 alfa
+    int row0;                        // image row of thread 0 (= first own row - 2)
+    int pw0;                         // q0 - 4
+    bool keep_s;                     // this row's south edges are final for this workgroup (last own row): store them
+    OFX_DEV double2 &at(int ci, int cj) const { return win[2 * ci + cj - pw0][ci - row0]; }
+    OFX_DEV double ps(int ci, int cj) const { return (ci >= 0 && cj >= 0) ? at(ci, cj).x : 0.0; }
+    OFX_DEV double pe(int ci, int cj) const { return (ci >= 0 && cj >= 0) ? at(ci, cj).y : 0.0; }
+    OFX_DEV double coef(int k, int ci, int cj) const { return cf[k * ROF_COEF + 2 * ci + cj - pw0 - 2][ci - row0]; }
+    OFX_DEV double Fs(int ci, int cj) const { return coef(0, ci, cj); }
+    OFX_DEV double Fe(int ci, int cj) const { return coef(1, ci, cj); }
+    OFX_DEV double AL(int ci, int cj) const { return coef(2, ci, cj); }
+#if ROF_VAR == 2                     // timing experiment: no global stores from the steps
+    OFX_DEV void put_w(int ci, int cj, double v) const { at(ci, cj - 1).y = v; }
+    OFX_DEV void put_n(int ci, int cj, double v) const { at(ci - 1, cj).x = v; }
+#else
+    OFX_DEV void put_w(int ci, int cj, double v) const { at(ci, cj - 1).y = v; a.Pe[rof_sk(ci, cj - 1, a.ny)] = v; }   // final
+    OFX_DEV void put_n(int ci, int cj, double v) const { at(ci - 1, cj).x = v; a.Ps[rof_sk(ci - 1, cj, a.ny)] = v; }   // final
+#endif
+    OFX_DEV void put_s(int ci, int cj, double v) const
+    {
+        at(ci, cj).x = v;
+        if (keep_s) a.Ps[rof_sk(ci, cj, a.ny)] = v;
+    }
+    OFX_DEV void put_e(int ci, int cj, double v) const { at(ci, cj).y = v; }
 };
 
-// one cell; the nine kinds keep the reference's own closed forms and association order (only the north side writes its
-// free terms with the F term first)
-OFX_DEV void rof_cell(const RofArr &a, int ci, int cj, double w)
+// What an inner cell computes from the alfa values alone (its Gauss elimination factors and the four denominators).  It is
+// taken off the sequential chain: while a thread walks the chain of cell (ci, cj) -- four dependent divisions once these
+// are known -- the same basic block computes the factors of cell (ci, cj + 1), which fills the chain's latency bubbles.
+struct RofPre {
+    double aa, bb, alf, gam, cc, d1, d2, d3, b0;
+};
+OFX_DEV RofPre rof_pre(double b0, double b1, double b2, double b3)
 {
+    RofPre p;
+    p.aa = 1 / b0;
+    p.bb = -(b0 + 1) / (b0 * b1 - 1);
+    p.alf = 1 + p.aa;
+    p.gam = -p.aa + p.bb * p.alf;
+    p.cc = (1 - p.gam) / (b2 + p.gam);
+    p.d1 = (b3 + p.gam + p.cc * (p.gam - 1));
+    p.d2 = (b2 + p.gam);
+    p.d3 = (b1 - p.aa);
+    p.b0 = b0;
+    return p;
+}
+
+// one cell; the nine kinds keep the reference's own closed forms and association order (only the north side writes its
+// free terms with the F term first).  Every LDS operand of every kind is read up front, unconditionally -- all slots exist,
+// the ones of cells outside the image hold don't-care values that the selects below replace by 0 -- so that a step pays one LDS
+// round trip, not one per neighbour.
+OFX_DEV void rof_cell(const RofRing &r, int ci, int cj, double w, RofPre &pre, bool &pre_ok)
+{
+    const RofArr &a = r.a;
     const int nx = a.nx, ny = a.ny;
     const bool top = ci == 0, bot = ci == ny - 1, lef = cj == 0, rig = cj == nx - 1;
-    const size_t c = (size_t) ci * nx + cj;
+    const double2 c_m2 = r.at(ci, cj - 2), c_m1 = r.at(ci, cj - 1), c_0 = r.at(ci, cj), c_p1 = r.at(ci, cj + 1);
+    const double2 n_m1 = r.at(ci - 1, cj - 1), n_0 = r.at(ci - 1, cj), n_p1 = r.at(ci - 1, cj + 1), nn_0 = r.at(ci - 2, cj);
+    const double2 s_0 = r.at(ci + 1, cj), s_m1 = r.at(ci + 1, cj - 1);
+    const double fe_w = r.Fe(ci, cj - 1), fe_c = r.Fe(ci, cj), fs_n = r.Fs(ci - 1, cj), fs_c = r.Fs(ci, cj);
+    const double al_w = r.AL(ci, cj - 1), al_n = r.AL(ci - 1, cj), al = r.AL(ci, cj);
+    const double al_e = r.AL(ci, cj + 1), al_ne = r.AL(ci - 1, cj + 1);      // for the factors of the next cell of the row
+    // keep the compiler from sinking some of these reads into the conditional blocks below (one more round trip each)
+    asm volatile("" ::"v"(c_m2.y), "v"(c_m1.x), "v"(c_m1.y), "v"(c_0.x), "v"(c_0.y), "v"(c_p1.x), "v"(c_p1.y), "v"(n_m1.x), "v"(n_m1.y),
+                 "v"(n_0.x), "v"(n_0.y), "v"(n_p1.x), "v"(nn_0.x), "v"(s_0.x), "v"(s_0.y), "v"(s_m1.y));
+    asm volatile("" ::"v"(fe_w), "v"(fe_c), "v"(fs_n), "v"(fs_c), "v"(al_w), "v"(al_n), "v"(al), "v"(al_e), "v"(al_ne));
+    const bool c1 = cj >= 1, c2 = cj >= 2, r1 = ci >= 1, r2 = ci >= 2;         // does the neighbour exist (else the value is 0)
     const bool nside = top && !lef && !rig;
     double W = 0, N = 0, S = 0, E = 0;
     if (!lef) {
-        const double fw = a.Fe[c - 1];
-        W = nside ? -fw - a.pe(ci, cj - 2) + a.ps(ci, cj - 1) - a.ps(ci - 1, cj - 1)
-                  : -a.pe(ci, cj - 2) + a.ps(ci, cj - 1) - a.ps(ci - 1, cj - 1) - fw;
+        const double pe_m2 = c2 ? c_m2.y : 0.0, ps_m1 = c_m1.x, ps_nm1 = r1 ? n_m1.x : 0.0;
+        W = nside ? -fe_w - pe_m2 + ps_m1 - ps_nm1 : -pe_m2 + ps_m1 - ps_nm1 - fe_w;
     }
-    if (!top) N = -a.ps(ci - 2, cj) + a.pe(ci - 1, cj) - a.pe(ci - 1, cj - 1) - a.Fs[c - nx];
+    if (!top) N = -(r2 ? nn_0.x : 0.0) + n_0.y - (c1 ? n_m1.y : 0.0) - fs_n;
     if (!bot) {
-        const double fs = a.Fs[c];
-        S = nside ? -fs - a.ps(ci + 1, cj) - a.pe(ci + 1, cj) + a.pe(ci + 1, cj - 1)
-                  : -a.ps(ci + 1, cj) - a.pe(ci + 1, cj) + a.pe(ci + 1, cj - 1) - fs;
+        const double pe_sm1 = c1 ? s_m1.y : 0.0;
+        S = nside ? -fs_c - s_0.x - s_0.y + pe_sm1 : -s_0.x - s_0.y + pe_sm1 - fs_c;
     }
     if (!rig) {
-        const double fe = a.Fe[c];
-        E = nside ? -fe - a.pe(ci, cj + 1) - a.ps(ci, cj + 1) + a.ps(ci - 1, cj + 1)
-                  : -a.pe(ci, cj + 1) - a.ps(ci, cj + 1) + a.ps(ci - 1, cj + 1) - fe;
+        const double ps_np1 = r1 ? n_p1.x : 0.0;
+        E = nside ? -fe_c - c_p1.y - c_p1.x + ps_np1 : -c_p1.y - c_p1.x + ps_np1 - fe_c;
     }
-    const double b0 = lef ? 0.0 : -2 - a.AL[c - 1], b1 = top ? 0.0 : -2 - a.AL[c - nx];
-    const double b2 = bot ? 0.0 : -2 - a.AL[c], b3 = rig ? 0.0 : -2 - a.AL[c];
+    const double b0 = lef ? 0.0 : -2 - al_w, b1 = top ? 0.0 : -2 - al_n;
+    const double b2 = bot ? 0.0 : -2 - al, b3 = rig ? 0.0 : -2 - al;
     // own edges: west = east edge of the left cell, north = south edge of the cell above
-    double *pw = lef ? nullptr : a.Pe + c - 1, *pn = top ? nullptr : a.Ps + c - nx, *psp = a.Ps + c, *pep = a.Pe + c;
+    const double ow = lef ? 0.0 : c_m1.y, on = top ? 0.0 : n_0.x, os = c_0.x, oe = c_0.y;
     double den;
     if (top && lef) {
         den = b2 * b3 - 1;
-        const double s_ = (1 - w) * *psp + w * (S * b3 + E) / den, e_ = (1 - w) * *pep + w * (E * b2 + S) / den;
-        *psp = s_; *pep = e_;
+        const double s_ = (1 - w) * os + w * (S * b3 + E) / den, e_ = (1 - w) * oe + w * (E * b2 + S) / den;
+        r.put_s(ci, cj, s_); r.put_e(ci, cj, e_);
     } else if (top && rig) {
         den = b0 * b2 - 1;
-        const double w_ = (1 - w) * *pw + w * (W * b2 - S) / den, s_ = (1 - w) * *psp + w * (S * b0 - W) / den;
-        *pw = w_; *psp = s_;
+        const double w_ = (1 - w) * ow + w * (W * b2 - S) / den, s_ = (1 - w) * os + w * (S * b0 - W) / den;
+        r.put_w(ci, cj, w_); r.put_s(ci, cj, s_);
     } else if (top) {
         den = b0 * b2 * b3 - b0 - b2 - b3 - 2;
-        const double w_ = (1 - w) * *pw + w * (W * b2 * b3 - E * b2 - S * b3 - W - E - S) / den;
-        const double s_ = (1 - w) * *psp + w * (S * b0 * b3 - W * b3 + E * b0 - W + E - S) / den;
-        const double e_ = (1 - w) * *pep + w * (E * b0 * b2 - W * b2 + S * b0 - W - E + S) / den;
-        *pw = w_; *psp = s_; *pep = e_;
+        const double w_ = (1 - w) * ow + w * (W * b2 * b3 - E * b2 - S * b3 - W - E - S) / den;
+        const double s_ = (1 - w) * os + w * (S * b0 * b3 - W * b3 + E * b0 - W + E - S) / den;
+        const double e_ = (1 - w) * oe + w * (E * b0 * b2 - W * b2 + S * b0 - W - E + S) / den;
+        r.put_w(ci, cj, w_); r.put_s(ci, cj, s_); r.put_e(ci, cj, e_);
     } else if (bot && lef) {
         den = b3 * b1 - 1;
-        const double n_ = (1 - w) * *pn + w * (b3 * N - E) / den, e_ = (1 - w) * *pep + w * (b1 * E - N) / den;
-        *pn = n_; *pep = e_;
+        const double n_ = (1 - w) * on + w * (b3 * N - E) / den, e_ = (1 - w) * oe + w * (b1 * E - N) / den;
+        r.put_n(ci, cj, n_); r.put_e(ci, cj, e_);
     } else if (bot && rig) {
         den = b0 * b1 - 1;
-        const double w_ = (1 - w) * *pw + w * (W * b1 + N) / den, n_ = (1 - w) * *pn + w * (N * b0 + W) / den;
-        *pw = w_; *pn = n_;
+        const double w_ = (1 - w) * ow + w * (W * b1 + N) / den, n_ = (1 - w) * on + w * (N * b0 + W) / den;
+        r.put_w(ci, cj, w_); r.put_n(ci, cj, n_);
     } else if (bot) {
         den = b0 * b1 * b3 - b0 - b1 - b3 - 2;
-        const double w_ = (1 - w) * *pw + w * (W * b1 * b3 - E + N - E * b1 - W + N * b3) / den;
-        const double n_ = (1 - w) * *pn + w * (N * b0 * b3 + W - E - N - E * b0 + W * b3) / den;
-        const double e_ = (1 - w) * *pep + w * (E * b0 * b1 - N - W - W * b1 - N * b0 - E) / den;
-        *pw = w_; *pn = n_; *pep = e_;
+        const double w_ = (1 - w) * ow + w * (W * b1 * b3 - E + N - E * b1 - W + N * b3) / den;
+        const double n_ = (1 - w) * on + w * (N * b0 * b3 + W - E - N - E * b0 + W * b3) / den;
+        const double e_ = (1 - w) * oe + w * (E * b0 * b1 - N - W - W * b1 - N * b0 - E) / den;
+        r.put_w(ci, cj, w_); r.put_n(ci, cj, n_); r.put_e(ci, cj, e_);
     } else if (lef) {
         den = b1 * b2 * b3 - (b1 + b2 + b3) - 2;
-        const double n_ = (1 - w) * *pn + w * (b2 * b3 * N - E * b2 - S * b3 - N - S - E) / den;
-        const double s_ = (1 - w) * *psp + w * (b1 * b3 * S + E * b1 - N * b3 - N - S + E) / den;
-        const double e_ = (1 - w) * *pep + w * (b1 * b2 * E - N * b2 + S * b1 - N + S - E) / den;
-        *pn = n_; *psp = s_; *pep = e_;
+        const double n_ = (1 - w) * on + w * (b2 * b3 * N - E * b2 - S * b3 - N - S - E) / den;
+        const double s_ = (1 - w) * os + w * (b1 * b3 * S + E * b1 - N * b3 - N - S + E) / den;
+        const double e_ = (1 - w) * oe + w * (b1 * b2 * E - N * b2 + S * b1 - N + S - E) / den;
+        r.put_n(ci, cj, n_); r.put_s(ci, cj, s_); r.put_e(ci, cj, e_);
     } else if (rig) {
         den = (b0 * b1 * b2) + (-b0 - b1 - b2 - 2);
-        const double w_ = (1 - w) * *pw + w * (W * b1 * b2 - S + N - S * b1 - W + N * b2) / den;
-        const double n_ = (1 - w) * *pn + w * (N * b0 * b2 + W - S - N - S * b0 + W * b2) / den;
-        const double s_ = (1 - w) * *psp + w * (S * b0 * b1 - N - W - W * b1 - N * b0 - S) / den;
-        *pw = w_; *pn = n_; *psp = s_;
+        const double w_ = (1 - w) * ow + w * (W * b1 * b2 - S + N - S * b1 - W + N * b2) / den;
+        const double n_ = (1 - w) * on + w * (N * b0 * b2 + W - S - N - S * b0 + W * b2) / den;
+        const double s_ = (1 - w) * os + w * (S * b0 * b1 - N - W - W * b1 - N * b0 - S) / den;
+        r.put_w(ci, cj, w_); r.put_n(ci, cj, n_); r.put_s(ci, cj, s_);
     } else {                                             // inner cell: Gauss elimination, each value from the new ones before it
-        const double aa = 1 / b0;
-        const double bb = -(b0 + 1) / (b0 * b1 - 1);
-        const double alf = 1 + aa;
-        const double gam = -aa + bb * alf;
-        const double x = N + aa * W;
-        const double y = -aa * W + bb * x;
-        const double cc = (1 - gam) / (b2 + gam);
-        const double e_ = (1 - w) * *pep + w * (E + y + cc * (S + y)) / (b3 + gam + cc * (gam - 1));
-        const double s_ = (1 - w) * *psp + w * (S + y + e_ * (1 - gam)) / (b2 + gam);
-        const double n_ = (1 - w) * *pn + w * (x - alf * (e_ + s_)) / (b1 - aa);
-        const double w_ = (1 - w) * *pw + w * (W + n_ - s_ - e_) / (b0);
-        *pep = e_; *psp = s_; *pn = n_; *pw = w_;
+#if ROF_VAR == 1                     // timing experiment: no arithmetic to speak of
+        r.put_e(ci, cj, oe + E); r.put_s(ci, cj, os + S); r.put_n(ci, cj, on + N); r.put_w(ci, cj, ow + W + b0 + b1 + b2 + b3);
+        return;
+#endif
+        RofPre P = pre;
+        if (!pre_ok) P = rof_pre(b0, b1, b2, b3);        // first inner cell of the row / of the launch
+        const double x = N + P.aa * W;
+        const double y = -P.aa * W + P.bb * x;
+        const double e_ = (1 - w) * oe + w * (E + y + P.cc * (S + y)) / P.d1;
+        const double s_ = (1 - w) * os + w * (S + y + e_ * (1 - P.gam)) / P.d2;
+        const double n_ = (1 - w) * on + w * (x - P.alf * (e_ + s_)) / P.d3;
+        const double w_ = (1 - w) * ow + w * (W + n_ - s_ - e_) / (P.b0);
+        r.put_e(ci, cj, e_); r.put_s(ci, cj, s_); r.put_n(ci, cj, n_); r.put_w(ci, cj, w_);
+        pre = rof_pre(-2 - al, -2 - al_ne, -2 - al_e, -2 - al_e);      // cell (ci, cj + 1): b0 from this cell's alfa
+        pre_ok = cj + 1 < nx - 1;
+        return;
     }
+    pre_ok = false;
 }
 
-// K steps [tau0, tau0 + K) of every row block of one sweep; blockIdx.y = which of the (independent) problems
+// ROF_K steps of every row block of one sweep, launch window starting at global step T0; blockIdx.y = which of the
+// (independent) problems
 struct RofSet {
     RofArr a[2];
 };
-__global__ __launch_bounds__(128) void k_rof_window(RofSet s, int tau0, double w)
+__global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, double w)
 {
-    const RofArr &a = s.a[blockIdx.y];
-    const int b = blockIdx.x, ci = b * ROF_R + (int) threadIdx.x;
-    const int qmax = 2 * (a.ny - 1) + a.nx - 1;
-    const int q_first = tau0 - ROF_K * b;
-    if (q_first > qmax || q_first + ROF_K - 1 < 0) return;
-    for (int q = q_first; q < q_first + ROF_K; q++) {
+    extern __shared__ double2 rof_lds[];
+    double2 (*win)[ROF_NT] = reinterpret_cast<double2 (*)[ROF_NT]>(rof_lds);
+    double (*cf)[ROF_NT] = reinterpret_cast<double (*)[ROF_NT]>(rof_lds + ROF_RING * ROF_NT);
+    const RofArr a = blockIdx.y ? s.a[1] : s.a[0];                          // by value: a dynamic index would be re-read from the kernel arguments at every use
+    const int nx = a.nx, ny = a.ny;
+    const int t = (int) threadIdx.x, row0 = (int) blockIdx.x * ROF_R - 2;
+    const int qmax = 2 * (ny - 1) + nx - 1;
+    const int q0 = T0 - ROF_LAG * (int) blockIdx.x, q1 = q0 + ROF_K - 1;
+    if (q0 > qmax || q1 < 0) return;                                        // uniform over the workgroup
+    // Who walks which row.  Threads 0 .. 127 = LDS columns = rows row0 .. row0 + 127 (125 own rows between two halo rows above
+    // and one below).  The image's first and last row consist of cells of another kind (3 x 3 systems) than the inner rows:
+    // left in their column's wave they would make that wave -- and with it the whole launch, which waits for its slowest
+    // workgroup -- execute two kinds per step.  They are walked by two threads of a third wave instead.
+    int ci = row0 + t;
+    const bool column = t < ROF_NT;
+    const bool row_own = column && ci >= 0 && ci < ny && t >= 2 && t < 2 + ROF_R;        // this column's row belongs to the block
+    bool own = row_own && ci != 0 && ci != ny - 1;
+    if (!column) {
+        ci = (t == ROF_NT) ? 0 : ny - 1;
+        own = t < ROF_NT + 2 && ci - row0 >= 2 && ci - row0 < 2 + ROF_R;
+    }
+    const RofRing ring = {a, win, cf, row0, q0 - 4, ci - row0 == 1 + ROF_R};
+    if (column) {
+        // everything the launch reads.  Unconditional loads (out-of-range entries read a harmless address and are never
+        // used) into registers first, so that all of them are in flight together: one memory latency, not one per entry
+        const int cic = min(max(ci, 0), ny - 1);
+        double2 ring_in[ROF_RING];
+#pragma unroll
+        for (int k = 0; k < ROF_RING; k++) {
+            const int p = q0 - 4 + k, x = p - 2 * cic;
+            const size_t e = (x >= 0 && x < nx) ? (size_t) p * ny + cic : (size_t) cic;
+            ring_in[k] = make_double2(a.Ps[e], a.Pe[e]);
+        }
+#pragma unroll
+        for (int k = 0; k < ROF_RING; k++) win[k][t] = ring_in[k];
+        double coef_in[3][ROF_COEF];
+#pragma unroll
+        for (int k = 0; k < ROF_COEF; k++) {
+            const int p = q0 - 2 + k, x = p - 2 * cic;
+            const size_t e = (x >= 0 && x < nx) ? (size_t) p * ny + cic : (size_t) cic;
+            coef_in[0][k] = a.Fs[e];
+            coef_in[1][k] = a.Fe[e];
+            coef_in[2][k] = a.AL[e];
+        }
+#pragma unroll
+        for (int k = 0; k < ROF_COEF; k++) {
+            cf[k][t] = coef_in[0][k];
+            cf[ROF_COEF + k][t] = coef_in[1][k];
+            cf[2 * ROF_COEF + k][t] = coef_in[2][k];
+        }
+    }
+    __syncthreads();
+    RofPre pre = {};
+    bool pre_ok = false;
+    for (int q = q0; q <= q1; q++) {
         const int cj = q - 2 * ci;
-        if ((int) threadIdx.x < ROF_R && ci < a.ny && q >= 0 && cj >= 0 && cj < a.nx) rof_cell(a, ci, cj, w);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (own && cj >= 0 && cj < nx) rof_cell(ring, ci, cj, w, pre, pre_ok);
+#if ROF_VAR == 3                     // timing experiment: no barrier between the steps (results are wrong)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+#else
         __syncthreads();
+#endif
+    }
+    if (row_own) {                                                           // entries a later launch still has to update
+        for (int p = q1 - 1; p <= q1; p++) {
+            const int x = p - 2 * ci;
+            if (x >= 0 && x < nx) {
+                const size_t e = (size_t) p * ny + ci;
+                a.Ps[e] = win[p - q0 + 4][t].x;
+                if (p == q1) a.Pe[e] = win[p - q0 + 4][t].y;
+            }
+        }
     }
 }
 
+// row-major <-> hyperplane-major (state planes of the host-facing entry points)
+__global__ void k_rof_skew(const double *__restrict__ in, double *__restrict__ out, int nx, int ny, int to_skew)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t c = (size_t) i * nx + j, k = rof_sk(i, j, ny);
+    if (to_skew) out[k] = in[c];
+    else out[c] = in[k];
+}
 // edge differences of f (once per call), :137-164
 __global__ void k_rof_fdiff(const double *__restrict__ f, double *__restrict__ Fs, double *__restrict__ Fe, int nx, int ny)
 {
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= ny) return;
-    const size_t c = (size_t) i * nx + j;
-    Fs[c] = (i < ny - 1) ? f[c + nx] - f[c] : 0.0;
-    Fe[c] = (j < nx - 1) ? f[c + 1] - f[c] : 0.0;
+    const size_t c = (size_t) i * nx + j, k = rof_sk(i, j, ny);
+    Fs[k] = (i < ny - 1) ? f[c + nx] - f[c] : 0.0;
+    Fe[k] = (j < nx - 1) ? f[c + 1] - f[c] : 0.0;
 }
 // alfa = hypot(forward gradient of u) / (lambda g) with the file-local hypot = sqrt(x x + y y), :15-20,173-187
 struct RofPt {
@@ -591,25 +752,26 @@ __global__ void k_rof_alfa(RofPt a, const double *__restrict__ g, int nx, int ny
     const size_t c = (size_t) i * nx + j;
     const double *u = a.u[k];
     const double ux = (j < nx - 1) ? u[c + 1] - u[c] : 0.0, uy = (i < ny - 1) ? u[c + nx] - u[c] : 0.0;
-    a.AL[k][c] = sqrt(ux * ux + uy * uy) / (lambda * g[c]);
+    a.AL[k][rof_sk(i, j, ny)] = sqrt(ux * ux + uy * uy) / (lambda * g[c]);
 }
 // u = lambda f + lambda (P_south - P_north + P_east - P_west), :616-640
 __global__ void k_rof_u(RofPt a, int nx, int ny, double lambda)
 {
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
     if (j >= nx || i >= ny) return;
-    const size_t c = (size_t) i * nx + j;
+    const size_t c = (size_t) i * nx + j, e = rof_sk(i, j, ny);
     const double *Ps = a.Ps[k], *Pe = a.Pe[k];
-    const double pn = i > 0 ? Ps[c - nx] : 0.0, pw = j > 0 ? Pe[c - 1] : 0.0;
-    a.uo[k][c] = lambda * a.f[k][c] + lambda * (Ps[c] - pn + Pe[c] - pw);
+    const double pn = i > 0 ? Ps[rof_sk(i - 1, j, ny)] : 0.0, pw = j > 0 ? Pe[rof_sk(i, j - 1, ny)] : 0.0;
+    a.uo[k][c] = lambda * a.f[k][c] + lambda * (Ps[e] - pn + Pe[e] - pw);
 }
 
 // nc = 1 | 2 independent problems sharing g, lambda and the size (the two flow components of Solver_wrt_u), every launch
-// serving both.  Device arrays in place: u[k] (in: seed, out: result), Ps[k] / Pe[k] (in/out state); scratch = 3 nc planes.
+// serving both.  Device arrays in place: u[k] (in: seed, out: result; row-major), Ps[k] / Pe[k] (in/out state,
+// HYPERPLANE-MAJOR, rof_skew_elems() doubles each); scratch = 3 nc hyperplane-major planes.
 static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *const *f, double *const *Ps, double *const *Pe,
                        const double *g, double lambda, double omega, int nx, int ny, int n_iter, double *scratch)
 {
-    const size_t n = (size_t) nx * ny;
+    const size_t n = rof_skew_elems(nx, ny);
     const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), nc), block(64, 4);
     RofSet set;
     RofPt pt;
@@ -624,14 +786,36 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
         pt.u[k] = u[c]; pt.f[k] = f[c]; pt.Ps[k] = Ps[c]; pt.Pe[k] = Pe[c]; pt.AL[k] = AL; pt.uo[k] = u[c];
     }
     const int B = ofx_cdiv(ny, ROF_R), qmax = 2 * (ny - 1) + nx - 1;
-    const long total = (long) qmax + 1 + (long) ROF_K * (B - 1);
+    const long total = (long) qmax + 1 + (long) ROF_LAG * (B - 1);
+    static bool lds_set = false;                       // same value for every device; the attribute belongs to the function
+    if (!lds_set) {
+        OFX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_rof_window), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int) ROF_LDS_BYTES));
+        lds_set = true;
+    }
     for (int it = 0; it < n_iter; it++) {
         hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
-        for (long tau0 = 0; tau0 < total; tau0 += ROF_K)
-            hipLaunchKernelGGL(k_rof_window, dim3(B, nc), dim3(128), 0, ctx->stream, set, (int) tau0, omega);
+        for (long T0 = 0; T0 < total; T0 += ROF_K)
+            hipLaunchKernelGGL(k_rof_window, dim3(B, nc), dim3(ROF_THREADS), ROF_LDS_BYTES, ctx->stream, set, (int) T0, omega);
         hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, pt, nx, ny, lambda);
         OFX_LAUNCH_CHECK(ctx);
     }
+    return OFX_OK;
+}
+// host-facing state planes: upload row-major, convert; convert back, download
+static int rof_state_in(ofx_ctx *ctx, const double *host, double **dev, double *tmp, int nx, int ny)
+{
+    OFX_TRY(ofx_alloc(ctx, rof_skew_elems(nx, ny), dev));
+    OFX_HIP(ctx, hipMemcpyAsync(tmp, host, (size_t) nx * ny * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_rof_skew, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, (const double *) tmp, *dev, nx, ny, 1);
+    OFX_LAUNCH_CHECK(ctx);
+    return OFX_OK;
+}
+static int rof_state_out(ofx_ctx *ctx, const double *dev, double *host, double *tmp, int nx, int ny)
+{
+    hipLaunchKernelGGL(k_rof_skew, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, dev, tmp, nx, ny, 0);
+    OFX_LAUNCH_CHECK(ctx);
+    OFX_HIP(ctx, hipMemcpyAsync(host, tmp, (size_t) nx * ny * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return OFX_OK;
 }
 
@@ -645,19 +829,20 @@ extern "C" int ofx_scalar_rof_box_cell_centered(ofx_ctx *ctx, double *u, const d
     if (nIter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "rof_box: nIter=%d", nIter);
     Dev d{ctx};
     const size_t n = (size_t) nx * ny;
-    double *du, *df, *dp1, *dp2, *dg;
+    double *du, *df, *dp1, *dp2, *dg, *tmp, *scratch;
     OFX_TRY(d.in(u, &du, n));
     OFX_TRY(d.in(f, &df, n));
-    OFX_TRY(d.in(initialP1, &dp1, n));
-    OFX_TRY(d.in(initialP2, &dp2, n));
     OFX_TRY(d.in(g_function, &dg, n));
-    double *scratch;
-    OFX_TRY(ofx_alloc(ctx, 3 * n, &scratch));
+    OFX_TRY(ofx_alloc(ctx, n, &tmp));
+    OFX_TRY(rof_state_in(ctx, initialP1, &dp1, tmp, nx, ny));
+    OFX_TRY(rof_state_in(ctx, initialP2, &dp2, tmp, nx, ny));
+    OFX_TRY(ofx_alloc(ctx, 3 * rof_skew_elems(nx, ny), &scratch));
     const double *fs[1] = {df};
     OFX_TRY(rof_box_dev(ctx, 1, &du, fs, &dp1, &dp2, dg, lambda, omega, nx, ny, nIter, scratch));
     OFX_TRY(d.out(du, u, n));
-    OFX_TRY(d.out(dp1, initialP1, n));
-    OFX_TRY(d.out(dp2, initialP2, n));
+    OFX_TRY(rof_state_out(ctx, dp1, initialP1, tmp, nx, ny));
+    OFX_TRY(d.sync());
+    OFX_TRY(rof_state_out(ctx, dp2, initialP2, tmp, nx, ny));
     return d.sync();
 }
 
@@ -687,13 +872,14 @@ extern "C" int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const doub
     if (n_iter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "solver_wrt_u: n_iter=%d", n_iter);
     Dev d{ctx};
     const size_t n = (size_t) nx * ny;
-    double *dv1, *dv2, *dchi, *dg, *dp[4], *f1, *f2, *du1, *du2;
+    double *dv1, *dv2, *dchi, *dg, *dp[4], *f1, *f2, *du1, *du2, *tmp, *scratch;
     OFX_TRY(d.in(v1, &dv1, n));
     OFX_TRY(d.in(v2, &dv2, n));
     OFX_TRY(d.in(chi, &dchi, n));
     OFX_TRY(d.in(g, &dg, n));
+    OFX_TRY(ofx_alloc(ctx, n, &tmp));
     double *hp[4] = {p11, p12, p21, p22};
-    for (int k = 0; k < 4; k++) OFX_TRY(d.in(hp[k], &dp[k], n));
+    for (int k = 0; k < 4; k++) OFX_TRY(rof_state_in(ctx, hp[k], &dp[k], tmp, nx, ny));
     OFX_TRY(ofx_alloc(ctx, n, &f1));
     OFX_TRY(ofx_alloc(ctx, n, &f2));
     OFX_TRY(ofx_alloc(ctx, n, &du1));
@@ -701,14 +887,16 @@ extern "C" int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const doub
     hipLaunchKernelGGL(k_occ_u_init, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, (const double *) dv1,
                        (const double *) dv2, (const double *) dchi, f1, f2, du1, du2, nx, ny, theta, beta);
     OFX_LAUNCH_CHECK(ctx);
-    double *scratch;
-    OFX_TRY(ofx_alloc(ctx, 6 * n, &scratch));
+    OFX_TRY(ofx_alloc(ctx, 6 * rof_skew_elems(nx, ny), &scratch));
     double *us[2] = {du1, du2}, *ps[2] = {dp[0], dp[2]}, *pe[2] = {dp[1], dp[3]};
     const double *fs[2] = {f1, f2};
     OFX_TRY(rof_box_dev(ctx, 2, us, fs, ps, pe, dg, theta, OCC_OMEGA, nx, ny, n_iter, scratch));
     OFX_TRY(d.out(du1, u1, n));
     OFX_TRY(d.out(du2, u2, n));
-    for (int k = 0; k < 4; k++) OFX_TRY(d.out(dp[k], hp[k], n));
+    for (int k = 0; k < 4; k++) {
+        OFX_TRY(rof_state_out(ctx, dp[k], hp[k], tmp, nx, ny));
+        OFX_TRY(d.sync());                                        // tmp is reused
+    }
     return d.sync();
 }
 
@@ -865,14 +1053,15 @@ struct OccParams {
 // work planes of a solve, allocated once at the finest level's size
 struct OccWork {
     double *I1x, *I1y, *I_1x, *I_1y, *I1wx, *I1wy, *I_1wx, *I_1wy, *rho1_c, *rho3_c, *grad1, *grad3, *v1, *v2, *vf1, *vf2, *vb1,
-        *vb2, *g, *u1p, *u2p, *f1, *f2, *t1, *t2, *divu, *state, *rof, *part;
-    int alloc(ofx_ctx *ctx, size_t n)
+        *vb2, *g, *u1p, *u2p, *f1, *f2, *t1, *t2, *divu, *state, *eta, *rof, *part;
+    int alloc(ofx_ctx *ctx, size_t n, size_t nskew)
     {
         double **planes[] = {&I1x, &I1y, &I_1x, &I_1y, &I1wx, &I1wy, &I_1wx, &I_1wy, &rho1_c, &rho3_c, &grad1, &grad3, &v1,
                              &v2, &vf1, &vf2, &vb1, &vb2, &g, &u1p, &u2p, &f1, &f2, &t1, &t2, &divu};
         for (auto p : planes) OFX_TRY(ofx_alloc(ctx, n, p));
-        OFX_TRY(ofx_alloc(ctx, 6 * n, &state));
-        OFX_TRY(ofx_alloc(ctx, 6 * n, &rof));
+        OFX_TRY(ofx_alloc(ctx, 4 * nskew, &state));          // dual planes of Solver_wrt_u, hyperplane-major
+        OFX_TRY(ofx_alloc(ctx, 2 * n, &eta));                // dual variable of Solver_wrt_chi
+        OFX_TRY(ofx_alloc(ctx, 6 * nskew, &rof));
         return ofx_alloc(ctx, OCC_ERR_BLOCKS + 1, &part);
     }
 };
@@ -885,8 +1074,10 @@ int occ_single_scale_dev(ofx_ctx *ctx, const double *I_1, const double *I0, cons
     const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), block(64, 4);
     const int g1 = occ_grid1d(n);
     hipStream_t st = ctx->stream;
-    OFX_HIP(ctx, hipMemsetAsync(W.state, 0, 6 * n * sizeof(double), st));
-    double *eta1 = W.state + 4 * n, *eta2 = W.state + 5 * n;
+    const size_t nsk = rof_skew_elems(nx, ny);
+    OFX_HIP(ctx, hipMemsetAsync(W.state, 0, 4 * nsk * sizeof(double), st));
+    OFX_HIP(ctx, hipMemsetAsync(W.eta, 0, 2 * n * sizeof(double), st));
+    double *eta1 = W.eta, *eta2 = W.eta + n;
     OFX_TRY(op_centered_gradient<double>(ctx, filtI0, W.t1, W.t2, nx, ny));
     hipLaunchKernelGGL(k_occ_g, dim3(g1), dim3(256), 0, st, (const double *) W.t1, (const double *) W.t2, W.g, (int) n);
     OFX_TRY(op_centered_gradient<double>(ctx, I1, W.I1x, W.I1y, nx, ny));
@@ -899,7 +1090,7 @@ int occ_single_scale_dev(ofx_ctx *ctx, const double *I_1, const double *I0, cons
                      W.v1, W.v2, W.vf1, W.vf2, W.vb1, W.vb2};
     const OccChi ac = {u1, u2, W.I1wx, W.I1wy, W.I_1wx, W.I_1wy, W.rho1_c, W.rho3_c, W.vf1, W.vf2, W.vb1, W.vb2, W.g, eta1, eta2,
                        W.divu, chi};
-    double *us[2] = {u1, u2}, *ps[2] = {W.state, W.state + 2 * n}, *pe[2] = {W.state + n, W.state + 3 * n};
+    double *us[2] = {u1, u2}, *ps[2] = {W.state, W.state + 2 * nsk}, *pe[2] = {W.state + nsk, W.state + 3 * nsk};
     const double *fs[2] = {W.f1, W.f2};
     double *h_err = reinterpret_cast<double *>(ctx->h_state);        // pinned
     for (int w = 0; w < P.warps; w++) {
@@ -968,7 +1159,7 @@ extern "C" int ofx_tvl1occ_multiscale(ofx_ctx *ctx, const double *I_1, const dou
     const OccParams P = {lambda, alpha, beta, theta, epsilon, warps, verbose};
     const size_t size = (size_t) nxx * nyy;
     OccWork W;
-    OFX_TRY(W.alloc(ctx, size));
+    OFX_TRY(W.alloc(ctx, size, rof_skew_elems(nxx, nyy)));
     struct Lv { double *im[4], *u1, *u2, *chi; };           // im: I_1, I0, I1, filtI0
     std::vector<Lv> lv(nscales);
     for (int s = 0; s < nscales; s++) {

@@ -74,11 +74,12 @@ def test_occlusion_solvers_bitexact(gpu64, orc, nx, ny):
     assert np.array_equal(c2, co)
 
 
-@pytest.mark.parametrize("nx,ny", [(2, 2), (3, 2), (2, 5), (7, 6), (19, 13), (33, 140), (300, 131), (130, 260)])
+@pytest.mark.parametrize("nx,ny", [(2, 2), (3, 2), (2, 5), (7, 6), (19, 13), (33, 140), (300, 131), (130, 260), (5, 400), (400, 3)])
 def test_rof_box_and_solver_wrt_u_bitexact(gpu64, ofx_mod, orc, nx, ny):
-    """the in-place box-relaxation sweep of Scalar_ROF_BoxCellCentered runs on hyperplanes of row blocks (K steps per
-    launch): every dual value and u bit-identical to the sequential sweep, for all nine cell kinds, one and several row
-    blocks (ny > 125), and Solver_wrt_u on top of it with the dual planes carried from call to call"""
+    """the in-place box-relaxation sweep of Scalar_ROF_BoxCellCentered runs on hyperplanes of row blocks (24 steps per launch
+    from an LDS copy of the launch window, blocks 32 steps apart): every dual value and u bit-identical to the sequential sweep,
+    for all nine cell kinds, one and several row blocks (ny > 125, up to 4 here), images narrower than the lag between blocks,
+    and Solver_wrt_u on top of it with the dual planes carried from call to call"""
     rng = np.random.default_rng(nx * 1000 + ny)
     u = rng.standard_normal((ny, nx))
     f = u / 0.3 + rng.standard_normal((ny, nx)) * 0.2
@@ -106,7 +107,7 @@ def test_rof_box_and_solver_wrt_u_bitexact(gpu64, ofx_mod, orc, nx, ny):
 def test_tvl1occ_multiscale(gpu64, synth, orc):
     """the whole TV-L1-with-occlusions solve, device resident, against the oracle (itself pinned against the compiled reference
     in tests/test_oracle_vs_ref.py): same outer-iteration table, flows and occlusion map bit-identical"""
-    for nx, ny, ns, warps in ((64, 48, 2, 2), (90, 70, 3, 1), (160, 120, 3, 2)):
+    for nx, ny, ns, warps in ((64, 48, 2, 2), (90, 70, 3, 1), (160, 120, 3, 2), (200, 300, 4, 1)):
         seq = synth.sequence(nx, ny, 3, 1)
         kw = dict(lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=ns, zfactor=0.5, warps=warps, epsilon=0.01)
         uo, vo, co, it = orc.tvl1occ_multiscale(seq[0], seq[1], seq[2], **kw)
