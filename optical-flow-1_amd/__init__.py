@@ -132,6 +132,7 @@ def lib():
         "ofx_solver_wrt_u": (_i, [_vp] + [_dp] * 6 + [_d, _d, _i, _i] + [_dp] * 4 + [_i]),
         "ofx_solver_wrt_chi": (_i, [_vp] + [_dp] * 14 + [_d] * 6 + [_i, _i, _dp, _dp, _i]),
         "ofx_tvl1occ_multiscale": (_i, [_vp] + [_dp] * 7 + [_i, _i, _d, _d, _d, _d, _i, _d, _i, _d, _i]),
+        "ofx_tvl1occ_batch": (_i, [_vp, _i, _i] + [_vp] * 7 + [_i, _i, _d, _d, _d, _d, _i, _d, _i, _d]),
         "ofx_hs_classic": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _d]),
         "ofx_brox_temporal": (_i, [_vp, _dp, _dp, _dp, _i, _i, _i, _d, _d, _i, _d, _d, _i, _i, _i]),
     }
@@ -191,6 +192,21 @@ def hs_batch_dev(ctxs, dI1, dI2, d_flo, nx, ny, alpha=7.0, nscales=10, zfactor=0
 def brox_batch_dev(ctxs, dI1, dI2, d_flo, nx, ny, alpha=50.0, gamma=10.0, nscales=10, nu=0.5, TOL=1e-4, inner=1, outer=15):
     """ofx_brox_batch_dev (see hs_batch_dev)"""
     return _batch_call(lib().ofx_brox_batch_dev, ctxs, dI1, dI2, d_flo, nx, ny, alpha, gamma, nscales, nu, TOL, inner, outer)
+
+
+def tvl1occ_batch(ctxs, triples, lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=3, zfactor=0.5, warps=2, epsilon=0.01):
+    """ofx_tvl1occ_batch: triples = list of (I_1, I0, I1) or (I_1, I0, I1, filtI0) host images, triple k on ctxs[k % len(ctxs)]
+    (one host thread per context inside the library).  Returns a list of (u1, u2, chi)."""
+    n = len(triples)
+    ny, nx = triples[0][1].shape
+    ins = [[_f64(t[k] if k < len(t) else t[1]) for t in triples] for k in range(4)]
+    outs = [[np.empty((ny, nx)) for _ in range(n)] for _ in range(3)]
+    ptr = lambda arrs: (_vp * n)(*[a.ctypes.data for a in arrs])
+    s = lib().ofx_tvl1occ_batch((_vp * len(ctxs))(*[c.h.value for c in ctxs]), len(ctxs), n, *[ptr(a) for a in ins],
+                                *[ptr(a) for a in outs], nx, ny, lam, alpha, beta, theta, nscales, zfactor, warps, epsilon)
+    if s:
+        raise OfxError(s, "; ".join((c.L.ofx_last_error(c.h) or b"").decode() for c in ctxs))
+    return list(zip(*outs))
 
 
 def tvl1_batch_group_size(ctxs, n_pairs, nx, ny, nscales=5, zfactor=0.5):

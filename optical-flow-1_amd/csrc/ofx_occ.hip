@@ -8,6 +8,9 @@
 #include "ofx_ops.h"
 #include "ofx_device.h"
 
+#include <atomic>
+#include <thread>
+
 #define OCC_IS_ZERO 1E-10      // src/tvl1occflow_constants.h:31
 #define OCC_THR_CHI 0.75       // src/tvl1occflow_constants.h:32
 #define OCC_MM_BLOCKS 256
@@ -787,11 +790,11 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
     }
     const int B = ofx_cdiv(ny, ROF_R), qmax = 2 * (ny - 1) + nx - 1;
     const long total = (long) qmax + 1 + (long) ROF_LAG * (B - 1);
-    static bool lds_set = false;                       // same value for every device; the attribute belongs to the function
-    if (!lds_set) {
+    static std::atomic<unsigned> lds_set(0);           // bit d: the attribute has been set on device d (per device, any thread)
+    if (!(lds_set.load() & (1u << (ctx->device & 31)))) {
         OFX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_rof_window), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int) ROF_LDS_BYTES));
-        lds_set = true;
+        lds_set.fetch_or(1u << (ctx->device & 31));
     }
     for (int it = 0; it < n_iter; it++) {
         hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
@@ -1208,4 +1211,31 @@ extern "C" int ofx_tvl1occ_multiscale(ofx_ctx *ctx, const double *I_1, const dou
     OFX_TRY(d.sync());
     S.total_ms = ofx_now_ms() - t0;
     return OFX_OK;
+}
+
+// Several independent triples: one solve is bound by the latency of the ROF sweeps (a chain of ~ 2 ny + nx steps that only
+// ny / 125 workgroups work on), so independent solves overlap almost perfectly when they are issued on different streams.
+// Triple k runs on context k mod n_ctx, one host thread per context; all contexts on one device.
+extern "C" int ofx_tvl1occ_batch(ofx_ctx *const *ctxs, int n_ctx, int n_triples, const double *const *I_1, const double *const *I0,
+                                 const double *const *I1, const double *const *filtI0, double *const *u1, double *const *u2,
+                                 double *const *chi, int nxx, int nyy, double lambda, double alpha, double beta, double theta,
+                                 int nscales, double zfactor, int warps, double epsilon)
+{
+    if (!ctxs || n_ctx < 1 || n_triples < 0 || !I_1 || !I0 || !I1 || !filtI0 || !u1 || !u2 || !chi) return OFX_ERR_ARG;
+    for (int w = 0; w < n_ctx; w++)
+        if (!ctxs[w] || ctxs[w]->device != ctxs[0]->device) return OFX_ERR_ARG;
+    std::atomic<int> status(OFX_OK);
+    auto worker = [&](int w) {
+        for (int k = w; k < n_triples; k += n_ctx) {
+            if (status.load() != OFX_OK) return;
+            const int s = ofx_tvl1occ_multiscale(ctxs[w], I_1[k], I0[k], I1[k], filtI0[k], u1[k], u2[k], chi[k], nxx, nyy, lambda,
+                                                 alpha, beta, theta, nscales, zfactor, warps, epsilon, 0);
+            if (s != OFX_OK) { int expected = OFX_OK; status.compare_exchange_strong(expected, s); return; }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < n_ctx && w < n_triples; w++) th.emplace_back(worker, w);
+    worker(0);
+    for (auto &t : th) t.join();
+    return status.load();
 }

@@ -123,3 +123,19 @@ def test_tvl1occ_arguments(gpu64, ofx_mod):
     for kw in (dict(nscales=0), dict(warps=0), dict(zfactor=1.0), dict(theta=0.0), dict(nscales=9)):
         with pytest.raises(ofx_mod.OfxError):
             gpu64.tvl1occ_multiscale(z, z, z, **kw)
+
+
+def test_tvl1occ_batch_over_contexts(ofx_mod, gpu64, synth):
+    """independent triples on several contexts (host thread + stream each) give what one context gives, in the order of the input"""
+    ctxs = [ofx_mod.Ofx(0, ofx_mod.F64) for _ in range(3)]
+    kw = dict(nscales=3, warps=1)
+    triples = []
+    for k in range(5):
+        seq = synth.sequence(96, 72, 3, k + 1)
+        triples.append((seq[0], seq[1], seq[2]) if k % 2 else (seq[2], seq[1], seq[0], seq[1]))
+    got = ofx_mod.tvl1occ_batch(ctxs, triples, **kw)
+    for t, (u, v, c) in zip(triples, got):
+        wu, wv, wc = gpu64.tvl1occ_multiscale(*t[:3], **kw)
+        assert np.array_equal(u, wu) and np.array_equal(v, wv) and np.array_equal(c, wc)
+    with pytest.raises(ofx_mod.OfxError):
+        ofx_mod.tvl1occ_batch(ctxs, triples, nscales=0)

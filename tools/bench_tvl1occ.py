@@ -21,6 +21,7 @@ ap.add_argument("--size", action="append")
 ap.add_argument("--cpu", default="ref")
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--warps", type=int, default=2)
+ap.add_argument("--batch", default="", help="contexts:triples, e.g. 4:8 -- also time a batch of independent triples")
 a = ap.parse_args()
 ctx = ofx.Ofx(0, ofx.F64)
 for size in a.size or ["320x240"]:
@@ -50,4 +51,13 @@ for size in a.size or ["320x240"]:
         rec["speedup"] = round(rec["cpu_s"] / gpu_s, 2)
         if a.check:
             rec["max_abs_diff"] = float(max(np.abs(u - r[0]).max(), np.abs(v - r[1]).max(), np.abs(c - r[2]).max()))
+    if a.batch:
+        n_ctx, n_tr = (int(v) for v in a.batch.split(":"))
+        ctxs = [ofx.Ofx(0, ofx.F64) for _ in range(n_ctx)]
+        triples = [tuple(synth.sequence(nx, ny, 3, k + 1)) for k in range(n_tr)]
+        ofx.tvl1occ_batch(ctxs, triples[:n_ctx], **dict(kw, nscales=1, warps=1))                # warm every context
+        t = time.perf_counter()
+        ofx.tvl1occ_batch(ctxs, triples, **kw)
+        bt = time.perf_counter() - t
+        rec["batch"] = {"contexts": n_ctx, "triples": n_tr, "seconds": round(bt, 4), "s_per_triple": round(bt / n_tr, 4)}
     print(json.dumps(rec), flush=True)
