@@ -20,8 +20,9 @@ payloads to rank 0.  The pairs of a rank are solved in ROUNDS and the gather of 
 own stream) while round r + 1 computes, so only the last round's transfer is exposed (`gather_ms`).
 
 The line also carries: `fixed_work` (option "fixed_work": every warp runs exactly 300 iterations, SURVEY 8d);
-`roofline` / `roofline_4k` for the dominant kernel k_tvl1_iter2, measured on a fixed-work pass with HIP events on the
-library's own stream; `sor` (BASELINE configs 3 / 4: exact Horn-Schunck and Brox solves); `cpu_baseline` (the compiled
+`roofline` / `roofline_4k` for the dominant kernel k_tvl1_iter2 as the job launches it (one launch = a lockstep group of
+up to 16 pairs), measured on fixed-work passes with HIP events on the library's own stream, with the one-pair launch beside
+it (`single_pair`); `sor` (BASELINE configs 3 / 4: exact Horn-Schunck and Brox solves); `cpu_baseline` (the compiled
 reference, oracle/_ref, on the host cores; rank 0 at N = 1 only).
 """
 import argparse
@@ -184,9 +185,12 @@ def load_pmc():
         return {}
 
 
-def roofline_of(ctx, solve_one, precision, nx, ny, passes):
-    """Fixed-work passes of ONE pair alone with HIP events (on the library's stream) around the iteration launches of
-    every level.  Returns (roofline dict for the full-resolution k_tvl1_iter2 launches, per-level list, work, seconds).
+def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None):
+    """Fixed-work passes with HIP events (on the library's stream) around the iteration launches of every level: of ONE pair
+    alone (per-level table, `single_pair`), and -- group = (G, solve_group) -- of a lockstep group of G pairs, which is how
+    the timed region launches the kernel (one launch = G pairs; blockIdx.y/z = pair).  The roofline is quoted on the group
+    launch when given: bytes and duration both per launch of G pairs.  Returns (roofline dict for the full-resolution
+    k_tvl1_iter2 launches, per-level list, work, seconds).
 
     Bytes: the kernel fuses TWO iterations per launch and touches every stream once per launch, so its compulsory
     HBM traffic is 15 storage elements per pixel PER LAUNCH (read U,P1,P2,A,R = 9, write U,P1,P2 = 6): `achieved` and
@@ -214,29 +218,56 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes):
     ctx.set_option("profile", 0)
     ctx.set_option("fixed_work", 0)
     us_iter = lv_ms[0] * 1e3 / max(lv_n[0], 1)            # per ITERATION (stats count iterations)
-    us_launch = 2.0 * us_iter
-    fused = 15.0 * elem * nx * ny                         # bytes per launch, compulsory for the fused kernel
-    ach = fused / (us_launch * 1e-6) / 1e9
-    equiv = 2.0 * fused / (us_launch * 1e-6) / 1e9
+    us_single = 2.0 * us_iter
+    fused = 15.0 * elem * nx * ny                         # bytes per pair and launch, compulsory for the fused kernel
+    G, us_launch, n_launch = 1, us_single, int(lv_n[0] // 2)
+    if group:
+        G, solve_group = group
+        ctx.set_option("profile", 1)
+        ctx.set_option("fixed_work", 1)
+        solve_group()                                    # warm (level arrays of G pairs)
+        g_ms, g_n = 0.0, 0
+        for _ in range(max(1, passes)):
+            st_g = solve_group()
+            g_ms += st_g[0].iter_ms[0]                   # the group's launches, recorded on every member
+            g_n += st_g[0].iter_launches[0] // 2
+        ctx.synchronize()
+        ctx.set_option("profile", 0)
+        ctx.set_option("fixed_work", 0)
+        us_launch, n_launch = g_ms * 1e3 / max(g_n, 1), g_n
+    ach = G * fused / (us_launch * 1e-6) / 1e9
+    equiv = 2.0 * ach
+    tname = "double" if precision == "f64" else "float"
     roof = {"bound": "hbm",
-            "kernel": "k_tvl1_iter2<%s> @ %dx%d (2 fused iterations per launch)" % ("double" if precision == "f64" else "float", nx, ny),
+            "kernel": "k_tvl1_iter2<%s> @ %dx%d (2 fused iterations per launch, %d pair%s per launch)" % (tname, nx, ny, G, "" if G == 1 else "s"),
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": None, "avg_launch_us": round(us_launch, 3), "launches": int(lv_n[0] // 2),
-            "fused_algorithmic_bytes_per_launch": fused,
-            "bytes_model": "15 storage elements/px per LAUNCH (2 fused iterations): read U,P1,P2,A,R + write U,P1,P2",
-            "algorithmic_equivalent_bytes_per_launch": 2.0 * fused,
+            "traffic": None, "avg_launch_us": round(us_launch, 3), "launches": n_launch, "pairs_per_launch": G,
+            "fused_algorithmic_bytes_per_launch": G * fused,
+            "bytes_model": "15 storage elements/px per pair and LAUNCH (2 fused iterations): read U,P1,P2,A,R + write U,P1,P2",
+            "algorithmic_equivalent_bytes_per_launch": 2.0 * G * fused,
             "algorithmic_equivalent_gbs": round(equiv, 1),
             "algorithmic_equivalent_frac": round(equiv / HBM_PEAK_GBS, 4),
             "algorithmic_equivalent_note": "SURVEY 8(d): 15 elements/px per ITERATION x 2 iterations per launch; the rate an "
                                            "unfused kernel would need -- may exceed the HBM peak, not a bandwidth",
-            "mpix_iters_per_s": round(nx * ny / us_iter, 1)}
+            "mpix_iters_per_s": round(2.0 * G * nx * ny / us_launch, 1)}
+    if group:
+        a1 = fused / (us_single * 1e-6) / 1e9
+        roof["single_pair"] = {"avg_launch_us": round(us_single, 3), "achieved": round(a1, 1), "frac": round(a1 / HBM_PEAK_GBS, 4),
+                               "note": "the same kernel launched for one pair alone: start-up and drain of every launch exposed "
+                                       "(at 1080p one pair is 2880 waves, less than one round of the 3072 wave slots)"}
     pmc = load_pmc()
     key = "%s_%dx%d" % (precision, nx, ny)
-    tr = pmc.get("bytes_per_launch_" + key)
+    tr = pmc.get("bytes_per_launch_group%d_%s" % (G, key)) if G > 1 else pmc.get("bytes_per_launch_" + key)
+    src = "profiles/pmc_traffic.json (builder-run rocprofv3 --pmc passes, not measured by this run)"
+    if not tr and G > 1 and pmc.get("bytes_per_launch_" + key):
+        tr = G * pmc["bytes_per_launch_" + key]
+        src += "; counter value of a one-pair launch x %d pairs" % G
     if tr:
-        det = pmc.get("detail_%dx%d" % (nx, ny), {}) if precision == "f64" else {}
+        det = {}
+        if precision == "f64":
+            det = (pmc.get("detail_group%d_%dx%d" % (G, nx, ny)) if G > 1 else None) or pmc.get("detail_%dx%d" % (nx, ny), {})
         roof["traffic"] = tr
-        roof["traffic_source"] = "profiles/pmc_traffic.json (builder-run rocprofv3 --pmc passes, not measured by this run)"
+        roof["traffic_source"] = src
         roof["hbm_frac_counter"] = round(tr / (us_launch * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         if "valu_active_fraction" in det:
             roof["valu_active"] = round(det["valu_active_fraction"], 3)
@@ -497,7 +528,12 @@ def main():
         def one():
             ctx.tvl1_multiscale_dev(dI0s[0].data_ptr(), dI1s[0].data_ptr(), flo[0].data_ptr(), nx, ny, **PAR)
             return ctx.stats().work_pix_iters
-        roof, levels, fw, tf = roofline_of(ctx, one, a.precision, nx, ny, a.fixed_steps)
+        gsz = min(lockstep, nsteps)
+
+        def grp():
+            return ctx.tvl1_group_dev([dI0s[var_of(i)].data_ptr() for i in range(gsz)], [dI1s[var_of(i)].data_ptr() for i in range(gsz)],
+                                      [flo[i].data_ptr() for i in range(gsz)], nx, ny, **PAR)
+        roof, levels, fw, tf = roofline_of(ctx, one, a.precision, nx, ny, a.fixed_steps, (gsz, grp) if gsz > 1 else None)
         ctx.set_option("concurrency", a.concurrency or nstreams)
         log("fixed-work pass: %d steps in %.3f s" % (a.fixed_steps, tf))
         fixed = {"value": round(fw_par / tq / 1e6, 1), "unit": "Mpix*warp-iters/s",
@@ -514,7 +550,15 @@ def main():
             def one4k():
                 ctx.tvl1_multiscale_dev(j0.data_ptr(), j1.data_ptr(), f4.data_ptr(), 3840, 2160, **PAR)
                 return ctx.stats().work_pix_iters
-            roof4k, lv4, fw4, tf4 = roofline_of(ctx, one4k, a.precision, 3840, 2160, 1)
+            g4 = 4                                       # pairs per launch of the 4K leg (the 4k-batch workload uses 4 .. 16)
+            jj = [synth.pair_device(a.pair, 3840, 2160, 2 + k, dev, tdt) for k in range(g4 - 1)]
+            ff = [torch.empty((2160, 3840, 2), dtype=torch.float32, device=dev) for _ in range(g4 - 1)]
+
+            def grp4k():
+                return ctx.tvl1_group_dev([j0.data_ptr()] + [t[0].data_ptr() for t in jj], [j1.data_ptr()] + [t[1].data_ptr() for t in jj],
+                                          [f4.data_ptr()] + [t.data_ptr() for t in ff], 3840, 2160, **PAR)
+            roof4k, lv4, fw4, tf4 = roofline_of(ctx, one4k, a.precision, 3840, 2160, 1, (g4, grp4k))
+            del jj, ff
             roof4k["single_pair_fixed_work"] = {"value": round(fw4 / tf4 / 1e6, 1), "unit": "Mpix*warp-iters/s", "levels": lv4}
             ctx.set_option("concurrency", a.concurrency or nstreams)
             del j0, j1, f4

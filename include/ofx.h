@@ -105,6 +105,8 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         two iterations; 1 (default) = a launch also stores it when the previous error is within 1.5x
  *                         of the threshold (the host then just switches buffers), 0 = never (the iteration is
  *                         recomputed alone), 2 = always.  Results are bit-identical in all three settings.
+ *   "nt_stores"      fused TV-L1 kernel: 0 (default) non-temporal stores when a launch's working set exceeds the Infinity
+ *                    Cache, 1 always, 2 never (A/B measurements)
  *   "warp_lds"       1/0  TV-L1 warp with the bicubic taps staged through LDS (default 1)
  *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default 0 = ofx_tvl1_batch_group_size's
  *                         rule: as large as possible, evened out over the contexts; at most 16)

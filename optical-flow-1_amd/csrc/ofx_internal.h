@@ -59,6 +59,7 @@ struct ofx_ctx {
                         // (odd stops are recomputed), 2 always (tests)
     int concurrency;    // contexts expected to share the device (tuning hint, default 1)
     int lockstep;       // pairs per lockstep group in ofx_tvl1_batch_dev (0 = default)
+    int nt_stores;      // fused TV-L1 kernel: 0 (default) non-temporal stores once a launch's working set exceeds the Infinity Cache, 1 always, 2 never
     int warp_lds;       // 1 (default): TV-L1 warp with the taps staged through LDS; 0: gathered from global memory
     int chunk;
     int fixed_work;

@@ -837,7 +837,7 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
     const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
     const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
     // one launch touches 15 storage elements per pixel; beyond the Infinity Cache its output is streamed out
-    const bool nt_stores = (double) nx * ny * G * 15.0 * sizeof(T) > 300e6;
+    const bool nt_stores = ctx->nt_stores ? ctx->nt_stores == 1 : (double) nx * ny * G * 15.0 * sizeof(T) > 300e6;
     // Launch unit j (a fused pair of iterations, or a single one) of pair g reads buffer (b_g + j) % 3 of the rotation
     // and writes (b_g + j + 1) % 3; (b_g + j + 2) % 3 receives the intermediate state of a fused pair (tvl1_store_a).
     unsigned b0[OFX_MAX_GROUP];

@@ -39,8 +39,11 @@ def test_bench_one_gpu_line_has_roofline_keys():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    for k in ("fused_algorithmic_bytes_per_launch", "algorithmic_equivalent_bytes_per_launch", "avg_launch_us"):
+    for k in ("fused_algorithmic_bytes_per_launch", "algorithmic_equivalent_bytes_per_launch", "avg_launch_us", "pairs_per_launch"):
         assert k in r, k
+    # quoted on the launch as the job issues it (a lockstep group), with the one-pair launch beside it; bytes scale with the group
+    assert r["pairs_per_launch"] > 1 and 0 < r["single_pair"]["frac"] <= 1.0
+    assert abs(r["achieved"] * r["avg_launch_us"] * 1e3 - r["fused_algorithmic_bytes_per_launch"]) < 1e-3 * r["fused_algorithmic_bytes_per_launch"]
 
 
 @pytest.mark.gpu

@@ -92,6 +92,46 @@ for sz in ("1920x1080", "3840x2160"):
                           "clock_ghz": vals["GRBM_GUI_ACTIVE"] / 8 / (vals["launch_us_fetch"] * 1e-6) / 1e9,
                           "launch_us": vals["launch_us_fetch"], "valu_insts_per_launch": vals["SQ_INSTS_VALU"],
                           "waves": vals["SQ_WAVES"]}
+# ---- the same counters on lockstep-group launches (tools/pmc_group.py) ----
+for sz, G in (("1920x1080", 16), ("3840x2160", 4)):
+    vals = {}
+    for kind in ("fetch", "write", "sq"):
+        f = newest(os.path.join(SRC, "pmcg_%s_%s" % (kind, sz), "*", "*_counter_collection.csv"))
+        kt = newest(os.path.join(SRC, "pmcg_%s_%s" % (kind, sz), "*", "*_kernel_trace.csv"))
+        if not f or not kt:
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            if "k_tvl1_iter2" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            vals[k] = sum(v) / len(v)
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt[0])) if "k_tvl1_iter2" in r["Kernel_Name"]]
+        vals["launch_us_" + kind] = sum(d) / len(d)
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        continue
+    nx, ny = map(int, sz.split("x"))
+    rd, wr = 2 * vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
+    pm["bytes_per_launch_group%d_f64_%s" % (G, sz)] = rd + wr
+    det = {"pairs_per_launch": G, "read_bytes": rd, "write_bytes": wr, "fused_compulsory_bytes_per_launch": G * 120.0 * nx * ny,
+           "traffic_over_fused_compulsory": (rd + wr) / (G * 120.0 * nx * ny), "launch_us": vals["launch_us_fetch"],
+           "counter_tb_per_s": (rd + wr) / (vals["launch_us_fetch"] * 1e-6) / 1e12}
+    if "TCC_HIT_sum" in vals:
+        det["l2_hit_rate"] = vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])
+    if "SQ_ACTIVE_INST_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
+        clk = vals["GRBM_GUI_ACTIVE"] / 8 / (vals["launch_us_fetch"] * 1e-6)
+        det["clock_ghz"] = clk / 1e9
+        det["valu_active_fraction"] = 4 * vals["SQ_ACTIVE_INST_VALU"] / 1024 / (vals["launch_us_sq"] * 1e-6 * clk)
+    pm["detail_group%d_%s" % (G, sz)] = det
+gt = newest(os.path.join(SRC, "trace_group", "*", "*_kernel_stats.csv"))
+if gt:
+    rows = [r for r in csv.DictReader(open(gt[0])) if "k_tvl1_iter2" in r["Name"]]
+    open(os.path.join(DST, tag + "_group_launch_kernel_stats.txt"), "w").write(
+        "# rocprofv3 --kernel-trace --stats -- python3 tools/pmc_group.py 1920x1080 G=16   (150 launches of 16 pairs, fixed work)\n"
+        "# kernel | calls | total ms | average us\n" +
+        "".join("%-100s %6s %10.3f %10.3f\n" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3) for r in rows) +
+        "# bench.py roofline (HIP events, same launches): %.2f us per launch of %d pairs\n" % (bench["roofline"]["avg_launch_us"], bench["roofline"].get("pairs_per_launch", 1)))
+
 for sz, ceil in (("1920x1080", "arithmetic alone 92 % of the production time, memory traffic alone 61 % -> VALU-bound (working set inside the 256 MiB Infinity Cache)"),
                  ("3840x2160", "arithmetic alone 81 % of the production time, memory traffic alone 70 % -> neither hides the other (4 waves per SIMD at 128 VGPRs)")):
     if "detail_" + sz not in pm:
@@ -104,9 +144,11 @@ for sz, ceil in (("1920x1080", "arithmetic alone 92 % of the production time, me
                                                                                                       100 * rate / 8, d["launch_us"], d["clock_ghz"])) + ceil
 json.dump(pm, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 # the committed bench line carries the traffic measured in THIS collection (bench.py reads the previous file)
-key = "bytes_per_launch_%s_%s" % (bench["dtype"], bench["roofline"]["kernel"].split("@ ")[1].split(" ")[0])
+gpl = bench["roofline"].get("pairs_per_launch", 1)
+key = "bytes_per_launch_%s%s_%s" % ("group%d_" % gpl if gpl > 1 else "", bench["dtype"], bench["roofline"]["kernel"].split("@ ")[1].split(" ")[0])
 if key in pm:
     bench["roofline"]["traffic"] = pm[key]
+    bench["roofline"]["hbm_frac_counter"] = round(pm[key] / (bench["roofline"]["avg_launch_us"] * 1e-6) / 8e12, 4)
     json.dump(bench, open(os.path.join(DST, tag + "_bench.json"), "w"))
 print(json.dumps(pm, indent=1))
 print("\n".join(out[-8:]))
