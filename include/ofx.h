@@ -316,9 +316,11 @@ int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *u2, double 
 int ofx_tvl1occ_multiscale(ofx_ctx *ctx, const double *I_1, const double *I0, const double *I1, const double *filtI0, double *u1,
                            double *u2, double *chi, int nxx, int nyy, double lambda, double alpha, double beta, double theta,
                            int nscales, double zfactor, int warps, double epsilon, int verbose);
-/* n_triples independent solves, triple k on context k mod n_ctx (one host thread and one stream per context, all on one
- * device): a single solve is bound by the latency of its sequential ROF sweeps and uses a few workgroups, so solves on different
- * streams overlap.  Arrays of n_triples host pointers.  Returns the first failing status (detail text on that context). */
+/* n_triples independent solves (e.g. the frames of a sequence), cut into lockstep groups of up to 16 consecutive triples
+ * (option "lockstep" of ctxs[0]; fewer when the device memory -- option "mem_budget", default half of what is free -- does
+ * not hold that many): the triples of a group share every kernel launch of a context, group q runs on context q mod n_ctx
+ * (one host thread and one stream per context, all on one device).  Every result is bit-identical to the triple solved alone.
+ * Arrays of n_triples host pointers.  Returns the first failing status (detail text on that context). */
 int ofx_tvl1occ_batch(ofx_ctx *const *ctxs, int n_ctx, int n_triples, const double *const *I_1, const double *const *I0,
                       const double *const *I1, const double *const *filtI0, double *const *u1, double *const *u2,
                       double *const *chi, int nxx, int nyy, double lambda, double alpha, double beta, double theta, int nscales,

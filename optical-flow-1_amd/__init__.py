@@ -195,8 +195,9 @@ def brox_batch_dev(ctxs, dI1, dI2, d_flo, nx, ny, alpha=50.0, gamma=10.0, nscale
 
 
 def tvl1occ_batch(ctxs, triples, lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=3, zfactor=0.5, warps=2, epsilon=0.01):
-    """ofx_tvl1occ_batch: triples = list of (I_1, I0, I1) or (I_1, I0, I1, filtI0) host images, triple k on ctxs[k % len(ctxs)]
-    (one host thread per context inside the library).  Returns a list of (u1, u2, chi)."""
+    """ofx_tvl1occ_batch: triples = list of (I_1, I0, I1) or (I_1, I0, I1, filtI0) host images; lockstep groups of up to 16
+    consecutive triples, group q on ctxs[q % len(ctxs)] (one host thread per context inside the library).  Returns a list of
+    (u1, u2, chi)."""
     n = len(triples)
     ny, nx = triples[0][1].shape
     ins = [[_f64(t[k] if k < len(t) else t[1]) for t in triples] for k in range(4)]

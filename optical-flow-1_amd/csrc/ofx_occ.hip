@@ -18,6 +18,21 @@
 
 static inline int occ_grid1d(size_t n) { return (int) ((n + 255) / 256); }
 
+// Lockstep groups of TV-L1-with-occlusions solves (ofx_tvl1occ_batch): triple g = blockIdx.z works on planes offset by
+// g * stride elements; bit g of mask = that triple is still iterating (its workgroups return at once otherwise, its state
+// stays frozen).  The operator-level entry points pass {0, 1} with gridDim.z = 1.
+struct OccGrp {
+    size_t stride;
+    unsigned mask;
+};
+#define OCC_ONE OccGrp{0, 1u}
+static __device__ __forceinline__ bool occ_grp(const OccGrp &G, size_t &off)
+{
+    if (!((G.mask >> blockIdx.z) & 1u)) return false;
+    off = (size_t) blockIdx.z * G.stride;
+    return true;
+}
+
 namespace {
 
 struct Dev {                   // upload / download helpers on the context's arena and stream
@@ -274,10 +289,12 @@ struct OccV {
     const double *u1, *u2, *chi, *I1wx, *I1wy, *I_1wx, *I_1wy, *rho1_c, *rho3_c, *grad1, *grad3;
     double *v1, *v2, *Vfwd_1, *Vfwd_2, *Vbck_1, *Vbck_2;
 };
-__global__ void k_occ_v(OccV a, int size, double alpha, double theta, double lambda)
+__global__ void k_occ_v(OccV a, int size, double alpha, double theta, double lambda, OccGrp G)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= size) return;
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t o;
+    if (i0 >= size || !occ_grp(G, o)) return;
+    const size_t i = o + i0;
     const double l_t = lambda * theta;
     const double _1pat = 1. + alpha * theta;
     const double at_d_1pat = alpha * theta / _1pat;
@@ -332,7 +349,7 @@ extern "C" int ofx_solver_wrt_v(ofx_ctx *ctx, const double *u1, const double *u2
     for (int k = 0; k < 6; k++) OFX_TRY(ofx_alloc(ctx, n, &dout[k]));
     const OccV a = {di[0], di[1], di[2], di[3], di[4], di[5], di[6], di[7], di[8], di[9], di[10],
                     dout[0], dout[1], dout[2], dout[3], dout[4], dout[5]};
-    hipLaunchKernelGGL(k_occ_v, dim3(occ_grid1d(n)), dim3(256), 0, ctx->stream, a, (int) n, alpha, theta, lambda);
+    hipLaunchKernelGGL(k_occ_v, dim3(occ_grid1d(n)), dim3(256), 0, ctx->stream, a, (int) n, alpha, theta, lambda, OCC_ONE);
     OFX_LAUNCH_CHECK(ctx);
     for (int k = 0; k < 6; k++) OFX_TRY(d.out(dout[k], outs[k], n));
     return d.sync();
@@ -343,12 +360,13 @@ extern "C" int ofx_solver_wrt_v(ofx_ctx *ctx, const double *u1, const double *u2
 // right / lower neighbour; (b) chi += tau_chi (div(g eta) - F - G - beta div u), clamped to [0, 1] -- reads eta of the left
 // / upper neighbour.  The kernel boundary between them is the only synchronisation needed.
 __global__ void k_occ_eta(const double *__restrict__ chi, const double *__restrict__ g, double *__restrict__ eta1,
-                          double *__restrict__ eta2, int nx, int ny, double tau_eta)
+                          double *__restrict__ eta2, int nx, int ny, double tau_eta, OccGrp G)
 {
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
-    if (j >= nx || i >= ny) return;
-    const size_t p = (size_t) i * nx + j;
+    size_t o;
+    if (j >= nx || i >= ny || !occ_grp(G, o)) return;
+    const size_t p = o + (size_t) i * nx + j;
     const double c = chi[p];
     const double chix = (j < nx - 1) ? chi[p + 1] - c : 0.0;          // forward_gradient, src/operators.cpp:86-125
     const double chiy = (i < ny - 1) ? chi[p + nx] - c : 0.0;
@@ -367,12 +385,14 @@ __global__ void k_occ_eta(const double *__restrict__ chi, const double *__restri
     eta2[p] = e2;
 }
 
-__global__ void k_occ_divu(const double *__restrict__ u1, const double *__restrict__ u2, double *__restrict__ div, int nx, int ny)
+__global__ void k_occ_divu(const double *__restrict__ u1, const double *__restrict__ u2, double *__restrict__ div, int nx, int ny,
+                           OccGrp G)
 {
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
-    if (j >= nx || i >= ny) return;
-    const size_t p = (size_t) i * nx + j;
+    size_t o;
+    if (j >= nx || i >= ny || !occ_grp(G, o)) return;
+    const size_t p = o + (size_t) i * nx + j;
     const double al = j > 0 ? u1[p - 1] : 0.0, bu = i > 0 ? u2[p - nx] : 0.0;
     div[p] = div_backward(u1[p], al, u2[p], bu, j == 0, j == nx - 1, i == 0, i == ny - 1);
 }
@@ -381,12 +401,14 @@ struct OccChi {
     const double *u1, *u2, *I1wx, *I1wy, *I_1wx, *I_1wy, *rho1_c, *rho3_c, *Vf1, *Vf2, *Vb1, *Vb2, *g, *eta1, *eta2, *div_u;
     double *chi;
 };
-__global__ void k_occ_chi(OccChi a, int nx, int ny, double lambda, double theta, double alpha, double beta, double tau_chi)
+__global__ void k_occ_chi(OccChi a, int nx, int ny, double lambda, double theta, double alpha, double beta, double tau_chi,
+                          OccGrp grp)
 {
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
-    if (j >= nx || i >= ny) return;
-    const size_t p = (size_t) i * nx + j;
+    size_t o;
+    if (j >= nx || i >= ny || !occ_grp(grp, o)) return;
+    const size_t p = o + (size_t) i * nx + j;
     // divergence of (g eta1, g eta2), src/operators.cpp:35-78
     const double ac = a.g[p] * a.eta1[p], bc = a.g[p] * a.eta2[p];
     const double al = j > 0 ? a.g[p - 1] * a.eta1[p - 1] : 0.0, bu = i > 0 ? a.g[p - nx] * a.eta2[p - nx] : 0.0;
@@ -429,14 +451,14 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
     for (int k = 0; k < 16; k++) OFX_TRY(d.in(ins[k], &di[k], n));
     OFX_TRY(ofx_alloc(ctx, n, &div_u));
     const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), block(64, 4);
-    hipLaunchKernelGGL(k_occ_divu, grid, block, 0, ctx->stream, (const double *) di[0], (const double *) di[1], div_u, nx, ny);
+    hipLaunchKernelGGL(k_occ_divu, grid, block, 0, ctx->stream, (const double *) di[0], (const double *) di[1], div_u, nx, ny, OCC_ONE);
     OFX_LAUNCH_CHECK(ctx);
     const OccChi a = {di[0], di[1], di[2], di[3], di[4], di[5], di[6], di[7], di[8], di[9], di[10], di[11], di[12], di[14], di[15],
                       div_u, di[13]};
     for (int it = 0; it < n_iter; it++) {
         hipLaunchKernelGGL(k_occ_eta, grid, block, 0, ctx->stream, (const double *) di[13], (const double *) di[12], di[14], di[15],
-                           nx, ny, tau_eta);
-        hipLaunchKernelGGL(k_occ_chi, grid, block, 0, ctx->stream, a, nx, ny, lambda, theta, alpha, beta, tau_chi);
+                           nx, ny, tau_eta, OCC_ONE);
+        hipLaunchKernelGGL(k_occ_chi, grid, block, 0, ctx->stream, a, nx, ny, lambda, theta, alpha, beta, tau_chi, OCC_ONE);
     }
     OFX_LAUNCH_CHECK(ctx);
     OFX_TRY(d.out(di[13], chi, n));
@@ -647,13 +669,20 @@ OFX_DEV void rof_cell(const RofRing &r, int ci, int cj, double w, RofPre &pre, b
 // (independent) problems
 struct RofSet {
     RofArr a[2];
+    size_t stride;                   // lockstep groups: problem set g = blockIdx.z works on arrays offset by g * stride
+    unsigned mask;                   // bit g: still iterating
 };
 __global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, double w)
 {
     extern __shared__ double2 rof_lds[];
     double2 (*win)[ROF_NT] = reinterpret_cast<double2 (*)[ROF_NT]>(rof_lds);
     double (*cf)[ROF_NT] = reinterpret_cast<double (*)[ROF_NT]>(rof_lds + ROF_RING * ROF_NT);
-    const RofArr a = blockIdx.y ? s.a[1] : s.a[0];                          // by value: a dynamic index would be re-read from the kernel arguments at every use
+    if (!((s.mask >> blockIdx.z) & 1u)) return;
+    RofArr a = blockIdx.y ? s.a[1] : s.a[0];                                // by value: a dynamic index would be re-read from the kernel arguments at every use
+    {
+        const size_t off = (size_t) blockIdx.z * s.stride;
+        a.Ps += off; a.Pe += off; a.Fs += off; a.Fe += off; a.AL += off;
+    }
     const int nx = a.nx, ny = a.ny;
     const int t = (int) threadIdx.x, row0 = (int) blockIdx.x * ROF_R - 2;
     const int qmax = 2 * (ny - 1) + nx - 1;
@@ -735,11 +764,13 @@ __global__ void k_rof_skew(const double *__restrict__ in, double *__restrict__ o
     else out[c] = in[k];
 }
 // edge differences of f (once per call), :137-164
-__global__ void k_rof_fdiff(const double *__restrict__ f, double *__restrict__ Fs, double *__restrict__ Fe, int nx, int ny)
+__global__ void k_rof_fdiff(const double *__restrict__ f, double *__restrict__ Fs, double *__restrict__ Fe, int nx, int ny,
+                            OccGrp Grm, size_t sk_stride)
 {
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
-    if (j >= nx || i >= ny) return;
-    const size_t c = (size_t) i * nx + j, k = rof_sk(i, j, ny);
+    size_t o;
+    if (j >= nx || i >= ny || !occ_grp(Grm, o)) return;
+    const size_t c = o + (size_t) i * nx + j, k = blockIdx.z * sk_stride + rof_sk(i, j, ny);
     Fs[k] = (i < ny - 1) ? f[c + nx] - f[c] : 0.0;
     Fe[k] = (j < nx - 1) ? f[c + 1] - f[c] : 0.0;
 }
@@ -747,47 +778,55 @@ __global__ void k_rof_fdiff(const double *__restrict__ f, double *__restrict__ F
 struct RofPt {
     const double *u[2], *f[2], *Ps[2], *Pe[2];
     double *AL[2], *uo[2];
+    int nc;                          // problems per set; blockIdx.z = set * nc + problem
+    size_t rm_stride, sk_stride;     // per set: row-major planes (u, f, g), hyperplane-major planes (Ps, Pe, AL)
+    unsigned mask;
 };
 __global__ void k_rof_alfa(RofPt a, const double *__restrict__ g, int nx, int ny, double lambda)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (j >= nx || i >= ny) return;
-    const size_t c = (size_t) i * nx + j;
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z % a.nc, set = blockIdx.z / a.nc;
+    if (j >= nx || i >= ny || !((a.mask >> set) & 1u)) return;
+    const size_t c = set * a.rm_stride + (size_t) i * nx + j;
     const double *u = a.u[k];
     const double ux = (j < nx - 1) ? u[c + 1] - u[c] : 0.0, uy = (i < ny - 1) ? u[c + nx] - u[c] : 0.0;
-    a.AL[k][rof_sk(i, j, ny)] = sqrt(ux * ux + uy * uy) / (lambda * g[c]);
+    a.AL[k][set * a.sk_stride + rof_sk(i, j, ny)] = sqrt(ux * ux + uy * uy) / (lambda * g[c]);
 }
 // u = lambda f + lambda (P_south - P_north + P_east - P_west), :616-640
 __global__ void k_rof_u(RofPt a, int nx, int ny, double lambda)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (j >= nx || i >= ny) return;
-    const size_t c = (size_t) i * nx + j, e = rof_sk(i, j, ny);
-    const double *Ps = a.Ps[k], *Pe = a.Pe[k];
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z % a.nc, set = blockIdx.z / a.nc;
+    if (j >= nx || i >= ny || !((a.mask >> set) & 1u)) return;
+    const size_t c = set * a.rm_stride + (size_t) i * nx + j;
+    const double *Ps = a.Ps[k] + set * a.sk_stride, *Pe = a.Pe[k] + set * a.sk_stride;
+    const size_t e = rof_sk(i, j, ny);
     const double pn = i > 0 ? Ps[rof_sk(i - 1, j, ny)] : 0.0, pw = j > 0 ? Pe[rof_sk(i, j - 1, ny)] : 0.0;
     a.uo[k][c] = lambda * a.f[k][c] + lambda * (Ps[e] - pn + Pe[e] - pw);
 }
 
 // nc = 1 | 2 independent problems sharing g, lambda and the size (the two flow components of Solver_wrt_u), every launch
-// serving both.  Device arrays in place: u[k] (in: seed, out: result; row-major), Ps[k] / Pe[k] (in/out state,
-// HYPERPLANE-MAJOR, rof_skew_elems() doubles each); scratch = 3 nc hyperplane-major planes.
+// serving both -- and all G sets of them (lockstep groups: set s on planes offset by s * nx * ny / s * rof_skew_elems(),
+// sets whose bit of `mask` is clear are left alone).  Device arrays in place: u[k] (in: seed, out: result; row-major),
+// Ps[k] / Pe[k] (in/out state, HYPERPLANE-MAJOR, rof_skew_elems() doubles per set); scratch = 3 nc G hyperplane-major planes.
 static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *const *f, double *const *Ps, double *const *Pe,
-                       const double *g, double lambda, double omega, int nx, int ny, int n_iter, double *scratch)
+                       const double *g, double lambda, double omega, int nx, int ny, int n_iter, double *scratch, int G = 1,
+                       unsigned mask = 1u)
 {
-    const size_t n = rof_skew_elems(nx, ny);
-    const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), nc), block(64, 4);
+    const size_t n = rof_skew_elems(nx, ny), nrm = (size_t) nx * ny;
+    const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), nc * G), block(64, 4);
     RofSet set;
     RofPt pt;
     for (int k = 0; k < 2; k++) {
         const int c = k < nc ? k : 0;
-        double *Fs = scratch + (3 * c) * n, *Fe = scratch + (3 * c + 1) * n, *AL = scratch + (3 * c + 2) * n;
+        double *Fs = scratch + (3 * c) * n * G, *Fe = scratch + (3 * c + 1) * n * G, *AL = scratch + (3 * c + 2) * n * G;
         if (k < nc) {
-            hipLaunchKernelGGL(k_rof_fdiff, dim3(grid.x, grid.y), block, 0, ctx->stream, f[c], Fs, Fe, nx, ny);
+            hipLaunchKernelGGL(k_rof_fdiff, dim3(grid.x, grid.y, G), block, 0, ctx->stream, f[c], Fs, Fe, nx, ny, OccGrp{nrm, mask}, n);
             OFX_LAUNCH_CHECK(ctx);
         }
         set.a[k] = RofArr{Ps[c], Pe[c], Fs, Fe, AL, nx, ny};
         pt.u[k] = u[c]; pt.f[k] = f[c]; pt.Ps[k] = Ps[c]; pt.Pe[k] = Pe[c]; pt.AL[k] = AL; pt.uo[k] = u[c];
     }
+    set.stride = n; set.mask = mask;
+    pt.nc = nc; pt.rm_stride = nrm; pt.sk_stride = n; pt.mask = mask;
     const int B = ofx_cdiv(ny, ROF_R), qmax = 2 * (ny - 1) + nx - 1;
     const long total = (long) qmax + 1 + (long) ROF_LAG * (B - 1);
     static std::atomic<unsigned> lds_set(0);           // bit d: the attribute has been set on device d (per device, any thread)
@@ -799,7 +838,7 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
     for (int it = 0; it < n_iter; it++) {
         hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
         for (long T0 = 0; T0 < total; T0 += ROF_K)
-            hipLaunchKernelGGL(k_rof_window, dim3(B, nc), dim3(ROF_THREADS), ROF_LDS_BYTES, ctx->stream, set, (int) T0, omega);
+            hipLaunchKernelGGL(k_rof_window, dim3(B, nc, G), dim3(ROF_THREADS), ROF_LDS_BYTES, ctx->stream, set, (int) T0, omega);
         hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, pt, nx, ny, lambda);
         OFX_LAUNCH_CHECK(ctx);
     }
@@ -853,11 +892,12 @@ extern "C" int ofx_scalar_rof_box_cell_centered(ofx_ctx *ctx, double *u, const d
 // f = v / theta + beta grad(chi), u = v + theta beta grad(chi) (tvl1occflow_solvers.cpp:192-203)
 __global__ void k_occ_u_init(const double *__restrict__ v1, const double *__restrict__ v2, const double *__restrict__ chi,
                              double *__restrict__ f1, double *__restrict__ f2, double *__restrict__ u1, double *__restrict__ u2,
-                             int nx, int ny, double theta, double beta)
+                             int nx, int ny, double theta, double beta, OccGrp G)
 {
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
-    if (j >= nx || i >= ny) return;
-    const size_t c = (size_t) i * nx + j;
+    size_t o;
+    if (j >= nx || i >= ny || !occ_grp(G, o)) return;
+    const size_t c = o + (size_t) i * nx + j;
     const double chix = (j < nx - 1) ? chi[c + 1] - chi[c] : 0.0, chiy = (i < ny - 1) ? chi[c + nx] - chi[c] : 0.0;
     f1[c] = v1[c] / theta + beta * chix;
     f2[c] = v2[c] / theta + beta * chiy;
@@ -888,7 +928,7 @@ extern "C" int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const doub
     OFX_TRY(ofx_alloc(ctx, n, &du1));
     OFX_TRY(ofx_alloc(ctx, n, &du2));
     hipLaunchKernelGGL(k_occ_u_init, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, (const double *) dv1,
-                       (const double *) dv2, (const double *) dchi, f1, f2, du1, du2, nx, ny, theta, beta);
+                       (const double *) dv2, (const double *) dchi, f1, f2, du1, du2, nx, ny, theta, beta, OCC_ONE);
     OFX_LAUNCH_CHECK(ctx);
     OFX_TRY(ofx_alloc(ctx, 6 * rof_skew_elems(nx, ny), &scratch));
     double *us[2] = {du1, du2}, *ps[2] = {dp[0], dp[2]}, *pe[2] = {dp[1], dp[3]};
@@ -909,6 +949,9 @@ extern "C" int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const doub
 // new[], uninitialised -- whenever the image width changes, i.e. once per pyramid level; its results are therefore only
 // defined on a heap that hands out zeros.  That is the semantics implemented here (state zeroed per level) and pinned by
 // the oracle against the reference built with a zero-filling operator new[] (oracle/ref_shim.cpp).
+// G independent triples are solved in lockstep (every array is [G][plane], every launch of the outer iteration serves all
+// triples that are still iterating, blockIdx.z = triple): one solve is a latency chain of ROF sweeps that keeps ny / 125
+// workgroups busy, so G of them cost hardly more time than one.
 #define OCC_EXT_MAX_ITERATIONS 20  // src/tvl1occflow_constants.h:35
 #define OCC_MAX_ITERATIONS_CHI 100 // :37
 #define OCC_MAX_ITERATIONS_U 10    // :36
@@ -917,11 +960,12 @@ extern "C" int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const doub
 #define OCC_TAU_CHI 0.15           // :27
 #define OCC_PRESMOOTHING_SIGMA 0.8 // :34
 #define OCC_ERR_BLOCKS 256
+#define OCC_MAX_GROUP 16           // triples per lockstep group
 
 // g = 1 / (1 + G_FACTOR |grad filtI0|), choosed_g choice 2 (:96-133); Ix, Iy = centred gradient
-__global__ void k_occ_g(const double *__restrict__ Ix, const double *__restrict__ Iy, double *__restrict__ g, int size)
+__global__ void k_occ_g(const double *__restrict__ Ix, const double *__restrict__ Iy, double *__restrict__ g, size_t size)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= size) return;
     const double gggrad = sqrt(Ix[i] * Ix[i] + Iy[i] * Iy[i]);
     g[i] = 1. / (1. + OCC_G_FACTOR * gggrad);
@@ -943,15 +987,16 @@ OFX_DEV double occ_sample(const double *__restrict__ in, const BicubicTaps &t, i
                           in[(size_t) t.row[2] * nx + t.col[q]], in[(size_t) t.row[3] * nx + t.col[q]], t.fy);
     return cubic_cell(c[0], c[1], c[2], c[3], t.fx);
 }
-__global__ void k_occ_prepare(OccPrep a, int nx, int ny)
+__global__ void k_occ_prepare(OccPrep a, int nx, int ny, OccGrp G)
 {
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
-    if (j >= nx || i >= ny) return;
-    const size_t p = (size_t) i * nx + j;
+    size_t o;
+    if (j >= nx || i >= ny || !occ_grp(G, o)) return;
+    const size_t p = o + (size_t) i * nx + j;
     const double u1 = a.u1[p], u2 = a.u2[p], i0 = a.I0[p];
     {
         const BicubicTaps t = bicubic_taps(j + u1, i + u2, nx, ny);
-        const double w = occ_sample(a.I1, t, nx), wx = occ_sample(a.I1x, t, nx), wy = occ_sample(a.I1y, t, nx);
+        const double w = occ_sample(a.I1 + o, t, nx), wx = occ_sample(a.I1x + o, t, nx), wy = occ_sample(a.I1y + o, t, nx);
         a.I1wx[p] = wx;
         a.I1wy[p] = wy;
         a.grad1[p] = (wx * wx + wy * wy);
@@ -959,7 +1004,7 @@ __global__ void k_occ_prepare(OccPrep a, int nx, int ny)
     }
     {
         const BicubicTaps t = bicubic_taps(j + (-u1), i + (-u2), nx, ny);
-        const double w = occ_sample(a.I_1, t, nx), wx = occ_sample(a.I_1x, t, nx), wy = occ_sample(a.I_1y, t, nx);
+        const double w = occ_sample(a.I_1 + o, t, nx), wx = occ_sample(a.I_1x + o, t, nx), wy = occ_sample(a.I_1y + o, t, nx);
         a.I_1wx[p] = wx;
         a.I_1wy[p] = wy;
         a.grad3[p] = (wx * wx + wy * wy);
@@ -967,14 +1012,14 @@ __global__ void k_occ_prepare(OccPrep a, int nx, int ny)
     }
 }
 
-// 3 x 3 median of both flow components in one launch (blockIdx.z)
+// 3 x 3 median of both flow components of every triple in one launch (blockIdx.z = 2 triple + component)
 __global__ void k_median3_pair(const double *__restrict__ in0, const double *__restrict__ in1, double *__restrict__ out0,
-                               double *__restrict__ out1, int nx, int ny)
+                               double *__restrict__ out1, int nx, int ny, size_t stride, unsigned mask)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= nx || y >= ny) return;
-    const double *in = blockIdx.z ? in1 : in0;
-    double *out = blockIdx.z ? out1 : out0;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, set = blockIdx.z >> 1;
+    if (x >= nx || y >= ny || !((mask >> set) & 1u)) return;
+    const double *in = ((blockIdx.z & 1) ? in1 : in0) + set * stride;
+    double *out = ((blockIdx.z & 1) ? out1 : out0) + set * stride;
     double win[9];
     int n = 0;
 #pragma unroll
@@ -999,20 +1044,32 @@ __global__ void k_median3_pair(const double *__restrict__ in0, const double *__r
     }
     out[(size_t) y * nx + x] = win[4];
 }
+// the medians back into u1 / u2 (triples that are still iterating only)
+__global__ void k_occ_copy2(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ oa, double *__restrict__ ob,
+                            int size, OccGrp G)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t o;
+    if (i >= size || !occ_grp(G, o)) return;
+    oa[o + i] = a[o + i];
+    ob[o + i] = b[o + i];
+}
 
-// L2error (:62-80): sum of the squared change of (u1, u2), fixed summation tree (block partials, then one block); the
-// previous-iterate planes are refreshed in the same pass
+// L2error (:62-80): sum of the squared change of (u1, u2), fixed summation tree (block partials, then one block per triple);
+// the previous-iterate planes are refreshed in the same pass
 __global__ __launch_bounds__(256) void k_occ_err_partial(const double *__restrict__ u1, const double *__restrict__ u2,
                                                          double *__restrict__ u1p, double *__restrict__ u2p, int size,
-                                                         double *__restrict__ part)
+                                                         double *__restrict__ part, OccGrp G)
 {
     __shared__ double sh[256];
+    size_t o;
+    if (!occ_grp(G, o)) return;                          // uniform over the workgroup
     double acc = 0.0;
     for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < (size_t) size; i += (size_t) OCC_ERR_BLOCKS * 256) {
-        const double a = u1[i], b = u2[i], d1 = a - u1p[i], d2 = b - u2p[i];
+        const double a = u1[o + i], b = u2[o + i], d1 = a - u1p[o + i], d2 = b - u2p[o + i];
         acc += d1 * d1 + d2 * d2;
-        u1p[i] = a;
-        u2p[i] = b;
+        u1p[o + i] = a;
+        u2p[o + i] = b;
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
@@ -1020,18 +1077,18 @@ __global__ __launch_bounds__(256) void k_occ_err_partial(const double *__restric
         if ((int) threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) part[blockIdx.z * OCC_ERR_BLOCKS + blockIdx.x] = sh[0];
 }
 __global__ __launch_bounds__(256) void k_occ_err_final(const double *__restrict__ part, double *__restrict__ out)
 {
     __shared__ double sh[256];
-    sh[threadIdx.x] = threadIdx.x < OCC_ERR_BLOCKS ? part[threadIdx.x] : 0.0;
+    sh[threadIdx.x] = threadIdx.x < OCC_ERR_BLOCKS ? part[blockIdx.x * OCC_ERR_BLOCKS + threadIdx.x] : 0.0;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int) threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = sh[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 __global__ void k_occ_scale2(double *__restrict__ a, double *__restrict__ b, size_t n, double s)
 {
@@ -1053,87 +1110,189 @@ struct OccParams {
     double lambda, alpha, beta, theta, epsilon;
     int warps, verbose;
 };
-// work planes of a solve, allocated once at the finest level's size
+// work planes of a group of G solves, allocated once at the finest level's size; a level uses them as [G][nx ny] /
+// [G][rof_skew_elems()]
 struct OccWork {
     double *I1x, *I1y, *I_1x, *I_1y, *I1wx, *I1wy, *I_1wx, *I_1wy, *rho1_c, *rho3_c, *grad1, *grad3, *v1, *v2, *vf1, *vf2, *vb1,
         *vb2, *g, *u1p, *u2p, *f1, *f2, *t1, *t2, *divu, *state, *eta, *rof, *part;
-    int alloc(ofx_ctx *ctx, size_t n, size_t nskew)
+    int alloc(ofx_ctx *ctx, size_t n, size_t nskew, int G)
     {
         double **planes[] = {&I1x, &I1y, &I_1x, &I_1y, &I1wx, &I1wy, &I_1wx, &I_1wy, &rho1_c, &rho3_c, &grad1, &grad3, &v1,
                              &v2, &vf1, &vf2, &vb1, &vb2, &g, &u1p, &u2p, &f1, &f2, &t1, &t2, &divu};
-        for (auto p : planes) OFX_TRY(ofx_alloc(ctx, n, p));
-        OFX_TRY(ofx_alloc(ctx, 4 * nskew, &state));          // dual planes of Solver_wrt_u, hyperplane-major
-        OFX_TRY(ofx_alloc(ctx, 2 * n, &eta));                // dual variable of Solver_wrt_chi
-        OFX_TRY(ofx_alloc(ctx, 6 * nskew, &rof));
-        return ofx_alloc(ctx, OCC_ERR_BLOCKS + 1, &part);
+        for (auto p : planes) OFX_TRY(ofx_alloc(ctx, n * G, p));
+        OFX_TRY(ofx_alloc(ctx, 4 * nskew * G, &state));      // dual planes of Solver_wrt_u, hyperplane-major
+        OFX_TRY(ofx_alloc(ctx, 2 * n * G, &eta));            // dual variable of Solver_wrt_chi
+        OFX_TRY(ofx_alloc(ctx, 6 * nskew * G, &rof));
+        return ofx_alloc(ctx, (size_t) (OCC_ERR_BLOCKS + 1) * G, &part);
     }
 };
 
-// one level, arrays on the device, u1 / u2 / chi in place; the level's dual state is zeroed here
-int occ_single_scale_dev(ofx_ctx *ctx, const double *I_1, const double *I0, const double *I1, const double *filtI0, double *u1,
-                         double *u2, double *chi, int nx, int ny, const OccParams &P, const OccWork &W, int scale)
+// one level of G triples, arrays [G][nx ny] on the device, u1 / u2 / chi in place; the level's dual state is zeroed here.
+// stats[g]: the record of triple g.
+int occ_single_scale_dev(ofx_ctx *ctx, int G, const double *I_1, const double *I0, const double *I1, const double *filtI0, double *u1,
+                         double *u2, double *chi, int nx, int ny, const OccParams &P, const OccWork &W, int scale, ofx_stats *stats)
 {
     const size_t n = (size_t) nx * ny;
-    const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), block(64, 4);
-    const int g1 = occ_grid1d(n);
+    const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), G), block(64, 4);
+    const dim3 g1(occ_grid1d(n), 1, G);
     hipStream_t st = ctx->stream;
     const size_t nsk = rof_skew_elems(nx, ny);
-    OFX_HIP(ctx, hipMemsetAsync(W.state, 0, 4 * nsk * sizeof(double), st));
-    OFX_HIP(ctx, hipMemsetAsync(W.eta, 0, 2 * n * sizeof(double), st));
-    double *eta1 = W.eta, *eta2 = W.eta + n;
-    OFX_TRY(op_centered_gradient<double>(ctx, filtI0, W.t1, W.t2, nx, ny));
-    hipLaunchKernelGGL(k_occ_g, dim3(g1), dim3(256), 0, st, (const double *) W.t1, (const double *) W.t2, W.g, (int) n);
-    OFX_TRY(op_centered_gradient<double>(ctx, I1, W.I1x, W.I1y, nx, ny));
-    OFX_TRY(op_centered_gradient<double>(ctx, I_1, W.I_1x, W.I_1y, nx, ny));
-    OFX_HIP(ctx, hipMemcpyAsync(W.u1p, u1, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    OFX_HIP(ctx, hipMemcpyAsync(W.u2p, u2, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
+    OFX_HIP(ctx, hipMemsetAsync(W.state, 0, 4 * nsk * G * sizeof(double), st));
+    OFX_HIP(ctx, hipMemsetAsync(W.eta, 0, 2 * n * G * sizeof(double), st));
+    double *eta1 = W.eta, *eta2 = W.eta + n * G;
+    for (int g = 0; g < G; g++) {                         // once per level: plane by plane
+        const size_t o = g * n;
+        OFX_TRY(op_centered_gradient<double>(ctx, filtI0 + o, W.t1 + o, W.t2 + o, nx, ny));
+        OFX_TRY(op_centered_gradient<double>(ctx, I1 + o, W.I1x + o, W.I1y + o, nx, ny));
+        OFX_TRY(op_centered_gradient<double>(ctx, I_1 + o, W.I_1x + o, W.I_1y + o, nx, ny));
+    }
+    hipLaunchKernelGGL(k_occ_g, dim3(occ_grid1d(n * G)), dim3(256), 0, st, (const double *) W.t1, (const double *) W.t2, W.g, n * G);
+    OFX_HIP(ctx, hipMemcpyAsync(W.u1p, u1, n * G * sizeof(double), hipMemcpyDeviceToDevice, st));
+    OFX_HIP(ctx, hipMemcpyAsync(W.u2p, u2, n * G * sizeof(double), hipMemcpyDeviceToDevice, st));
     const OccPrep prep = {I0, I1, W.I1x, W.I1y, I_1, W.I_1x, W.I_1y, u1, u2, W.I1wx, W.I1wy, W.I_1wx, W.I_1wy, W.grad1, W.grad3,
                           W.rho1_c, W.rho3_c};
     const OccV av = {u1, u2, chi, W.I1wx, W.I1wy, W.I_1wx, W.I_1wy, W.rho1_c, W.rho3_c, W.grad1, W.grad3,
                      W.v1, W.v2, W.vf1, W.vf2, W.vb1, W.vb2};
     const OccChi ac = {u1, u2, W.I1wx, W.I1wy, W.I_1wx, W.I_1wy, W.rho1_c, W.rho3_c, W.vf1, W.vf2, W.vb1, W.vb2, W.g, eta1, eta2,
                        W.divu, chi};
-    double *us[2] = {u1, u2}, *ps[2] = {W.state, W.state + 2 * nsk}, *pe[2] = {W.state + nsk, W.state + 3 * nsk};
+    double *us[2] = {u1, u2}, *ps[2] = {W.state, W.state + 2 * nsk * G}, *pe[2] = {W.state + nsk * G, W.state + 3 * nsk * G};
     const double *fs[2] = {W.f1, W.f2};
-    double *h_err = reinterpret_cast<double *>(ctx->h_state);        // pinned
+    double *h_err = reinterpret_cast<double *>(ctx->h_state);        // pinned, >= OCC_MAX_GROUP doubles
+    double *d_err = W.part + (size_t) OCC_ERR_BLOCKS * G;
     for (int w = 0; w < P.warps; w++) {
-        hipLaunchKernelGGL(k_occ_prepare, grid, block, 0, st, prep, nx, ny);
+        hipLaunchKernelGGL(k_occ_prepare, grid, block, 0, st, prep, nx, ny, OccGrp{n, all});
         OFX_LAUNCH_CHECK(ctx);
-        int it = 0;
-        double error = INFINITY;
-        while (error > P.epsilon && it < OCC_EXT_MAX_ITERATIONS) {
-            it++;
-            hipLaunchKernelGGL(k_occ_v, dim3(g1), dim3(256), 0, st, av, (int) n, P.alpha, P.theta, P.lambda);
+        int it[OCC_MAX_GROUP];
+        double error[OCC_MAX_GROUP];
+        for (int g = 0; g < G; g++) { it[g] = 0; error[g] = INFINITY; }
+        unsigned active = all;
+        while (active) {                                  // while (error > epsilon && it < EXT_MAX_ITERATIONS), per triple
+            const OccGrp grp = {n, active};
+            hipLaunchKernelGGL(k_occ_v, g1, dim3(256), 0, st, av, (int) n, P.alpha, P.theta, P.lambda, grp);
             hipLaunchKernelGGL(k_occ_u_init, grid, block, 0, st, (const double *) W.v1, (const double *) W.v2, (const double *) chi,
-                               W.f1, W.f2, u1, u2, nx, ny, P.theta, P.beta);
+                               W.f1, W.f2, u1, u2, nx, ny, P.theta, P.beta, grp);
             OFX_LAUNCH_CHECK(ctx);
-            OFX_TRY(rof_box_dev(ctx, 2, us, fs, ps, pe, W.g, P.theta, OCC_OMEGA, nx, ny, OCC_MAX_ITERATIONS_U, W.rof));
-            hipLaunchKernelGGL(k_median3_pair, dim3(grid.x, grid.y, 2), block, 0, st, (const double *) u1, (const double *) u2, W.t1,
-                               W.t2, nx, ny);
-            OFX_HIP(ctx, hipMemcpyAsync(u1, W.t1, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-            OFX_HIP(ctx, hipMemcpyAsync(u2, W.t2, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_occ_divu, grid, block, 0, st, (const double *) u1, (const double *) u2, W.divu, nx, ny);
+            OFX_TRY(rof_box_dev(ctx, 2, us, fs, ps, pe, W.g, P.theta, OCC_OMEGA, nx, ny, OCC_MAX_ITERATIONS_U, W.rof, G, active));
+            hipLaunchKernelGGL(k_median3_pair, dim3(grid.x, grid.y, 2 * G), block, 0, st, (const double *) u1, (const double *) u2, W.t1,
+                               W.t2, nx, ny, n, active);
+            hipLaunchKernelGGL(k_occ_copy2, g1, dim3(256), 0, st, (const double *) W.t1, (const double *) W.t2, u1, u2, (int) n, grp);
+            hipLaunchKernelGGL(k_occ_divu, grid, block, 0, st, (const double *) u1, (const double *) u2, W.divu, nx, ny, grp);
             for (int k = 0; k < OCC_MAX_ITERATIONS_CHI; k++) {
                 hipLaunchKernelGGL(k_occ_eta, grid, block, 0, st, (const double *) chi, (const double *) W.g, eta1, eta2, nx, ny,
-                                   OCC_TAU_ETA);
-                hipLaunchKernelGGL(k_occ_chi, grid, block, 0, st, ac, nx, ny, P.lambda, P.theta, P.alpha, P.beta, OCC_TAU_CHI);
+                                   OCC_TAU_ETA, grp);
+                hipLaunchKernelGGL(k_occ_chi, grid, block, 0, st, ac, nx, ny, P.lambda, P.theta, P.alpha, P.beta, OCC_TAU_CHI, grp);
             }
-            hipLaunchKernelGGL(k_occ_err_partial, dim3(OCC_ERR_BLOCKS), dim3(256), 0, st, (const double *) u1, (const double *) u2,
-                               W.u1p, W.u2p, (int) n, W.part);
-            hipLaunchKernelGGL(k_occ_err_final, dim3(1), dim3(256), 0, st, (const double *) W.part, W.part + OCC_ERR_BLOCKS);
+            hipLaunchKernelGGL(k_occ_err_partial, dim3(OCC_ERR_BLOCKS, 1, G), dim3(256), 0, st, (const double *) u1, (const double *) u2,
+                               W.u1p, W.u2p, (int) n, W.part, grp);
+            hipLaunchKernelGGL(k_occ_err_final, dim3(G), dim3(256), 0, st, (const double *) W.part, d_err);
             OFX_LAUNCH_CHECK(ctx);
-            OFX_HIP(ctx, hipMemcpyAsync(h_err, W.part + OCC_ERR_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, st));
+            OFX_HIP(ctx, hipMemcpyAsync(h_err, d_err, G * sizeof(double), hipMemcpyDeviceToHost, st));
             OFX_HIP(ctx, hipStreamSynchronize(st));
-            error = *h_err / (int) n;
+            for (int g = 0; g < G; g++) {
+                if (!((active >> g) & 1u)) continue;
+                it[g]++;
+                error[g] = h_err[g] / (int) n;
+                if (!(error[g] > P.epsilon && it[g] < OCC_EXT_MAX_ITERATIONS)) active &= ~(1u << g);
+            }
         }
-        if (P.verbose) fprintf(stderr, "Warping: %d, Iterations: %d, Error: %e\n", w, it, error);     // :292-296
-        ofx_stats &S = ctx->stats;
-        if (scale < OFX_MAX_SCALES && w < OFX_MAX_SOLVES) {
-            S.iters[scale][w] = it;
-            S.error[scale][w] = error;
+        if (P.verbose && G == 1) fprintf(stderr, "Warping: %d, Iterations: %d, Error: %e\n", w, it[0], error[0]);     // :292-296
+        for (int g = 0; g < G; g++) {
+            ofx_stats &S = stats[g];
+            if (scale < OFX_MAX_SCALES && w < OFX_MAX_SOLVES) {
+                S.iters[scale][w] = it[g];
+                S.error[scale][w] = error[g];
+            }
+            S.work_pix_iters += (double) it[g] * (double) n;
         }
-        S.work_pix_iters += (double) it * (double) n;
     }
+    return OFX_OK;
+}
+
+// G triples (host planes) on one context
+int occ_group(ofx_ctx *ctx, int G, const double *const *I_1, const double *const *I0, const double *const *I1,
+              const double *const *filtI0, double *const *u1, double *const *u2, double *const *chi, int nxx, int nyy,
+              const OccParams &P, int nscales, double zfactor, ofx_stats *stats)
+{
+    const double t0 = ofx_now_ms();
+    std::vector<int> nxs, nys;
+    OFX_TRY(op_pyramid_sizes(ctx, nxx, nyy, nscales, zfactor, nxs, nys));
+    if (nxs[nscales - 1] < 2 || nys[nscales - 1] < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: coarsest level %dx%d", nxs[nscales - 1], nys[nscales - 1]);
+    for (int g = 0; g < G; g++) {
+        ofx_stats &S = stats[g];
+        S = ofx_stats{};
+        S.nscales = nscales;
+        S.nsolves = P.warps;
+        for (int s = 0; s < nscales && s < OFX_MAX_SCALES; s++) { S.nx[s] = nxs[s]; S.ny[s] = nys[s]; }
+    }
+    const size_t size = (size_t) nxx * nyy;
+    OccWork W;
+    OFX_TRY(W.alloc(ctx, size, rof_skew_elems(nxx, nyy), G));
+    struct Lv { double *im[4], *u1, *u2, *chi; };           // im: I_1, I0, I1, filtI0; every array [G][n_s]
+    std::vector<Lv> lv(nscales);
+    for (int s = 0; s < nscales; s++) {
+        const size_t n = (size_t) nxs[s] * nys[s] * G;
+        for (int k = 0; k < 4; k++) OFX_TRY(ofx_alloc(ctx, n, &lv[s].im[k]));
+        OFX_TRY(ofx_alloc(ctx, n, &lv[s].u1));
+        OFX_TRY(ofx_alloc(ctx, n, &lv[s].u2));
+        OFX_TRY(ofx_alloc(ctx, n, &lv[s].chi));
+    }
+    hipStream_t st = ctx->stream;
+    // :382-395 call image_normalization_4 and then overwrite its output with the raw images: no normalisation
+    const double *const *host[4] = {I_1, I0, I1, filtI0};
+    for (int g = 0; g < G; g++)
+        for (int k = 0; k < 4; k++) {
+            OFX_HIP(ctx, hipMemcpyAsync(lv[0].im[k] + g * size, host[k][g], size * sizeof(double), hipMemcpyHostToDevice, st));
+            OFX_TRY(op_gaussian<double>(ctx, lv[0].im[k] + g * size, W.t1, nxx, nyy, OCC_PRESMOOTHING_SIGMA));
+        }
+    for (int s = 1; s < nscales; s++) {
+        const size_t np = (size_t) nxs[s - 1] * nys[s - 1], n = (size_t) nxs[s] * nys[s];
+        for (int g = 0; g < G; g++)
+            for (int k = 0; k < 4; k++)
+                OFX_TRY(op_zoom_out<double>(ctx, lv[s - 1].im[k] + g * np, lv[s].im[k] + g * n, W.t1, W.t2, nxs[s - 1], nys[s - 1], zfactor));
+    }
+    {
+        const size_t n = (size_t) nxs[nscales - 1] * nys[nscales - 1] * G;
+        OFX_HIP(ctx, hipMemsetAsync(lv[nscales - 1].u1, 0, n * sizeof(double), st));
+        OFX_HIP(ctx, hipMemsetAsync(lv[nscales - 1].u2, 0, n * sizeof(double), st));
+        OFX_HIP(ctx, hipMemsetAsync(lv[nscales - 1].chi, 0, n * sizeof(double), st));
+    }
+    for (int s = nscales - 1; s >= 0; s--) {
+        if (P.verbose && G == 1) fprintf(stderr, "Scale %d: %dx%d\n", s, nxs[s], nys[s]);
+        OFX_TRY(occ_single_scale_dev(ctx, G, lv[s].im[0], lv[s].im[1], lv[s].im[2], lv[s].im[3], lv[s].u1, lv[s].u2, lv[s].chi, nxs[s],
+                                     nys[s], P, W, s, stats));
+        if (s) {
+            const double fx = (double) nxs[s - 1] / nxs[s], fy = (double) nys[s - 1] / nys[s];
+            const size_t n = (size_t) nxs[s - 1] * nys[s - 1], nc = (size_t) nxs[s] * nys[s];
+            for (int g = 0; g < G; g++) {
+                OFX_TRY(op_resample<double>(ctx, lv[s].u1 + g * nc, lv[s - 1].u1 + g * n, nxs[s], nys[s], nxs[s - 1], nys[s - 1], fx, fy));
+                OFX_TRY(op_resample<double>(ctx, lv[s].u2 + g * nc, lv[s - 1].u2 + g * n, nxs[s], nys[s], nxs[s - 1], nys[s - 1], fx, fy));
+                OFX_TRY(op_resample<double>(ctx, lv[s].chi + g * nc, lv[s - 1].chi + g * n, nxs[s], nys[s], nxs[s - 1], nys[s - 1], fx, fy));
+            }
+            hipLaunchKernelGGL(k_occ_scale2, dim3(occ_grid1d(n * G)), dim3(256), 0, st, lv[s - 1].u1, lv[s - 1].u2, n * G, (double) 1.0 / zfactor);
+        } else {
+            hipLaunchKernelGGL(k_occ_threshold, dim3(occ_grid1d(size * G)), dim3(256), 0, st, lv[0].chi, size * G);
+        }
+        OFX_LAUNCH_CHECK(ctx);
+    }
+    Dev d{ctx};
+    for (int g = 0; g < G; g++) {
+        OFX_TRY(d.out(lv[0].u1 + g * size, u1[g], size));
+        OFX_TRY(d.out(lv[0].u2 + g * size, u2[g], size));
+        OFX_TRY(d.out(lv[0].chi + g * size, chi[g], size));
+    }
+    OFX_TRY(d.sync());
+    const double ms = ofx_now_ms() - t0;
+    for (int g = 0; g < G; g++) stats[g].total_ms = ms;
+    return OFX_OK;
+}
+
+int occ_check_args(ofx_ctx *ctx, int nxx, int nyy, double lambda, double theta, int nscales, double zfactor, int warps)
+{
+    if (nxx < 2 || nyy < 2 || (long long) nxx * nyy > 0x3fffffffLL) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: bad size %dx%d", nxx, nyy);
+    if (nscales < 1 || warps < 1 || warps > OFX_MAX_SOLVES) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: nscales=%d warps=%d", nscales, warps);
+    if (!(zfactor > 0.0 && zfactor < 1.0)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: zfactor=%g", zfactor);
+    if (!(theta > 0.0) || !(lambda > 0.0)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: theta=%g lambda=%g", theta, lambda);
     return OFX_OK;
 }
 
@@ -1146,76 +1305,14 @@ extern "C" int ofx_tvl1occ_multiscale(ofx_ctx *ctx, const double *I_1, const dou
 {
     OFX_ENTER(ctx);
     if (!I_1 || !I0 || !I1 || !filtI0 || !u1 || !u2 || !chi) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: NULL pointer");
-    if (nxx < 2 || nyy < 2 || (long long) nxx * nyy > 0x3fffffffLL) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: bad size %dx%d", nxx, nyy);
-    if (nscales < 1 || warps < 1 || warps > OFX_MAX_SOLVES) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: nscales=%d warps=%d", nscales, warps);
-    if (!(zfactor > 0.0 && zfactor < 1.0)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: zfactor=%g", zfactor);
-    if (!(theta > 0.0) || !(lambda > 0.0)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: theta=%g lambda=%g", theta, lambda);
-    const double t0 = ofx_now_ms();
-    std::vector<int> nxs, nys;
-    OFX_TRY(op_pyramid_sizes(ctx, nxx, nyy, nscales, zfactor, nxs, nys));
-    if (nxs[nscales - 1] < 2 || nys[nscales - 1] < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1occ: coarsest level %dx%d", nxs[nscales - 1], nys[nscales - 1]);
-    ofx_stats &S = ctx->stats;
-    S = ofx_stats{};
-    S.nscales = nscales;
-    S.nsolves = warps;
-    for (int s = 0; s < nscales && s < OFX_MAX_SCALES; s++) { S.nx[s] = nxs[s]; S.ny[s] = nys[s]; }
+    OFX_TRY(occ_check_args(ctx, nxx, nyy, lambda, theta, nscales, zfactor, warps));
     const OccParams P = {lambda, alpha, beta, theta, epsilon, warps, verbose};
-    const size_t size = (size_t) nxx * nyy;
-    OccWork W;
-    OFX_TRY(W.alloc(ctx, size, rof_skew_elems(nxx, nyy)));
-    struct Lv { double *im[4], *u1, *u2, *chi; };           // im: I_1, I0, I1, filtI0
-    std::vector<Lv> lv(nscales);
-    for (int s = 0; s < nscales; s++) {
-        const size_t n = (size_t) nxs[s] * nys[s];
-        for (int k = 0; k < 4; k++) OFX_TRY(ofx_alloc(ctx, n, &lv[s].im[k]));
-        OFX_TRY(ofx_alloc(ctx, n, &lv[s].u1));
-        OFX_TRY(ofx_alloc(ctx, n, &lv[s].u2));
-        OFX_TRY(ofx_alloc(ctx, n, &lv[s].chi));
-    }
-    hipStream_t st = ctx->stream;
-    // :382-395 call image_normalization_4 and then overwrite its output with the raw images: no normalisation
-    const double *host[4] = {I_1, I0, I1, filtI0};
-    for (int k = 0; k < 4; k++) {
-        OFX_HIP(ctx, hipMemcpyAsync(lv[0].im[k], host[k], size * sizeof(double), hipMemcpyHostToDevice, st));
-        OFX_TRY(op_gaussian<double>(ctx, lv[0].im[k], W.t1, nxx, nyy, OCC_PRESMOOTHING_SIGMA));
-    }
-    for (int s = 1; s < nscales; s++)
-        for (int k = 0; k < 4; k++)
-            OFX_TRY(op_zoom_out<double>(ctx, lv[s - 1].im[k], lv[s].im[k], W.t1, W.t2, nxs[s - 1], nys[s - 1], zfactor));
-    {
-        const size_t n = (size_t) nxs[nscales - 1] * nys[nscales - 1];
-        OFX_HIP(ctx, hipMemsetAsync(lv[nscales - 1].u1, 0, n * sizeof(double), st));
-        OFX_HIP(ctx, hipMemsetAsync(lv[nscales - 1].u2, 0, n * sizeof(double), st));
-        OFX_HIP(ctx, hipMemsetAsync(lv[nscales - 1].chi, 0, n * sizeof(double), st));
-    }
-    for (int s = nscales - 1; s >= 0; s--) {
-        if (verbose) fprintf(stderr, "Scale %d: %dx%d\n", s, nxs[s], nys[s]);
-        OFX_TRY(occ_single_scale_dev(ctx, lv[s].im[0], lv[s].im[1], lv[s].im[2], lv[s].im[3], lv[s].u1, lv[s].u2, lv[s].chi, nxs[s],
-                                     nys[s], P, W, s));
-        if (s) {
-            const double fx = (double) nxs[s - 1] / nxs[s], fy = (double) nys[s - 1] / nys[s];
-            const size_t n = (size_t) nxs[s - 1] * nys[s - 1];
-            OFX_TRY(op_resample<double>(ctx, lv[s].u1, lv[s - 1].u1, nxs[s], nys[s], nxs[s - 1], nys[s - 1], fx, fy));
-            OFX_TRY(op_resample<double>(ctx, lv[s].u2, lv[s - 1].u2, nxs[s], nys[s], nxs[s - 1], nys[s - 1], fx, fy));
-            OFX_TRY(op_resample<double>(ctx, lv[s].chi, lv[s - 1].chi, nxs[s], nys[s], nxs[s - 1], nys[s - 1], fx, fy));
-            hipLaunchKernelGGL(k_occ_scale2, dim3(occ_grid1d(n)), dim3(256), 0, st, lv[s - 1].u1, lv[s - 1].u2, n, (double) 1.0 / zfactor);
-        } else {
-            hipLaunchKernelGGL(k_occ_threshold, dim3(occ_grid1d(size)), dim3(256), 0, st, lv[0].chi, size);
-        }
-        OFX_LAUNCH_CHECK(ctx);
-    }
-    Dev d{ctx};
-    OFX_TRY(d.out(lv[0].u1, u1, size));
-    OFX_TRY(d.out(lv[0].u2, u2, size));
-    OFX_TRY(d.out(lv[0].chi, chi, size));
-    OFX_TRY(d.sync());
-    S.total_ms = ofx_now_ms() - t0;
-    return OFX_OK;
+    return occ_group(ctx, 1, &I_1, &I0, &I1, &filtI0, &u1, &u2, &chi, nxx, nyy, P, nscales, zfactor, &ctx->stats);
 }
 
-// Several independent triples: one solve is bound by the latency of the ROF sweeps (a chain of ~ 2 ny + nx steps that only
-// ny / 125 workgroups work on), so independent solves overlap almost perfectly when they are issued on different streams.
-// Triple k runs on context k mod n_ctx, one host thread per context; all contexts on one device.
+// Several independent triples (e.g. the frames of a sequence): cut into lockstep groups of up to 16 consecutive triples (fewer
+// when the device memory the contexts may use -- option "mem_budget" -- does not hold that many), group q on context
+// q mod n_ctx, one host thread per context; all contexts on one device.
 extern "C" int ofx_tvl1occ_batch(ofx_ctx *const *ctxs, int n_ctx, int n_triples, const double *const *I_1, const double *const *I0,
                                  const double *const *I1, const double *const *filtI0, double *const *u1, double *const *u2,
                                  double *const *chi, int nxx, int nyy, double lambda, double alpha, double beta, double theta,
@@ -1224,17 +1321,49 @@ extern "C" int ofx_tvl1occ_batch(ofx_ctx *const *ctxs, int n_ctx, int n_triples,
     if (!ctxs || n_ctx < 1 || n_triples < 0 || !I_1 || !I0 || !I1 || !filtI0 || !u1 || !u2 || !chi) return OFX_ERR_ARG;
     for (int w = 0; w < n_ctx; w++)
         if (!ctxs[w] || ctxs[w]->device != ctxs[0]->device) return OFX_ERR_ARG;
+    if (n_triples == 0) return OFX_OK;
+    {
+        ofx_ctx *ctx = ctxs[0];
+        OFX_ENTER(ctx);
+        OFX_TRY(occ_check_args(ctx, nxx, nyy, lambda, theta, nscales, zfactor, warps));
+    }
+    // group size: option "lockstep" of ctxs[0], else as many as fit (~ 60 row-major + 10 hyperplane-major planes per triple)
+    int G = ctxs[0]->lockstep > 0 ? ctxs[0]->lockstep : OCC_MAX_GROUP;
+    if (G > OCC_MAX_GROUP) G = OCC_MAX_GROUP;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipSetDevice(ctxs[0]->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return OFX_ERR_HIP;
+        const double budget = (ctxs[0]->mem_budget > 0 ? ctxs[0]->mem_budget : 0.5 * (double) free_b) / n_ctx;
+        const double per = 8.0 * (60.0 * nxx * nyy + 10.0 * (double) rof_skew_elems(nxx, nyy));
+        const int fit = (int) (budget / per);
+        if (fit < 1) return ofx_fail(ctxs[0], OFX_ERR_NOMEM, "tvl1occ batch: %.1f GB per triple, %.1f GB per context available", per / 1e9, budget / 1e9);
+        if (G > fit) G = fit;
+    }
+    const int per_ctx = (n_triples + n_ctx - 1) / n_ctx;     // even the groups out over the contexts
+    if (G > per_ctx) G = per_ctx;
+    const int n_groups = (n_triples + G - 1) / G;
+    const OccParams P = {lambda, alpha, beta, theta, epsilon, warps, 0};
     std::atomic<int> status(OFX_OK);
     auto worker = [&](int w) {
-        for (int k = w; k < n_triples; k += n_ctx) {
+        std::vector<ofx_stats> st(G);
+        for (int q = w; q < n_groups; q += n_ctx) {
             if (status.load() != OFX_OK) return;
-            const int s = ofx_tvl1occ_multiscale(ctxs[w], I_1[k], I0[k], I1[k], filtI0[k], u1[k], u2[k], chi[k], nxx, nyy, lambda,
-                                                 alpha, beta, theta, nscales, zfactor, warps, epsilon, 0);
+            const int first = q * G, cnt = (n_triples - first < G) ? n_triples - first : G;
+            ofx_ctx *ctx = ctxs[w];
+            int s = OFX_OK;
+            if (hipSetDevice(ctx->device) != hipSuccess) s = ofx_fail(ctx, OFX_ERR_NODEV, "hipSetDevice(%d) failed", ctx->device);
+            else {
+                ctx->errmsg[0] = 0;
+                ofx_arena_reset(ctx);
+                s = occ_group(ctx, cnt, I_1 + first, I0 + first, I1 + first, filtI0 + first, u1 + first, u2 + first, chi + first, nxx,
+                              nyy, P, nscales, zfactor, st.data());
+                ctx->stats = st[0];
+            }
             if (s != OFX_OK) { int expected = OFX_OK; status.compare_exchange_strong(expected, s); return; }
         }
     };
     std::vector<std::thread> th;
-    for (int w = 1; w < n_ctx && w < n_triples; w++) th.emplace_back(worker, w);
+    for (int w = 1; w < n_ctx && w < n_groups; w++) th.emplace_back(worker, w);
     worker(0);
     for (auto &t : th) t.join();
     return status.load();

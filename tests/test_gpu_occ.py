@@ -139,3 +139,28 @@ def test_tvl1occ_batch_over_contexts(ofx_mod, gpu64, synth):
         assert np.array_equal(u, wu) and np.array_equal(v, wv) and np.array_equal(c, wc)
     with pytest.raises(ofx_mod.OfxError):
         ofx_mod.tvl1occ_batch(ctxs, triples, nscales=0)
+
+
+def test_tvl1occ_lockstep_group_with_different_iteration_counts(ofx_mod, gpu64, synth, orc):
+    """one context, one lockstep group: triples whose outer loops end at different iterations (and at different levels) ride in
+    the same launches, the finished ones frozen -- every result equal to the triple solved alone, and to the oracle"""
+    ctx = ofx_mod.Ofx(0, ofx_mod.F64)
+    kw = dict(nscales=3, warps=2, epsilon=0.002)
+    triples = []
+    for k in range(6):
+        seq = synth.sequence(160, 120, 3, k + 1)
+        triples.append((seq[0], seq[1], seq[2]) if k % 3 else (seq[2], seq[1], seq[1]))      # a static half for some: other counts
+    got = ofx_mod.tvl1occ_batch([ctx], triples, **kw)
+    tables = []
+    for t, (u, v, c) in zip(triples, got):
+        wu, wv, wc = gpu64.tvl1occ_multiscale(*t[:3], **kw)
+        st = gpu64.stats()
+        tables.append(tuple(st.iters[s][w] for s in range(3) for w in range(2)))
+        assert np.array_equal(u, wu) and np.array_equal(v, wv) and np.array_equal(c, wc)
+    assert len(set(tables)) > 1, tables                     # the group really was heterogeneous
+    uo, vo, co, _ = orc.tvl1occ_multiscale(*triples[1][:3], **kw)
+    assert np.array_equal(got[1][0], uo) and np.array_equal(got[1][2], co)
+    ctx.set_option("lockstep", 4)                           # 4 + 2
+    again = ofx_mod.tvl1occ_batch([ctx], triples, **kw)
+    for a, b in zip(got, again):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
