@@ -22,14 +22,15 @@ for sz in 1920x1080 3840x2160; do
   timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq_$sz -- python3 $R/tools/pmc_iter.py $sz n=40 > $OUT/pmc_sq_$sz.log 2>&1
 done
 # the same counters on the kernel as the job launches it: lockstep group of 16 (1080p) / 4 (4K) pairs per launch
-for spec in 1920x1080:16 3840x2160:4; do
-  sz=${spec%%:*}; g=${spec##*:}
-  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmcg_fetch_$sz -- python3 $R/tools/pmc_group.py $sz G=$g > $OUT/pmcg_fetch_$sz.log 2>&1
-  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmcg_write_$sz -- python3 $R/tools/pmc_group.py $sz G=$g > $OUT/pmcg_write_$sz.log 2>&1
-  timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmcg_sq_$sz -- python3 $R/tools/pmc_group.py $sz G=$g > $OUT/pmcg_sq_$sz.log 2>&1
+for spec in 1920x1080:16 1920x1080:5 3840x2160:4; do
+  sz=${spec%%:*}; g=${spec##*:}; [ $g = 5 ] && sz=${sz}_g5
+  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmcg_fetch_$sz -- python3 $R/tools/pmc_group.py ${sz%%_*} G=$g > $OUT/pmcg_fetch_$sz.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmcg_write_$sz -- python3 $R/tools/pmc_group.py ${sz%%_*} G=$g > $OUT/pmcg_write_$sz.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmcg_sq_$sz -- python3 $R/tools/pmc_group.py ${sz%%_*} G=$g > $OUT/pmcg_sq_$sz.log 2>&1
 done
 # kernel trace of the group launches alone (what bench.py's roofline object times with HIP events)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_group -- python3 $R/tools/pmc_group.py 1920x1080 G=16 > $OUT/trace_group.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_group5 -- python3 $R/tools/pmc_group.py 1920x1080 G=5 > $OUT/trace_group5.log 2>&1
 # SOR window kernels in a lockstep group of 16 pairs (hyperplane-major layout): per-kernel stats + counters
 for cfg in hs_cfg3 brox_cfg4; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sor_trace_$cfg -- python3 $R/tools/bench_sor_groups.py --only=$cfg --grid=1x16 > $OUT/sor_trace_$cfg.jsonl 2> $OUT/sor_trace_$cfg.err || true

@@ -93,11 +93,12 @@ for sz in ("1920x1080", "3840x2160"):
                           "launch_us": vals["launch_us_fetch"], "valu_insts_per_launch": vals["SQ_INSTS_VALU"],
                           "waves": vals["SQ_WAVES"]}
 # ---- the same counters on lockstep-group launches (tools/pmc_group.py) ----
-for sz, G in (("1920x1080", 16), ("3840x2160", 4)):
+for sz, G in (("1920x1080", 16), ("1920x1080", 5), ("3840x2160", 4)):
     vals = {}
+    dsz = sz + ("_g5" if G == 5 else "")
     for kind in ("fetch", "write", "sq"):
-        f = newest(os.path.join(SRC, "pmcg_%s_%s" % (kind, sz), "*", "*_counter_collection.csv"))
-        kt = newest(os.path.join(SRC, "pmcg_%s_%s" % (kind, sz), "*", "*_kernel_trace.csv"))
+        f = newest(os.path.join(SRC, "pmcg_%s_%s" % (kind, dsz), "*", "*_counter_collection.csv"))
+        kt = newest(os.path.join(SRC, "pmcg_%s_%s" % (kind, dsz), "*", "*_kernel_trace.csv"))
         if not f or not kt:
             continue
         acc = collections.defaultdict(list)
@@ -123,14 +124,18 @@ for sz, G in (("1920x1080", 16), ("3840x2160", 4)):
         det["clock_ghz"] = clk / 1e9
         det["valu_active_fraction"] = 4 * vals["SQ_ACTIVE_INST_VALU"] / 1024 / (vals["launch_us_sq"] * 1e-6 * clk)
     pm["detail_group%d_%s" % (G, sz)] = det
-gt = newest(os.path.join(SRC, "trace_group", "*", "*_kernel_stats.csv"))
-if gt:
+lines = []
+for d_, G in (("trace_group", 16), ("trace_group5", 5)):
+    gt = newest(os.path.join(SRC, d_, "*", "*_kernel_stats.csv"))
+    if not gt:
+        continue
     rows = [r for r in csv.DictReader(open(gt[0])) if "k_tvl1_iter2" in r["Name"]]
+    lines.append("# rocprofv3 --kernel-trace --stats -- python3 tools/pmc_group.py 1920x1080 G=%d   (150 launches of %d pairs, fixed work)\n"
+                 "# kernel | calls | total ms | average us\n" % (G, G) +
+                 "".join("%-100s %6s %10.3f %10.3f\n" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3) for r in rows))
+if lines:
     open(os.path.join(DST, tag + "_group_launch_kernel_stats.txt"), "w").write(
-        "# rocprofv3 --kernel-trace --stats -- python3 tools/pmc_group.py 1920x1080 G=16   (150 launches of 16 pairs, fixed work)\n"
-        "# kernel | calls | total ms | average us\n" +
-        "".join("%-100s %6s %10.3f %10.3f\n" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3) for r in rows) +
-        "# bench.py roofline (HIP events, same launches): %.2f us per launch of %d pairs\n" % (bench["roofline"]["avg_launch_us"], bench["roofline"].get("pairs_per_launch", 1)))
+        "".join(lines) + "# bench.py roofline (HIP events, launches of %d pairs): %.2f us per launch\n" % (bench["roofline"].get("pairs_per_launch", 1), bench["roofline"]["avg_launch_us"]))
 
 for sz, ceil in (("1920x1080", "arithmetic alone 92 % of the production time, memory traffic alone 61 % -> VALU-bound (working set inside the 256 MiB Infinity Cache)"),
                  ("3840x2160", "arithmetic alone 81 % of the production time, memory traffic alone 70 % -> neither hides the other (4 waves per SIMD at 128 VGPRs)")):
