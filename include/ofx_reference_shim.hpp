@@ -1,7 +1,7 @@
 // ofx_reference_shim.hpp -- the reference's OWN prototypes, defined on top of libofx.so (include/ofx.h).
 //
-// A program written against the reference headers (src/tvl1flow.h, horn_schunck.h, brox_optic_flow.h, operators.h,
-// bicubic_interpolation.h, zoom.h, utils.h -- cited per function below) keeps compiling unchanged: include this file in
+// A program written against the reference headers (src/tvl1flow.h, tvl1occflow.h, tvl1occflow_solvers.h, horn_schunck.h,
+// brox_optic_flow.h, operators.h, bicubic_interpolation.h, zoom.h, utils.h -- cited per function below) keeps compiling unchanged: include this file in
 // ONE translation unit instead of compiling tvl1flow.cpp, operators.cpp, bicubic_interpolation.cpp, zoom.cpp,
 // utils.cpp, horn_schunck_pyramidal.cpp, brox_optic_flow_spatial.cpp, brox_spatial_mask.cpp,
 // brox_optic_flow_temporal.cpp, brox_temporal_mask.cpp, and link with -lofx.  `ofpix_t` must be double (src/of.h:4-10,
@@ -25,6 +25,8 @@
 #include "horn_schunck.h"
 #include "operators.h"
 #include "tvl1flow.h"
+#include "tvl1occflow.h"
+#include "tvl1occflow_solvers.h"
 #include "utils.h"
 #include "zoom.h"
 
@@ -194,6 +196,51 @@ void image_normalization_2(const ofpix_t *I1, const ofpix_t *I2, ofpix_t *I1n, o
 void getminmax(ofpix_t *min, ofpix_t *max, const ofpix_t *x, int n)
 {
     ofx_shim::check(ofx_getminmax(ofx_shim::ctx(), x, n, min, max));
+}
+
+// ---- src/utils.h:10,39-87, src/bicubic_interpolation.h:59-67 (colour / three-frame operators) --------------------
+void me_median_filtering(ofpix_t *in, int nx, int ny, int wsize)
+{
+    ofx_shim::check(ofx_me_median_filtering(ofx_shim::ctx(), in, nx, ny, wsize));
+}
+void image_normalization_2_color(const ofpix_t *I1, const ofpix_t *I2, ofpix_t *I1n, ofpix_t *I2n, int size, int nz)
+{
+    ofx_shim::check(ofx_image_normalization_2_color(ofx_shim::ctx(), I1, I2, I1n, I2n, size, nz));
+}
+void image_normalization_3(ofpix_t *I0, ofpix_t *I1, ofpix_t *I2, int size)
+{
+    ofx_shim::check(ofx_image_normalization_3(ofx_shim::ctx(), I0, I1, I2, size));
+}
+void image_normalization_4(const ofpix_t *I_1, const ofpix_t *I0, const ofpix_t *I1, const ofpix_t *filtI0, ofpix_t *I_1n,
+                           ofpix_t *I0n, ofpix_t *I1n, ofpix_t *filtI0n, int size)
+{
+    ofx_shim::check(ofx_image_normalization_4(ofx_shim::ctx(), I_1, I0, I1, filtI0, I_1n, I0n, I1n, filtI0n, size));
+}
+void bicubic_interpolation_warp_color(const ofpix_t *input, const ofpix_t *u, const ofpix_t *v, ofpix_t *output, const int nx,
+                                      const int ny, const int nz, bool border_out)
+{
+    ofx_shim::check(ofx_bicubic_warp_color(ofx_shim::ctx(), input, u, v, output, nx, ny, nz, border_out ? 1 : 0));
+}
+
+// ---- src/tvl1occflow.h (the multiscale overload), src/tvl1occflow_solvers.h:57-66 ----------------------------------
+// The reference's Solver_wrt_u / Solver_wrt_chi keep hidden static state between calls (and read it uninitialised): their
+// counterparts take that state as arguments (ofx_solver_wrt_u / ofx_solver_wrt_chi) and are not given the old signatures.
+// The single-scale Dual_TVL1_optic_flow overload of tvl1occflow.h depends on the same hidden state and is not provided either.
+void Dual_TVL1_optic_flow_multiscale(ofpix_t *I_1, ofpix_t *I0, ofpix_t *I1, ofpix_t *filtI0, ofpix_t *u1, ofpix_t *u2,
+                                     ofpix_t *chi, const int nxx, const int nyy, const double lambda, const double alpha,
+                                     const double beta, const double theta, const int nscales, const double zfactor,
+                                     const int warps, const double epsilon, const bool verbose)
+{
+    ofx_shim::check(ofx_tvl1occ_multiscale(ofx_shim::ctx(), I_1, I0, I1, filtI0, u1, u2, chi, nxx, nyy, lambda, alpha, beta, theta,
+                                           nscales, zfactor, warps, epsilon, verbose ? 1 : 0));
+}
+void Solver_wrt_v(ofpix_t *u1, ofpix_t *u2, ofpix_t *v1, ofpix_t *v2, ofpix_t *chi, const ofpix_t *I1wx, const ofpix_t *I1wy,
+                  const ofpix_t *I_1wx, const ofpix_t *I_1wy, const ofpix_t *rho1_c, const ofpix_t *rho3_c, ofpix_t *Vfwd_1,
+                  ofpix_t *Vfwd_2, ofpix_t *Vbck_1, ofpix_t *Vbck_2, const ofpix_t *grad1, const ofpix_t *grad3, const double alpha,
+                  const double theta, const double lambda, const int nx, const int ny)
+{
+    ofx_shim::check(ofx_solver_wrt_v(ofx_shim::ctx(), u1, u2, v1, v2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, Vfwd_1, Vfwd_2,
+                                     Vbck_1, Vbck_2, grad1, grad3, alpha, theta, lambda, nx, ny));
 }
 
 #endif

@@ -64,6 +64,17 @@ int main(int argc, char **argv)
         std::vector<ofpix_t> us((size_t) n * (frames - 1)), vs((size_t) n * (frames - 1));
         brox_optic_flow_temporal(I.data(), us.data(), vs.data(), nx, ny, frames, 18.0, 7.0, 2, 0.75, 1e-4, 1, 3, false);
         put(fo, us); put(fo, vs);
+        // TV-L1 with occlusions through the reference's own overload (src/tvl1occflow.h), and its stateless helpers
+        if (frames >= 3) {
+            std::vector<ofpix_t> chi(n);
+            ofpix_t *I2 = I.data() + 2 * (size_t) n;
+            Dual_TVL1_optic_flow_multiscale(I0, I1, I2, I1, u.data(), v.data(), chi.data(), nx, ny, 0.15, 0.01, 0.15, 0.3, 3, 0.5, 2, 0.01, false);
+            put(fo, u); put(fo, v); put(fo, chi);
+            a.assign(I0, I0 + n);
+            me_median_filtering(a.data(), nx, ny, 3); put(fo, a);
+            image_normalization_4(I0, I1, I2, I1, a.data(), b.data(), c.data(), u.data(), n);
+            put(fo, a); put(fo, b); put(fo, c); put(fo, u);
+        }
         // the reference's failure mode: an exception with its own text
         try {
             std::vector<ofpix_t> tiny(9, 1.0);

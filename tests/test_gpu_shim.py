@@ -61,4 +61,9 @@ def test_reference_prototypes_through_the_shim(orc, synth, tmp_path):
     uo, vo, _ = orc.brox_temporal(seq, alpha=18.0, gamma=7.0, nscales=2, nu=0.75, TOL=1e-4, inner=1, outer=3)
     T = (frames - 1, ny, nx)
     assert np.abs(take(T) - uo).max() < 1e-11 and np.abs(take(T) - vo).max() < 1e-11
+    uo, vo, co, _ = orc.tvl1occ_multiscale(seq[0], seq[1], seq[2], filtI0=seq[1], nscales=3, warps=2)
+    assert np.array_equal(take(S), uo) and np.array_equal(take(S), vo) and np.array_equal(take(S), co)
+    assert np.array_equal(take(S), orc.median_filtering(seq[0], 3))
+    for want in orc.image_normalization_4(seq[0], seq[1], seq[2], seq[1]):
+        assert np.array_equal(take(S), want)
     assert pos[0] == out.size
