@@ -175,3 +175,30 @@ def test_sor_random_lockstep_groups(gpu64, orc, synth, seed):
     finally:
         for name in ("sor_window", "sor_rows", "sor_batch", "sor_spw"):
             gpu64.set_option(name, 0)
+
+
+FUZZ_OCC = int(os.environ.get("OFX_FUZZ_OCC", "4"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_OCC))
+def test_tvl1occ_random_lockstep_groups(ofx_mod, gpu64, orc, synth, seed):
+    """TV-L1 with occlusions: random sizes (rows above / below the 125-row blocks of the ROF sweep, widths below its 24-step
+    launch window), parameters and group sizes; every triple of a lockstep group equals the oracle bit for bit"""
+    rng = np.random.default_rng(9100 + seed)
+    nx, ny = int(rng.integers(20, 150)), int(rng.integers(20, 290))
+    ns = 1
+    while ns < 3 and min(nx, ny) / 2 ** ns >= 12:
+        ns += 1
+    kw = dict(lam=float(rng.choice([0.15, 0.3])), alpha=float(rng.choice([0.01, 0.05])), beta=float(rng.choice([0.15, 0.05])),
+              theta=float(rng.choice([0.3, 0.2])), nscales=ns, zfactor=0.5, warps=int(rng.integers(1, 3)),
+              epsilon=float(rng.choice([0.01, 0.001])))
+    G = int(rng.integers(2, 5))
+    triples = []
+    for k in range(G):
+        seq = synth.sequence(nx, ny, 3, int(rng.integers(1, 9)))
+        triples.append((seq[0], seq[1], seq[2]) if rng.random() < 0.7 else (seq[1], seq[1], seq[2], seq[0]))
+    ctx = ofx_mod.Ofx(0, ofx_mod.F64)
+    got = ofx_mod.tvl1occ_batch([ctx], triples, **kw)
+    for t, (u, v, c) in zip(triples, got):
+        uo, vo, co, _ = orc.tvl1occ_multiscale(t[0], t[1], t[2], filtI0=t[3] if len(t) > 3 else None, **kw)
+        assert np.array_equal(u, uo) and np.array_equal(v, vo) and np.array_equal(c, co), (nx, ny, kw)
