@@ -218,7 +218,9 @@ OFX_DEV bool tvl1_continues(double prev1, double prev2, int k, int size, double 
 // `amask`: first launch of a loop whose predecessor stopped at once).  If the loop then stops on the first
 // iteration the host just points the level at that buffer; a miss falls back to recomputing the single iteration.
 // Same formula in k_loop_finalize, which tells the host whether the stopping launch had stored its A state.
-OFX_DEV bool tvl1_store_a(int k, double e1, double eps2, double afac) { return k >= 1 && e1 <= eps2 * afac; }
+// afac = 0 switches the mechanism off (fixed-work mode, option store_a = 0): without the guard a loop that has reached its
+// bitwise fixed point (e1 == 0) would satisfy 0 <= 0 and store the state in every launch.
+OFX_DEV bool tvl1_store_a(int k, double e1, double eps2, double afac) { return afac > 0.0 && k >= 1 && e1 <= eps2 * afac; }
 
 // ---- lockstep groups ------------------------------------------------------------------------------------
 // Every array of a level holds G image pairs back to back (pair g at element offset g * nx * ny) and one
