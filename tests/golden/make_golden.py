@@ -36,6 +36,10 @@ SOLVER_CASES = {
     # temporal Brox: "pair" is the number of frames of synth.sequence
     "broxt_seq4_64x48": ("broxt", 4, 64, 48, dict(alpha=18.0, gamma=7.0, nscales=2, nu=0.75, TOL=1e-4, inner=1, outer=3)),
     "broxt_seq3_48x40": ("broxt", 3, 48, 40, dict(alpha=30.0, gamma=0.0, nscales=2, nu=0.5, TOL=1e-4, inner=2, outer=2)),
+    # TV-L1 with occlusions on frames 0, 1, 2 of synth.sequence(nx, ny, 3, pair): the reference built with the zero-filling
+    # operator new[] of oracle/ref_shim.cpp (its dual variables are read uninitialised otherwise)
+    "occ_seq1_64x48": ("occ", 1, 64, 48, dict(lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=2, zfactor=0.5, warps=2, epsilon=0.01)),
+    "occ_seq3_90x70_e001": ("occ", 3, 90, 70, dict(lam=0.3, alpha=0.05, beta=0.05, theta=0.2, nscales=3, zfactor=0.5, warps=2, epsilon=0.001)),
 }
 
 
@@ -46,18 +50,25 @@ def run_verbose(case):
     kind = SOLVER_CASES[case][0]
     text = out.stderr if kind not in ("brox", "broxt") else out.stdout
     pat = {"tvl1": r"Iterations: (\d+),", "hs": r"Iterations (\d+) \(", "brox": r"Iterations: (\d+)",
-           "broxt": r"Iterations: (\d+)"}[kind]
+           "broxt": r"Iterations: (\d+)", "occ": r"Iterations: (\d+),"}[kind]
     iters = [int(x) for x in re.findall(pat, text)]
     data = np.load(os.path.join(HERE, "_child.npz"))
     u, v = data["u"], data["v"]
+    extra = {"chi": data["chi"]} if "chi" in data else {}
     os.remove(os.path.join(HERE, "_child.npz"))
-    return u, v, np.array(iters, dtype=np.int32)
+    return u, v, np.array(iters, dtype=np.int32), extra
 
 
 def child(case):
     kind, pair, nx, ny, kw = SOLVER_CASES[case]
     ref = oracle.Ref()
     ref.set_num_threads(1)
+    if kind == "occ":
+        seq = synth.sequence(nx, ny, 3, pair)
+        u, v, chi = ref.tvl1occ_multiscale(seq[0], seq[1], seq[2], verbose=1, **kw)
+        sys.stdout.flush()
+        np.savez(os.path.join(HERE, "_child.npz"), u=u, v=v, chi=chi)
+        return
     if kind == "broxt":
         u, v = ref.brox_temporal(synth.sequence(nx, ny, pair), verbose=1, **kw)
     else:
@@ -79,6 +90,8 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only":
         only = sys.argv[2].split(",")
         return solvers(only)
+    if len(sys.argv) > 1 and sys.argv[1] == "--occ-operators":      # just tests/golden/occ_operators.npz
+        return occ_operators(ref)
     rng = np.random.default_rng(20261004)
 
     # ---- operators on tiny arrays (borders, odd sizes, negative / far-out warp coordinates) ----
@@ -112,8 +125,57 @@ def main():
     ops["zoom_sizes"] = np.array([[nx, ny, *ref.zoom_size(nx, ny, f)] for nx, ny in ((1920, 1080), (135, 68), (40, 23), (7, 5))
                                   for f in (0.5, 0.75)], dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, "operators.npz"), **ops)
+    occ_operators(ref)
 
     solvers(None)
+
+
+def occ_operators(ref):
+    """operators next to the hot path: colour warp / normalisations, median, the three sub-solvers of TV-L1
+    with occlusions (Solver_wrt_u / _chi from their first call at a width, i.e. from zero dual variables) and the ROF box sweep"""
+    rng = np.random.default_rng(20261005)
+    occ = {}
+    for tag, (ny, nx) in {"9x13": (13, 9), "24x19": (19, 24), "17x130": (130, 17)}.items():
+        f = lambda s=1.0: rng.standard_normal((ny, nx)) * s
+        u1, u2 = f(0.8), f(0.8)
+        chi = np.clip(rng.random((ny, nx)) * 1.4 - 0.2, 0, 1)
+        I1wx, I1wy, I_1wx, I_1wy = f(6), f(6), f(6), f(6)
+        I1wx[::5, ::3] = 0.0
+        I1wy[::5, ::3] = 0.0
+        rho1_c, rho3_c = f(3), f(3)
+        grad1, grad3 = I1wx ** 2 + I1wy ** 2, I_1wx ** 2 + I_1wy ** 2
+        g = 1.0 / (1.0 + 0.05 * rng.random((ny, nx)) * 40)
+        ins = dict(u1=u1, u2=u2, chi=chi, I1wx=I1wx, I1wy=I1wy, I_1wx=I_1wx, I_1wy=I_1wy, rho1_c=rho1_c, rho3_c=rho3_c,
+                   grad1=grad1, grad3=grad3, g=g)
+        for k, a in ins.items():
+            occ["in_%s_%s" % (k, tag)] = a
+        v = ref.occ_solver_v(u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, grad1, grad3, 0.01, 0.3, 0.15)
+        for k, a in zip(("v1", "v2", "vf1", "vf2", "vb1", "vb2"), v):
+            occ["%s_%s" % (k, tag)] = a
+        occ["chi100_" + tag] = ref.occ_solver_chi(u1, u2, chi, I1wx, I1wy, I_1wx, I_1wy, rho1_c, rho3_c, v[2], v[3], v[4], v[5], g,
+                                                  0.15, 0.3, 0.01, 0.15, 0.15, 0.15, fresh=True)
+        su1, su2 = ref.occ_solver_u(v[0], v[1], chi, g, 0.3, 0.15, fresh=True)
+        occ["su1_" + tag], occ["su2_" + tag] = su1, su2
+        P1, P2 = f(0.1), f(0.1)
+        occ["in_P1_" + tag], occ["in_P2_" + tag] = P1, P2
+        rf = u1 / 0.3 + rho1_c * 0.05
+        occ["in_roff_" + tag] = rf
+        ru, rp1, rp2 = ref.rof_box(u1, rf, P1, P2, g, 0.3, 1.25, 3)
+        occ["rof_u_" + tag], occ["rof_p1_" + tag], occ["rof_p2_" + tag] = ru, rp1, rp2
+        img = np.round(f(4), 1)
+        occ["in_med_" + tag] = img
+        occ["med3_" + tag], occ["med5_" + tag] = ref.median_filtering(img, 3), ref.median_filtering(img, 5)
+        col = rng.random((ny, nx, 3)) * 255
+        occ["in_col_" + tag] = col
+        occ["warpcol_nb_" + tag] = ref.bicubic_warp_color(col, u1 * 3, u2 * 3, False)
+        occ["warpcol_bo_" + tag] = ref.bicubic_warp_color(col, u1 * 3, u2 * 3, True)
+        n1, n2 = ref.image_normalization_2_color(col, col * 0.4 - 20)
+        occ["ncol1_" + tag], occ["ncol2_" + tag] = n1, n2
+        for k, a in zip("abcd", ref.image_normalization_4(I1wx, I1wy * 2 + 30, rho1_c, chi)):
+            occ["n4%s_%s" % (k, tag)] = a
+        for k, a in zip("abc", ref.image_normalization_3(I1wx, I1wy * 2 + 30, rho1_c)):
+            occ["n3%s_%s" % (k, tag)] = a
+    np.savez_compressed(os.path.join(HERE, "occ_operators.npz"), **occ)
 
 
 def solvers(only):
@@ -124,8 +186,8 @@ def solvers(only):
     for case, (kind, pair, nx, ny, kw) in SOLVER_CASES.items():
         if only is not None and case not in only:
             continue
-        u, v, iters = run_verbose(case)
-        np.savez_compressed(os.path.join(HERE, case + ".npz"), u=u, v=v, iters=iters)
+        u, v, iters, extra = run_verbose(case)
+        np.savez_compressed(os.path.join(HERE, case + ".npz"), u=u, v=v, iters=iters, **extra)
         meta[case] = dict(kind=kind, pair=pair, nx=nx, ny=ny, params=kw, mean_u=float(u.mean()), mean_v=float(v.mean()),
                           iters=int(iters.sum()))
         print(case, meta[case])

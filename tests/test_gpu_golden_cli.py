@@ -69,6 +69,19 @@ def test_hs_and_brox_vs_reference_vectors(gpu64, synth):
     assert aepe(u, v, g["u"], g["v"]) < 1e-4 and np.abs(u - g["u"]).max() < 1e-11
 
 
+@pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c]["kind"] == "occ"))
+def test_tvl1occ_vs_reference_vectors(gpu64, synth, case):
+    """TV-L1 with occlusions against the compiled reference's committed outputs (zero-filled heap): flow, occlusion map and the
+    outer iterations the reference printed, bit for bit"""
+    c, g = CASES[case], load(case)
+    seq = synth.sequence(c["nx"], c["ny"], 3, c["pair"])
+    u, v, chi = gpu64.tvl1occ_multiscale(seq[0], seq[1], seq[2], **c["params"])
+    assert np.array_equal(u, g["u"]) and np.array_equal(v, g["v"]) and np.array_equal(chi, g["chi"])
+    st, P = gpu64.stats(), c["params"]
+    got = [st.iters[s][w] for s in range(P["nscales"] - 1, -1, -1) for w in range(P["warps"])]      # printed coarse to fine
+    assert got == list(g["iters"])
+
+
 def write_pgm(path, img):
     with open(path, "wb") as f:
         f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))

@@ -55,7 +55,12 @@ def test_bicubic_at_and_zoom_size(orc):
 def test_solvers(orc, synth, case):
     c = CASES[case]
     g = load(case)
-    if c["kind"] == "broxt":        # temporal Brox: "pair" holds the number of frames of synth.sequence
+    if c["kind"] == "occ":          # TV-L1 with occlusions: "pair" is the variant of the three-frame synthetic sequence
+        seq = synth.sequence(c["nx"], c["ny"], 3, c["pair"])
+        u, v, chi, iters = orc.tvl1occ_multiscale(seq[0], seq[1], seq[2], **c["params"])
+        assert np.array_equal(chi, g["chi"])
+        out = (u, v, iters)
+    elif c["kind"] == "broxt":      # temporal Brox: "pair" holds the number of frames of synth.sequence
         out = orc.brox_temporal(synth.sequence(c["nx"], c["ny"], c["pair"]), **c["params"])
     else:
         I0, I1 = synth.pair(c["pair"], c["nx"], c["ny"])
@@ -65,6 +70,37 @@ def test_solvers(orc, synth, case):
     assert np.array_equal(u, g["u"]) and np.array_equal(v, g["v"])
     # the reference prints coarse-to-fine; the oracle stores [scale][solve] with scale 0 = finest
     assert list(iters[::-1].ravel()) == list(g["iters"])
+
+
+@pytest.mark.parametrize("tag", ["9x13", "24x19", "17x130"])
+def test_occlusion_operators(orc, tag):
+    """SURVEY 8f.1 / 8f.4 operators against the compiled reference's committed outputs (tests/golden/occ_operators.npz):
+    Solver_wrt_v, Solver_wrt_chi (100 iterations from a zero dual variable), Solver_wrt_u (10 ROF iterations from zero dual
+    planes), the ROF box sweep from given dual planes, medians, colour warp and the joint normalisations"""
+    g = load("occ_operators")
+    i = lambda k: g["in_%s_%s" % (k, tag)]
+    u1, u2, chi = i("u1"), i("u2"), i("chi")
+    args = (i("I1wx"), i("I1wy"), i("I_1wx"), i("I_1wy"), i("rho1_c"), i("rho3_c"))
+    v = orc.occ_solver_v(u1, u2, chi, *args, i("grad1"), i("grad3"), 0.01, 0.3, 0.15)
+    for k, a in zip(("v1", "v2", "vf1", "vf2", "vb1", "vb2"), v):
+        assert np.array_equal(a, g["%s_%s" % (k, tag)]), k
+    c100, _, _ = orc.occ_solver_chi(u1, u2, chi, *args, v[2], v[3], v[4], v[5], i("g"), 0.15, 0.3, 0.01, 0.15, 0.15, 0.15)
+    assert np.array_equal(c100, g["chi100_" + tag])
+    su1, su2, _ = orc.occ_solver_u(v[0], v[1], chi, i("g"), 0.3, 0.15)
+    assert np.array_equal(su1, g["su1_" + tag]) and np.array_equal(su2, g["su2_" + tag])
+    for a, k in zip(orc.rof_box(u1, i("roff"), i("P1"), i("P2"), i("g"), 0.3, 1.25, 3), ("rof_u", "rof_p1", "rof_p2")):
+        assert np.array_equal(a, g["%s_%s" % (k, tag)]), k
+    assert np.array_equal(orc.median_filtering(i("med"), 3), g["med3_" + tag])
+    assert np.array_equal(orc.median_filtering(i("med"), 5), g["med5_" + tag])
+    col = i("col")
+    assert np.array_equal(orc.bicubic_warp_color(col, u1 * 3, u2 * 3, False), g["warpcol_nb_" + tag])
+    assert np.array_equal(orc.bicubic_warp_color(col, u1 * 3, u2 * 3, True), g["warpcol_bo_" + tag])
+    for a, k in zip(orc.image_normalization_2_color(col, col * 0.4 - 20), ("ncol1", "ncol2")):
+        assert np.array_equal(a, g["%s_%s" % (k, tag)])
+    for a, k in zip(orc.image_normalization_4(i("I1wx"), i("I1wy") * 2 + 30, i("rho1_c"), chi), "abcd"):
+        assert np.array_equal(a, g["n4%s_%s" % (k, tag)])
+    for a, k in zip(orc.image_normalization_3(i("I1wx"), i("I1wy") * 2 + 30, i("rho1_c")), "abc"):
+        assert np.array_equal(a, g["n3%s_%s" % (k, tag)])
 
 
 @pytest.mark.parametrize("batch", [1, 7, 64])
