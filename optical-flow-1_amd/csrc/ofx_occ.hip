@@ -479,12 +479,13 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
 // edge of its neighbour, 0 on the image border), Fs / Fe = differences of f across those edges (0 on the border), AL =
 // alfa of the cell (the reference stores the same value on both edges).
 // * Hyperplane-major arrays.  One thread owns one image row, so the 64 lanes of a wave touch 64 different rows at every step;
-//   in row-major arrays that is 64 cache lines per load instruction.  All five arrays of a sweep are therefore stored with
-//   index (2 ci + cj) ny + ci: the cells of one step are contiguous (same layout idea as LaySkew in ofx_sor.hip).
+//   in row-major arrays that is 64 cache lines per load instruction.  All arrays of a sweep are therefore stored with
+//   index (2 ci + cj) ny + ci: the cells of one step are contiguous (same layout idea as LaySkew in ofx_sor.hip); Ps / Pe
+//   and Fs / Fe are interleaved pairs (one 16-byte access each).
 // * A launch works from LDS.  One thread owns one row; a workgroup first brings everything its ROF_K steps will touch into
-//   LDS -- the (Ps, Pe) pairs of positions q0 - 4 .. q1 + 2 of the skewed coordinate p = 2 ci + cj and the (Fs, Fe, alfa)
-//   triples of positions q0 - 2 .. q1 + 1, per row -- with all loads in flight at once (one memory latency per launch instead of one
-//   per step), then runs its steps on LDS only: every neighbour access is an LDS access, one barrier per step, and the thread
+//   LDS -- the (Ps, Pe) pairs of positions q0 - 4 .. q1 + 2 of the skewed coordinate p = 2 ci + cj and the (Fs, Fe), alfa
+//   of positions q0 - 2 .. q1 + 1, per row -- with all loads in flight at once and shared between the three waves so that none
+//   exceeds the 63 loads a wave can have outstanding (one memory latency per launch instead of one per step), then runs its steps on LDS only: every neighbour access is an LDS access, one barrier per step, and the thread
 //   that makes the LAST update of a value (the north edge from the row below, the west edge from the next cell of the row)
 //   also stores it to global memory, without waiting for the store.  A step costs the LDS round trip plus the cell's chain
 //   of six dependent IEEE divisions.  Entries whose last update falls into a later launch (2 per row) are written back at
@@ -504,10 +505,11 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
 #define ROF_LAG (ROF_K + 8)
 #define ROF_RING (ROF_K + 7)         // positions q0 - 4 .. q1 + 2
 #define ROF_COEF (ROF_K + 3)         // positions q0 - 2 .. q1 + 1
-#define ROF_LDS_BYTES ((size_t) ROF_NT * (ROF_RING * sizeof(double2) + 3 * ROF_COEF * sizeof(double)))
-struct RofArr {                      // all five arrays hyperplane-major
-    double *Ps, *Pe;
-    const double *Fs, *Fe, *AL;
+#define ROF_LDS_BYTES ((size_t) ROF_NT * (ROF_RING * sizeof(double2) + ROF_COEF * (sizeof(double2) + sizeof(double))))
+struct RofArr {                      // all arrays hyperplane-major; PP = (Ps, Pe) and FF = (Fs, Fe) per cell: one 16-byte access each
+    double2 *PP;
+    const double2 *FF;
+    const double *AL;
     int nx, ny;
 };
 static inline __host__ __device__ size_t rof_skew_elems(int nx, int ny) { return (size_t) (2 * (ny - 1) + nx) * ny; }
@@ -516,29 +518,29 @@ OFX_DEV size_t rof_sk(int ci, int cj, int ny) { return (size_t) (2 * ci + cj) * 
 // the LDS copy of one workgroup's launch window and what a cell may do with it
 struct RofRing {
     const RofArr &a;
-    double2 (*win)[ROF_NT];          // [position - (q0 - 4)][thread]: .x = Ps, .y = Pe
-    double (*cf)[ROF_NT];            // [k * ROF_COEF + position - (q0 - 2)][thread]: k = 0 Fs, 1 Fe, 2 alfa
-    int row0;                        // image row of thread 0 (= first own row - 2)
+    double2 (*win)[ROF_NT];          // [position - (q0 - 4)][column]: .x = Ps, .y = Pe
+    double2 (*cff)[ROF_NT];          // [position - (q0 - 2)][column]: .x = Fs, .y = Fe
+    double (*cal)[ROF_NT];           // [position - (q0 - 2)][column]: alfa
+    int row0;                        // image row of column 0 (= first own row - 2)
     int pw0;                         // q0 - 4
     bool keep_s;                     // this row's south edges are final for this workgroup (last own row): store them
     OFX_DEV double2 &at(int ci, int cj) const { return win[2 * ci + cj - pw0][ci - row0]; }
     OFX_DEV double ps(int ci, int cj) const { return (ci >= 0 && cj >= 0) ? at(ci, cj).x : 0.0; }
     OFX_DEV double pe(int ci, int cj) const { return (ci >= 0 && cj >= 0) ? at(ci, cj).y : 0.0; }
-    OFX_DEV double coef(int k, int ci, int cj) const { return cf[k * ROF_COEF + 2 * ci + cj - pw0 - 2][ci - row0]; }
-    OFX_DEV double Fs(int ci, int cj) const { return coef(0, ci, cj); }
-    OFX_DEV double Fe(int ci, int cj) const { return coef(1, ci, cj); }
-    OFX_DEV double AL(int ci, int cj) const { return coef(2, ci, cj); }
+    OFX_DEV double Fs(int ci, int cj) const { return cff[2 * ci + cj - pw0 - 2][ci - row0].x; }
+    OFX_DEV double Fe(int ci, int cj) const { return cff[2 * ci + cj - pw0 - 2][ci - row0].y; }
+    OFX_DEV double AL(int ci, int cj) const { return cal[2 * ci + cj - pw0 - 2][ci - row0]; }
 #if ROF_VAR == 2                     // timing experiment: no global stores from the steps
     OFX_DEV void put_w(int ci, int cj, double v) const { at(ci, cj - 1).y = v; }
     OFX_DEV void put_n(int ci, int cj, double v) const { at(ci - 1, cj).x = v; }
 #else
-    OFX_DEV void put_w(int ci, int cj, double v) const { at(ci, cj - 1).y = v; a.Pe[rof_sk(ci, cj - 1, a.ny)] = v; }   // final
-    OFX_DEV void put_n(int ci, int cj, double v) const { at(ci - 1, cj).x = v; a.Ps[rof_sk(ci - 1, cj, a.ny)] = v; }   // final
+    OFX_DEV void put_w(int ci, int cj, double v) const { at(ci, cj - 1).y = v; a.PP[rof_sk(ci, cj - 1, a.ny)].y = v; }   // final
+    OFX_DEV void put_n(int ci, int cj, double v) const { at(ci - 1, cj).x = v; a.PP[rof_sk(ci - 1, cj, a.ny)].x = v; }   // final
 #endif
     OFX_DEV void put_s(int ci, int cj, double v) const
     {
         at(ci, cj).x = v;
-        if (keep_s) a.Ps[rof_sk(ci, cj, a.ny)] = v;
+        if (keep_s) a.PP[rof_sk(ci, cj, a.ny)].x = v;
     }
     OFX_DEV void put_e(int ci, int cj, double v) const { at(ci, cj).y = v; }
 };
@@ -676,12 +678,13 @@ __global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, do
 {
     extern __shared__ double2 rof_lds[];
     double2 (*win)[ROF_NT] = reinterpret_cast<double2 (*)[ROF_NT]>(rof_lds);
-    double (*cf)[ROF_NT] = reinterpret_cast<double (*)[ROF_NT]>(rof_lds + ROF_RING * ROF_NT);
+    double2 (*cff)[ROF_NT] = reinterpret_cast<double2 (*)[ROF_NT]>(rof_lds + ROF_RING * ROF_NT);
+    double (*cal)[ROF_NT] = reinterpret_cast<double (*)[ROF_NT]>(rof_lds + (ROF_RING + ROF_COEF) * ROF_NT);
     if (!((s.mask >> blockIdx.z) & 1u)) return;
     RofArr a = blockIdx.y ? s.a[1] : s.a[0];                                // by value: a dynamic index would be re-read from the kernel arguments at every use
     {
         const size_t off = (size_t) blockIdx.z * s.stride;
-        a.Ps += off; a.Pe += off; a.Fs += off; a.Fe += off; a.AL += off;
+        a.PP += off; a.FF += off; a.AL += off;
     }
     const int nx = a.nx, ny = a.ny;
     const int t = (int) threadIdx.x, row0 = (int) blockIdx.x * ROF_R - 2;
@@ -700,35 +703,44 @@ __global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, do
         ci = (t == ROF_NT) ? 0 : ny - 1;
         own = t < ROF_NT + 2 && ci - row0 >= 2 && ci - row0 < 2 + ROF_R;
     }
-    const RofRing ring = {a, win, cf, row0, q0 - 4, ci - row0 == 1 + ROF_R};
+    const RofRing ring = {a, win, cff, cal, row0, q0 - 4, ci - row0 == 1 + ROF_R};
+    // Everything the launch reads.  Unconditional loads (out-of-range entries read a harmless address and are never used)
+    // into registers first, so that all of them are in flight together -- one memory latency, not one per entry -- and split so
+    // that no wave has more loads than fit in flight at once (63): the column threads bring their (Ps, Pe) and (Fs, Fe)
+    // pairs, 31 + 27 16-byte loads; the third wave brings alfa for two columns per lane, 2 x 27 8-byte loads.
     if (column) {
-        // everything the launch reads.  Unconditional loads (out-of-range entries read a harmless address and are never
-        // used) into registers first, so that all of them are in flight together: one memory latency, not one per entry
         const int cic = min(max(ci, 0), ny - 1);
-        double2 ring_in[ROF_RING];
+        double2 ring_in[ROF_RING], ff_in[ROF_COEF];
 #pragma unroll
         for (int k = 0; k < ROF_RING; k++) {
             const int p = q0 - 4 + k, x = p - 2 * cic;
-            const size_t e = (x >= 0 && x < nx) ? (size_t) p * ny + cic : (size_t) cic;
-            ring_in[k] = make_double2(a.Ps[e], a.Pe[e]);
+            ring_in[k] = a.PP[(x >= 0 && x < nx) ? (size_t) p * ny + cic : (size_t) cic];
         }
-#pragma unroll
-        for (int k = 0; k < ROF_RING; k++) win[k][t] = ring_in[k];
-        double coef_in[3][ROF_COEF];
 #pragma unroll
         for (int k = 0; k < ROF_COEF; k++) {
             const int p = q0 - 2 + k, x = p - 2 * cic;
-            const size_t e = (x >= 0 && x < nx) ? (size_t) p * ny + cic : (size_t) cic;
-            coef_in[0][k] = a.Fs[e];
-            coef_in[1][k] = a.Fe[e];
-            coef_in[2][k] = a.AL[e];
+            ff_in[k] = a.FF[(x >= 0 && x < nx) ? (size_t) p * ny + cic : (size_t) cic];
         }
 #pragma unroll
-        for (int k = 0; k < ROF_COEF; k++) {
-            cf[k][t] = coef_in[0][k];
-            cf[ROF_COEF + k][t] = coef_in[1][k];
-            cf[2 * ROF_COEF + k][t] = coef_in[2][k];
+        for (int k = 0; k < ROF_RING; k++) win[k][t] = ring_in[k];
+#pragma unroll
+        for (int k = 0; k < ROF_COEF; k++) cff[k][t] = ff_in[k];
+    } else {
+        const int lane = t - ROF_NT;                       // 0 .. 63: columns lane and lane + 64
+        double al_in[2][ROF_COEF];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int cc = min(max(row0 + lane + 64 * h, 0), ny - 1);
+#pragma unroll
+            for (int k = 0; k < ROF_COEF; k++) {
+                const int p = q0 - 2 + k, x = p - 2 * cc;
+                al_in[h][k] = a.AL[(x >= 0 && x < nx) ? (size_t) p * ny + cc : (size_t) cc];
+            }
         }
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int k = 0; k < ROF_COEF; k++) cal[k][lane + 64 * h] = al_in[h][k];
     }
     __syncthreads();
     RofPre pre = {};
@@ -747,36 +759,39 @@ __global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, do
             const int x = p - 2 * ci;
             if (x >= 0 && x < nx) {
                 const size_t e = (size_t) p * ny + ci;
-                a.Ps[e] = win[p - q0 + 4][t].x;
-                if (p == q1) a.Pe[e] = win[p - q0 + 4][t].y;
+                a.PP[e].x = win[p - q0 + 4][t].x;
+                if (p == q1) a.PP[e].y = win[p - q0 + 4][t].y;
             }
         }
     }
 }
 
-// row-major <-> hyperplane-major (state planes of the host-facing entry points)
-__global__ void k_rof_skew(const double *__restrict__ in, double *__restrict__ out, int nx, int ny, int to_skew)
+// row-major planes (Ps, Pe) <-> hyperplane-major pairs (state of the host-facing entry points)
+__global__ void k_rof_skew(double *__restrict__ ps, double *__restrict__ pe, double2 *__restrict__ pp, int nx, int ny, int to_skew)
 {
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= ny) return;
     const size_t c = (size_t) i * nx + j, k = rof_sk(i, j, ny);
-    if (to_skew) out[k] = in[c];
-    else out[c] = in[k];
+    if (to_skew) pp[k] = make_double2(ps[c], pe[c]);
+    else {
+        const double2 v = pp[k];
+        ps[c] = v.x;
+        pe[c] = v.y;
+    }
 }
 // edge differences of f (once per call), :137-164
-__global__ void k_rof_fdiff(const double *__restrict__ f, double *__restrict__ Fs, double *__restrict__ Fe, int nx, int ny,
-                            OccGrp Grm, size_t sk_stride)
+__global__ void k_rof_fdiff(const double *__restrict__ f, double2 *__restrict__ FF, int nx, int ny, OccGrp Grm, size_t sk_stride)
 {
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
     size_t o;
     if (j >= nx || i >= ny || !occ_grp(Grm, o)) return;
     const size_t c = o + (size_t) i * nx + j, k = blockIdx.z * sk_stride + rof_sk(i, j, ny);
-    Fs[k] = (i < ny - 1) ? f[c + nx] - f[c] : 0.0;
-    Fe[k] = (j < nx - 1) ? f[c + 1] - f[c] : 0.0;
+    FF[k] = make_double2((i < ny - 1) ? f[c + nx] - f[c] : 0.0, (j < nx - 1) ? f[c + 1] - f[c] : 0.0);
 }
 // alfa = hypot(forward gradient of u) / (lambda g) with the file-local hypot = sqrt(x x + y y), :15-20,173-187
 struct RofPt {
-    const double *u[2], *f[2], *Ps[2], *Pe[2];
+    const double *u[2], *f[2];
+    const double2 *PP[2];
     double *AL[2], *uo[2];
     int nc;                          // problems per set; blockIdx.z = set * nc + problem
     size_t rm_stride, sk_stride;     // per set: row-major planes (u, f, g), hyperplane-major planes (Ps, Pe, AL)
@@ -797,19 +812,19 @@ __global__ void k_rof_u(RofPt a, int nx, int ny, double lambda)
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z % a.nc, set = blockIdx.z / a.nc;
     if (j >= nx || i >= ny || !((a.mask >> set) & 1u)) return;
     const size_t c = set * a.rm_stride + (size_t) i * nx + j;
-    const double *Ps = a.Ps[k] + set * a.sk_stride, *Pe = a.Pe[k] + set * a.sk_stride;
-    const size_t e = rof_sk(i, j, ny);
-    const double pn = i > 0 ? Ps[rof_sk(i - 1, j, ny)] : 0.0, pw = j > 0 ? Pe[rof_sk(i, j - 1, ny)] : 0.0;
-    a.uo[k][c] = lambda * a.f[k][c] + lambda * (Ps[e] - pn + Pe[e] - pw);
+    const double2 *PP = a.PP[k] + set * a.sk_stride;
+    const double2 own = PP[rof_sk(i, j, ny)];
+    const double pn = i > 0 ? PP[rof_sk(i - 1, j, ny)].x : 0.0, pw = j > 0 ? PP[rof_sk(i, j - 1, ny)].y : 0.0;
+    a.uo[k][c] = lambda * a.f[k][c] + lambda * (own.x - pn + own.y - pw);
 }
 
 // nc = 1 | 2 independent problems sharing g, lambda and the size (the two flow components of Solver_wrt_u), every launch
 // serving both -- and all G sets of them (lockstep groups: set s on planes offset by s * nx * ny / s * rof_skew_elems(),
 // sets whose bit of `mask` is clear are left alone).  Device arrays in place: u[k] (in: seed, out: result; row-major),
-// Ps[k] / Pe[k] (in/out state, HYPERPLANE-MAJOR, rof_skew_elems() doubles per set); scratch = 3 nc G hyperplane-major planes.
-static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *const *f, double *const *Ps, double *const *Pe,
-                       const double *g, double lambda, double omega, int nx, int ny, int n_iter, double *scratch, int G = 1,
-                       unsigned mask = 1u)
+// PP[k] = (Ps, Pe) pairs (in/out state, HYPERPLANE-MAJOR, rof_skew_elems() pairs per set); scratch = 3 nc G hyperplane-major
+// planes of doubles (the (Fs, Fe) pairs of every problem first, then the alfa planes).
+static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *const *f, double2 *const *PP, const double *g,
+                       double lambda, double omega, int nx, int ny, int n_iter, double *scratch, int G = 1, unsigned mask = 1u)
 {
     const size_t n = rof_skew_elems(nx, ny), nrm = (size_t) nx * ny;
     const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), nc * G), block(64, 4);
@@ -817,13 +832,14 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
     RofPt pt;
     for (int k = 0; k < 2; k++) {
         const int c = k < nc ? k : 0;
-        double *Fs = scratch + (3 * c) * n * G, *Fe = scratch + (3 * c + 1) * n * G, *AL = scratch + (3 * c + 2) * n * G;
+        double2 *FF = reinterpret_cast<double2 *>(scratch + (2 * c) * n * G);        // pairs first: 16-byte aligned whatever n
+        double *AL = scratch + (2 * nc + c) * n * G;
         if (k < nc) {
-            hipLaunchKernelGGL(k_rof_fdiff, dim3(grid.x, grid.y, G), block, 0, ctx->stream, f[c], Fs, Fe, nx, ny, OccGrp{nrm, mask}, n);
+            hipLaunchKernelGGL(k_rof_fdiff, dim3(grid.x, grid.y, G), block, 0, ctx->stream, f[c], FF, nx, ny, OccGrp{nrm, mask}, n);
             OFX_LAUNCH_CHECK(ctx);
         }
-        set.a[k] = RofArr{Ps[c], Pe[c], Fs, Fe, AL, nx, ny};
-        pt.u[k] = u[c]; pt.f[k] = f[c]; pt.Ps[k] = Ps[c]; pt.Pe[k] = Pe[c]; pt.AL[k] = AL; pt.uo[k] = u[c];
+        set.a[k] = RofArr{PP[c], FF, AL, nx, ny};
+        pt.u[k] = u[c]; pt.f[k] = f[c]; pt.PP[k] = PP[c]; pt.AL[k] = AL; pt.uo[k] = u[c];
     }
     set.stride = n; set.mask = mask;
     pt.nc = nc; pt.rm_stride = nrm; pt.sk_stride = n; pt.mask = mask;
@@ -844,20 +860,25 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
     }
     return OFX_OK;
 }
-// host-facing state planes: upload row-major, convert; convert back, download
-static int rof_state_in(ofx_ctx *ctx, const double *host, double **dev, double *tmp, int nx, int ny)
+// host-facing state planes: upload both row-major planes, interleave; split, download.  tmp = 2 nx ny doubles
+static int rof_state_in(ofx_ctx *ctx, const double *hps, const double *hpe, double2 **dev, double *tmp, int nx, int ny)
 {
+    const size_t n = (size_t) nx * ny;
     OFX_TRY(ofx_alloc(ctx, rof_skew_elems(nx, ny), dev));
-    OFX_HIP(ctx, hipMemcpyAsync(tmp, host, (size_t) nx * ny * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_rof_skew, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, (const double *) tmp, *dev, nx, ny, 1);
+    OFX_HIP(ctx, hipMemcpyAsync(tmp, hps, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    OFX_HIP(ctx, hipMemcpyAsync(tmp + n, hpe, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_rof_skew, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, tmp, tmp + n, *dev, nx, ny, 1);
     OFX_LAUNCH_CHECK(ctx);
     return OFX_OK;
 }
-static int rof_state_out(ofx_ctx *ctx, const double *dev, double *host, double *tmp, int nx, int ny)
+static int rof_state_out(ofx_ctx *ctx, double2 *dev, double *hps, double *hpe, double *tmp, int nx, int ny)
 {
-    hipLaunchKernelGGL(k_rof_skew, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, dev, tmp, nx, ny, 0);
+    const size_t n = (size_t) nx * ny;
+    hipLaunchKernelGGL(k_rof_skew, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, tmp, tmp + n, dev, nx, ny, 0);
     OFX_LAUNCH_CHECK(ctx);
-    OFX_HIP(ctx, hipMemcpyAsync(host, tmp, (size_t) nx * ny * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipMemcpyAsync(hps, tmp, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipMemcpyAsync(hpe, tmp + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));      // tmp may be reused by the caller
     return OFX_OK;
 }
 
@@ -871,20 +892,18 @@ extern "C" int ofx_scalar_rof_box_cell_centered(ofx_ctx *ctx, double *u, const d
     if (nIter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "rof_box: nIter=%d", nIter);
     Dev d{ctx};
     const size_t n = (size_t) nx * ny;
-    double *du, *df, *dp1, *dp2, *dg, *tmp, *scratch;
+    double *du, *df, *dg, *tmp, *scratch;
+    double2 *dpp;
     OFX_TRY(d.in(u, &du, n));
     OFX_TRY(d.in(f, &df, n));
     OFX_TRY(d.in(g_function, &dg, n));
-    OFX_TRY(ofx_alloc(ctx, n, &tmp));
-    OFX_TRY(rof_state_in(ctx, initialP1, &dp1, tmp, nx, ny));
-    OFX_TRY(rof_state_in(ctx, initialP2, &dp2, tmp, nx, ny));
+    OFX_TRY(ofx_alloc(ctx, 2 * n, &tmp));
+    OFX_TRY(rof_state_in(ctx, initialP1, initialP2, &dpp, tmp, nx, ny));
     OFX_TRY(ofx_alloc(ctx, 3 * rof_skew_elems(nx, ny), &scratch));
     const double *fs[1] = {df};
-    OFX_TRY(rof_box_dev(ctx, 1, &du, fs, &dp1, &dp2, dg, lambda, omega, nx, ny, nIter, scratch));
+    OFX_TRY(rof_box_dev(ctx, 1, &du, fs, &dpp, dg, lambda, omega, nx, ny, nIter, scratch));
     OFX_TRY(d.out(du, u, n));
-    OFX_TRY(rof_state_out(ctx, dp1, initialP1, tmp, nx, ny));
-    OFX_TRY(d.sync());
-    OFX_TRY(rof_state_out(ctx, dp2, initialP2, tmp, nx, ny));
+    OFX_TRY(rof_state_out(ctx, dpp, initialP1, initialP2, tmp, nx, ny));
     return d.sync();
 }
 
@@ -915,14 +934,15 @@ extern "C" int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const doub
     if (n_iter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "solver_wrt_u: n_iter=%d", n_iter);
     Dev d{ctx};
     const size_t n = (size_t) nx * ny;
-    double *dv1, *dv2, *dchi, *dg, *dp[4], *f1, *f2, *du1, *du2, *tmp, *scratch;
+    double *dv1, *dv2, *dchi, *dg, *f1, *f2, *du1, *du2, *tmp, *scratch;
+    double2 *dpp[2];
     OFX_TRY(d.in(v1, &dv1, n));
     OFX_TRY(d.in(v2, &dv2, n));
     OFX_TRY(d.in(chi, &dchi, n));
     OFX_TRY(d.in(g, &dg, n));
-    OFX_TRY(ofx_alloc(ctx, n, &tmp));
-    double *hp[4] = {p11, p12, p21, p22};
-    for (int k = 0; k < 4; k++) OFX_TRY(rof_state_in(ctx, hp[k], &dp[k], tmp, nx, ny));
+    OFX_TRY(ofx_alloc(ctx, 2 * n, &tmp));
+    OFX_TRY(rof_state_in(ctx, p11, p12, &dpp[0], tmp, nx, ny));
+    OFX_TRY(rof_state_in(ctx, p21, p22, &dpp[1], tmp, nx, ny));
     OFX_TRY(ofx_alloc(ctx, n, &f1));
     OFX_TRY(ofx_alloc(ctx, n, &f2));
     OFX_TRY(ofx_alloc(ctx, n, &du1));
@@ -931,15 +951,13 @@ extern "C" int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const doub
                        (const double *) dv2, (const double *) dchi, f1, f2, du1, du2, nx, ny, theta, beta, OCC_ONE);
     OFX_LAUNCH_CHECK(ctx);
     OFX_TRY(ofx_alloc(ctx, 6 * rof_skew_elems(nx, ny), &scratch));
-    double *us[2] = {du1, du2}, *ps[2] = {dp[0], dp[2]}, *pe[2] = {dp[1], dp[3]};
+    double *us[2] = {du1, du2};
     const double *fs[2] = {f1, f2};
-    OFX_TRY(rof_box_dev(ctx, 2, us, fs, ps, pe, dg, theta, OCC_OMEGA, nx, ny, n_iter, scratch));
+    OFX_TRY(rof_box_dev(ctx, 2, us, fs, dpp, dg, theta, OCC_OMEGA, nx, ny, n_iter, scratch));
     OFX_TRY(d.out(du1, u1, n));
     OFX_TRY(d.out(du2, u2, n));
-    for (int k = 0; k < 4; k++) {
-        OFX_TRY(rof_state_out(ctx, dp[k], hp[k], tmp, nx, ny));
-        OFX_TRY(d.sync());                                        // tmp is reused
-    }
+    OFX_TRY(rof_state_out(ctx, dpp[0], p11, p12, tmp, nx, ny));
+    OFX_TRY(rof_state_out(ctx, dpp[1], p21, p22, tmp, nx, ny));
     return d.sync();
 }
 
@@ -1156,7 +1174,8 @@ int occ_single_scale_dev(ofx_ctx *ctx, int G, const double *I_1, const double *I
                      W.v1, W.v2, W.vf1, W.vf2, W.vb1, W.vb2};
     const OccChi ac = {u1, u2, W.I1wx, W.I1wy, W.I_1wx, W.I_1wy, W.rho1_c, W.rho3_c, W.vf1, W.vf2, W.vb1, W.vb2, W.g, eta1, eta2,
                        W.divu, chi};
-    double *us[2] = {u1, u2}, *ps[2] = {W.state, W.state + 2 * nsk * G}, *pe[2] = {W.state + nsk * G, W.state + 3 * nsk * G};
+    double *us[2] = {u1, u2};
+    double2 *pps[2] = {reinterpret_cast<double2 *>(W.state), reinterpret_cast<double2 *>(W.state + 2 * nsk * G)};
     const double *fs[2] = {W.f1, W.f2};
     double *h_err = reinterpret_cast<double *>(ctx->h_state);        // pinned, >= OCC_MAX_GROUP doubles
     double *d_err = W.part + (size_t) OCC_ERR_BLOCKS * G;
@@ -1173,7 +1192,7 @@ int occ_single_scale_dev(ofx_ctx *ctx, int G, const double *I_1, const double *I
             hipLaunchKernelGGL(k_occ_u_init, grid, block, 0, st, (const double *) W.v1, (const double *) W.v2, (const double *) chi,
                                W.f1, W.f2, u1, u2, nx, ny, P.theta, P.beta, grp);
             OFX_LAUNCH_CHECK(ctx);
-            OFX_TRY(rof_box_dev(ctx, 2, us, fs, ps, pe, W.g, P.theta, OCC_OMEGA, nx, ny, OCC_MAX_ITERATIONS_U, W.rof, G, active));
+            OFX_TRY(rof_box_dev(ctx, 2, us, fs, pps, W.g, P.theta, OCC_OMEGA, nx, ny, OCC_MAX_ITERATIONS_U, W.rof, G, active));
             hipLaunchKernelGGL(k_median3_pair, dim3(grid.x, grid.y, 2 * G), block, 0, st, (const double *) u1, (const double *) u2, W.t1,
                                W.t2, nx, ny, n, active);
             hipLaunchKernelGGL(k_occ_copy2, g1, dim3(256), 0, st, (const double *) W.t1, (const double *) W.t2, u1, u2, (int) n, grp);
