@@ -22,7 +22,7 @@ own stream) while round r + 1 computes, so only the last round's transfer is exp
 The line also carries: `fixed_work` (option "fixed_work": every warp runs exactly 300 iterations, SURVEY 8d);
 `roofline` / `roofline_4k` for the dominant kernel k_tvl1_iter2 as the job launches it (one launch = a lockstep group of
 up to 16 pairs), measured on fixed-work passes with HIP events on the library's own stream, with the one-pair launch beside
-it (`single_pair`); `sor` (BASELINE configs 3 / 4: exact Horn-Schunck and Brox solves); `cpu_baseline` (the compiled
+it (`single_pair`); `sor` (BASELINE configs 3 / 4: exact Horn-Schunck and Brox solves); `occ` (TV-L1 with occlusions); `cpu_baseline` (the compiled
 reference, oracle/_ref, on the host cores; rank 0 at N = 1 only).
 """
 import argparse
@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-4k", action="store_true", help="skip the roofline_4k leg")
     ap.add_argument("--no-sor", action="store_true", help="skip the sor leg (BASELINE configs 3 / 4)")
+    ap.add_argument("--no-occ", action="store_true", help="skip the occ leg (TV-L1 with occlusions, SURVEY 8f.1)")
     ap.add_argument("--lockstep", type=int, default=0,
                     help="pairs per lockstep group (they share every kernel launch of one context); 0 = the library's choice")
     ap.add_argument("--concurrency", type=int, default=0, help="override the library's concurrency hint (0 = streams)")
@@ -331,6 +332,36 @@ def sor_leg(ofx_mod, synth, local, dev):
     return out
 
 
+def occ_leg(ofx_mod, synth, local):
+    """SURVEY 8(f)1 (next row, not the headline): TV-L1 with occlusions, 640x480 triples of the synthetic sequence with the
+    reference's defaults (5 levels, 2 warps).  `one_triple`: one solve through the host entry point; `batch`: 32 triples in
+    lockstep groups of 16 on 2 contexts (host arrays in / out, so uploads and downloads are inside).  work = outer iterations x
+    pixels, as the reference's verbose line counts them; every result is bit-identical to the reference on a zero-filled heap
+    (tests/test_gpu_occ.py, tests/test_gpu_golden_cli.py)."""
+    nx, ny, ns, NB = 640, 480, 5, 32
+    kw = dict(lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=ns, zfactor=0.5, warps=2, epsilon=0.01)
+    solo = ofx_mod.Ofx(local, ofx_mod.F64)
+    ctxs = [ofx_mod.Ofx(local, ofx_mod.F64) for _ in range(2)]
+    seq = synth.sequence(nx, ny, 3, 1)
+    solo.tvl1occ_multiscale(seq[0], seq[1], seq[2], **dict(kw, nscales=1, warps=1))      # warm (arena, clocks)
+    t0 = time.perf_counter()
+    solo.tvl1occ_multiscale(seq[0], seq[1], seq[2], **kw)
+    dt1 = time.perf_counter() - t0
+    st = solo.stats()
+    triples = [tuple(synth.sequence(nx, ny, 3, k + 1)) for k in range(NB)]
+    ofx_mod.tvl1occ_batch(ctxs, triples[:4], **dict(kw, nscales=1, warps=1))             # warm both contexts
+    t0 = time.perf_counter()
+    ofx_mod.tvl1occ_batch(ctxs, triples, **kw)
+    dtb = time.perf_counter() - t0
+    out = {"size": "%dx%d" % (nx, ny), "levels": ns, "warps": 2,
+           "one_triple": {"seconds": round(dt1, 4), "outer_iterations": int(st.iterations().sum()),
+                          "mpix_outer_iters_per_s": round(st.work_pix_iters / dt1 / 1e6, 1)},
+           "batch": {"seconds": round(dtb, 4), "triples": NB, "contexts": 2, "lockstep_group": 16, "ms_per_triple": round(dtb / NB * 1e3, 2)}}
+    for c in ctxs + [solo]:
+        c.close()
+    return out
+
+
 def main():
     a = parse()
     if "RANK" not in os.environ and a.gpus > 1:
@@ -570,6 +601,10 @@ def main():
     if rank == 0 and world == 1 and not a.no_sor:
         sor = sor_leg(ofx_mod, synth, local, dev)
         log("sor leg done")
+    occ = None
+    if rank == 0 and world == 1 and not a.no_occ:
+        occ = occ_leg(ofx_mod, synth, local)
+        log("occ leg done")
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cnx, cny = WORKLOADS["1080p"] if strong else (nx, ny)
@@ -617,6 +652,8 @@ def main():
         line["roofline_4k"] = roof4k
     if sor:
         line["sor"] = sor
+    if occ:
+        line["occ"] = occ
     if cpu:
         line["cpu_baseline"] = cpu
     print(json.dumps(line))

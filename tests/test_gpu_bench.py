@@ -10,7 +10,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--nx", "320", "--ny", "240", "--no-cpu", "--no-4k", "--no-sor", "--fixed-steps", "1", "--warmup", "1"]
+SMALL = ["--nx", "320", "--ny", "240", "--no-cpu", "--no-4k", "--no-sor", "--no-occ", "--fixed-steps", "1", "--warmup", "1"]
 
 
 def run_bench(args, timeout=600):

@@ -9,12 +9,12 @@ mkdir -p $OUT
 cd $R
 timeout -k 10 400 python bench.py --steps 64 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 # BASELINE config 5 size (3840x2160) and the f32 fast mode, same command otherwise
-timeout -k 10 400 python bench.py --steps 16 --warmup 1 --nx 3840 --ny 2160 --no-cpu --no-sor --no-4k > $OUT/bench_4k.json 2> $OUT/bench_4k.err
-timeout -k 10 400 python bench.py --steps 64 --warmup 2 --precision f32 --no-cpu --no-sor --no-4k > $OUT/bench_f32.json 2> $OUT/bench_f32.err
-timeout -k 10 400 python bench.py --steps 16 --warmup 1 --nx 3840 --ny 2160 --precision f32 --no-cpu --no-sor --no-4k > $OUT/bench_4k_f32.json 2> $OUT/bench_4k_f32.err
+timeout -k 10 400 python bench.py --steps 16 --warmup 1 --nx 3840 --ny 2160 --no-cpu --no-sor --no-occ --no-4k > $OUT/bench_4k.json 2> $OUT/bench_4k.err
+timeout -k 10 400 python bench.py --steps 64 --warmup 2 --precision f32 --no-cpu --no-sor --no-occ --no-4k > $OUT/bench_f32.json 2> $OUT/bench_f32.err
+timeout -k 10 400 python bench.py --steps 16 --warmup 1 --nx 3840 --ny 2160 --precision f32 --no-cpu --no-sor --no-occ --no-4k > $OUT/bench_4k_f32.json 2> $OUT/bench_4k_f32.err
 cd /tmp && export TMPDIR=/tmp
 # kernel trace + stats of the SAME command (one pair in flight so that per-kernel times are not overlapped)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu --no-4k --no-sor --streams 1 --lockstep 1 > $OUT/trace.json 2> $OUT/trace.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu --no-4k --no-sor --no-occ --streams 1 --lockstep 1 > $OUT/trace.json 2> $OUT/trace.err
 # PMC passes (own runs, --kernel-trace only): HBM traffic of the dominant kernel at the bench size and at 4K
 for sz in 1920x1080 3840x2160; do
   timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$sz -- python3 $R/tools/pmc_iter.py $sz n=40 > $OUT/pmc_fetch_$sz.log 2>&1
