@@ -496,7 +496,7 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
 //   another one wrote (read up to ROF_K + 2 positions ahead, stored up to 1 step late) was written by an earlier launch,
 //   and that the rows below are still untouched by the next block.
 #ifndef ROF_VAR
-#define ROF_VAR 0                    // 1, 2, 3: timing experiments of tools/rof_variants.sh, never shipped
+#define ROF_VAR 0                    // 1 .. 5: timing experiments of tools/rof_variants.sh, never shipped
 #endif
 #define ROF_NT 128
 #define ROF_R (ROF_NT - 3)
@@ -585,6 +585,9 @@ OFX_DEV void rof_cell(const RofRing &r, int ci, int cj, double w, RofPre &pre, b
     asm volatile("" ::"v"(c_m2.y), "v"(c_m1.x), "v"(c_m1.y), "v"(c_0.x), "v"(c_0.y), "v"(c_p1.x), "v"(c_p1.y), "v"(n_m1.x), "v"(n_m1.y),
                  "v"(n_0.x), "v"(n_0.y), "v"(n_p1.x), "v"(nn_0.x), "v"(s_0.x), "v"(s_0.y), "v"(s_m1.y));
     asm volatile("" ::"v"(fe_w), "v"(fe_c), "v"(fs_n), "v"(fs_c), "v"(al_w), "v"(al_n), "v"(al), "v"(al_e), "v"(al_ne));
+#if ROF_VAR == 5                     // timing experiment: the LDS reads of a step and nothing else
+    return;
+#endif
     const bool c1 = cj >= 1, c2 = cj >= 2, r1 = ci >= 1, r2 = ci >= 2;         // does the neighbour exist (else the value is 0)
     const bool nside = top && !lef && !rig;
     double W = 0, N = 0, S = 0, E = 0;
@@ -747,7 +750,9 @@ __global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, do
     bool pre_ok = false;
     for (int q = q0; q <= q1; q++) {
         const int cj = q - 2 * ci;
+#if ROF_VAR != 4                     // 4: timing experiment, the step loop without its cells
         if (own && cj >= 0 && cj < nx) rof_cell(ring, ci, cj, w, pre, pre_ok);
+#endif
 #if ROF_VAR == 3                     // timing experiment: no barrier between the steps (results are wrong)
         __builtin_amdgcn_s_waitcnt(0xc07f);
 #else
