@@ -485,13 +485,13 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
 // * A launch works from LDS.  One thread owns one row; a workgroup first brings everything its ROF_K steps will touch into
 //   LDS -- the (Ps, Pe) pairs of positions q0 - 4 .. q1 + 2 of the skewed coordinate p = 2 ci + cj and the (Fs, Fe), alfa
 //   of positions q0 - 2 .. q1 + 1, per row -- with all loads in flight at once and shared between the three waves so that none
-//   exceeds the 63 loads a wave can have outstanding (one memory latency per launch instead of one per step), then runs its steps on LDS only: every neighbour access is an LDS access, one barrier per step, and the thread
-//   that makes the LAST update of a value (the north edge from the row below, the west edge from the next cell of the row)
-//   also stores it to global memory, without waiting for the store.  A step costs the LDS round trip plus the cell's chain
-//   of six dependent IEEE divisions.  Entries whose last update falls into a later launch (2 per row) are written back at
-//   the end.
-// * Rows are cut into blocks of ROF_R = 125, one workgroup of 128 threads each: 125 row owners + 3 threads that only bring
-//   the halo rows (two above, one below) into LDS.  Block b runs ROF_LAG steps behind block b - 1 and a launch executes
+//   exceeds the 63 loads a wave can have outstanding (one memory latency per launch instead of one per step), then runs its
+//   steps on LDS only: every neighbour access is an LDS access, one barrier per step, and the thread that makes the LAST
+//   update of a value (the north edge from the row below, the west edge from the next cell of the row) also stores it to
+//   global memory, without waiting for the store.  Entries whose last update falls into a later launch (2 per row) are
+//   written back at the end.  Where a step's time goes: profiles/r02_k_rof_window_breakdown.txt.
+// * Rows are cut into blocks of ROF_R = 125, one workgroup each: 128 columns of LDS = 125 own rows + 3 halo rows (two above,
+//   one below), walked by 128 threads, plus a third wave for the image's first / last row (see the kernel).  Block b runs ROF_LAG steps behind block b - 1 and a launch executes
 //   ROF_K steps of every block; ROF_LAG = ROF_K + 8 guarantees that whatever a workgroup takes from global memory that
 //   another one wrote (read up to ROF_K + 2 positions ahead, stored up to 1 step late) was written by an earlier launch,
 //   and that the rows below are still untouched by the next block.
