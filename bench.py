@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="pairs per rank (1080p, default 64) / pairs of the batch (4k-batch, default 64)")
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="repetitions of the timed K-step region (each one bracketed by barrier + sync); the median one is reported")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--nx", type=int, default=0, help="override the workload's image width (tests / rehearsals)")
@@ -58,6 +60,7 @@ def parse():
     ap.add_argument("--fixed-steps", type=int, default=2, help="fixed-work passes for the roofline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-4k", action="store_true", help="skip the roofline_4k leg")
+    ap.add_argument("--no-single", action="store_true", help="skip the single_pair leg (one pair at a time, device-resident and host entry)")
     ap.add_argument("--no-sor", action="store_true", help="skip the sor leg (BASELINE configs 3 / 4)")
     ap.add_argument("--no-occ", action="store_true", help="skip the occ leg (TV-L1 with occlusions, SURVEY 8f.1)")
     ap.add_argument("--lockstep", type=int, default=0,
@@ -482,22 +485,49 @@ def main():
     if world > 1:
         # one throw-away gather: RCCL sets up its channels on first use, which is not part of the steady state
         w_ = dist.gather(flo[:1], [torch.empty_like(flo[:1]) for _ in range(world)] if rank == 0 else None, dst=0)
-    fence()
-    t0 = time.perf_counter()
-    work, pending = 0.0, []
-    for r, (first, cnt) in enumerate(rounds):
-        work += run_pairs(first, min(cnt, nsteps - first))   # returns with the round's flows complete in HBM
-        if world > 1:
-            # strong scaling: a rank may own one pair fewer than `slots`; the gather buffers have the same size on
-            # every rank (rounds are cut from the slot count), rank 0 ignores the unused tail slots
-            pending.append(dist.gather(flo[first:first + cnt], gathered[r] if rank == 0 else None, dst=0, async_op=True))
-    t_compute = time.perf_counter() - t0
-    for w_ in pending:
-        w_.wait()
-    fence()
-    elapsed = time.perf_counter() - t0
-    gather_ms = (elapsed - t_compute) * 1e3
-    log("timed region: %d pairs in %.3f s (exposed gather %.2f ms)" % (nsteps, elapsed, gather_ms))
+    mark = None
+    if os.environ.get("OFX_BENCH_MARK"):
+        # tools/trace_budget.py finds the timed repetitions in a rocprofv3 kernel trace between two fills of this 7777-element
+        # tensor (profiling runs only; the driver's command does not set the variable)
+        mark = torch.empty(7777, dtype=torch.float32, device=dev)
+        mark.fill_(1.0)
+        torch.cuda.synchronize()
+
+    def timed_region():
+        """EXACTLY the K steps of the command, bracketed by barrier + device sync on both sides."""
+        fence()
+        t0 = time.perf_counter()
+        work, pending = 0.0, []
+        for r, (first, cnt) in enumerate(rounds):
+            work += run_pairs(first, min(cnt, nsteps - first))   # returns with the round's flows complete in HBM
+            if world > 1:
+                # strong scaling: a rank may own one pair fewer than `slots`; the gather buffers have the same size on
+                # every rank (rounds are cut from the slot count), rank 0 ignores the unused tail slots
+                pending.append(dist.gather(flo[first:first + cnt], gathered[r] if rank == 0 else None, dst=0, async_op=True))
+        t_compute = time.perf_counter() - t0
+        for w_ in pending:
+            w_.wait()
+        fence()
+        el = time.perf_counter() - t0
+        return el, (el - t_compute) * 1e3, work
+
+    # The region is short (20 pairs = 57 ms), so it is repeated and the MEDIAN repetition is reported (`value`,
+    # `ms_per_step`, `gather_ms` all from that one repetition); the spread goes into `repetitions`.
+    reps = [timed_region() for _ in range(max(1, a.reps))]
+    if world > 1:
+        t = torch.tensor([r_[0] for r_ in reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                # a repetition takes as long as its slowest rank
+        rep_s = [float(x) for x in t.tolist()]
+    else:
+        rep_s = [r_[0] for r_ in reps]
+    order = sorted(range(len(reps)), key=lambda i: rep_s[i])
+    mid = order[(len(order) - 1) // 2]                          # lower median: an actually measured repetition
+    elapsed, gather_ms, work = rep_s[mid], reps[mid][1], reps[mid][2]
+    if mark is not None:
+        mark.fill_(2.0)
+        torch.cuda.synchronize()
+    log("timed region: %d pairs, %d repetitions %s s -> median %.4f s (exposed gather %.2f ms)"
+        % (nsteps, len(reps), [round(x, 4) for x in rep_s], elapsed, gather_ms))
 
     gather_check = None
     if a.check and world > 1 and rank == 0:
@@ -522,11 +552,11 @@ def main():
         gather_check = "ok: %d payloads from %d ranks byte-identical to rank 0's own solves" % (n_checked, world)
         log("gather check " + gather_check)
     if world > 1:
-        t = torch.tensor([elapsed, gather_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([gather_ms], dtype=torch.float64, device=dev)
         w = torch.tensor([work], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
-        elapsed, gather_ms, work = float(t[0].item()), float(t[1].item()), float(w.item())
+        gather_ms, work = float(t[0].item()), float(w.item())
 
     # how the loops of this workload end (one lockstep group, untimed): a loop that stops on the first iteration of a
     # fused pair continues from the stored intermediate state (option store_a) or recomputes that iteration
@@ -538,6 +568,42 @@ def main():
         ctx.synchronize()
         odd = {"loops": gsz * PAR["nscales"] * PAR["warps"], "odd_stops": sum(s_.odd_stops for s_ in st_),
                "served_from_stored_state": sum(s_.odd_stops_stored for s_ in st_)}
+
+    # ---- one pair at a time (BASELINE configs[0] / [1] read literally: what bin/tvl1flow runs) ---------------------------
+    single = None
+    if rank == 0 and nsteps > 0 and not a.no_single:
+        ctx.set_option("concurrency", 1)
+        npair = min(nvar, 8)
+        ctx.tvl1_multiscale_dev(dI0s[0].data_ptr(), dI1s[0].data_ptr(), flo[0].data_ptr(), nx, ny, **PAR)    # warm
+        ctx.synchronize()
+        w1, ts = 0.0, []
+        for k in range(npair):
+            tq0 = time.perf_counter()
+            ctx.tvl1_multiscale_dev(dI0s[k].data_ptr(), dI1s[k].data_ptr(), flo[0].data_ptr(), nx, ny, **PAR)
+            ctx.synchronize()
+            ts.append(time.perf_counter() - tq0)
+            w1 += ctx.stats().work_pix_iters
+        single = {"device_resident": {"value": round(w1 / sum(ts) / 1e6, 1), "unit": "Mpix*warp-iters/s",
+                                      "ms_per_pair": round(sum(ts) / npair * 1e3, 3), "pairs": npair,
+                                      "note": "ofx_tvl1_multiscale_dev, one pair in flight, epsilon = 0.01, inputs and .flo payload in HBM"}}
+        # the host entry point (host double planes in, host double planes out -- the reference's calling convention):
+        # PCIe and the host-side staging are inside; never part of `value`
+        hp = [(dI0s[k].double().cpu().numpy(), dI1s[k].double().cpu().numpy()) for k in range(min(npair, 4))]
+        ctx.tvl1_multiscale(hp[0][0], hp[0][1], **PAR)                                                       # warm (pinned staging)
+        w2, th = 0.0, []
+        for I0_, I1_ in hp:
+            tq0 = time.perf_counter()
+            ctx.tvl1_multiscale(I0_, I1_, **PAR)
+            th.append(time.perf_counter() - tq0)
+            w2 += ctx.stats().work_pix_iters
+        single["host_entry"] = {"value": round(w2 / sum(th) / 1e6, 1), "unit": "Mpix*warp-iters/s",
+                                "ms_per_pair": round(sum(th) / len(hp) * 1e3, 3), "pairs": len(hp),
+                                "note": "ofx_tvl1_multiscale, host arrays in / out (2 x %.1f MB up, 2 x %.1f MB down over PCIe)"
+                                        % (nx * ny * 8 / 1e6, nx * ny * 8 / 1e6)}
+        ctx.set_option("concurrency", a.concurrency or nstreams)
+        del hp
+        log("single-pair leg: device-resident %.3f ms, host entry %.3f ms per pair"
+            % (single["device_resident"]["ms_per_pair"], single["host_entry"]["ms_per_pair"]))
 
     # ---- fixed-work pass + roofline (rank 0's numbers are reported; every rank runs it to stay in step) ----
     fixed, roof, roof4k = None, None, None
@@ -640,6 +706,12 @@ def main():
         "pairs_per_s": round(npairs_job / elapsed, 3),
         "gather_ms": round(gather_ms, 3) if world > 1 else 0.0,
     }
+    vals = [work / x / 1e6 for x in rep_s]
+    line["repetitions"] = {"n": len(rep_s), "seconds": [round(x, 5) for x in rep_s], "reported": "median repetition",
+                           "value_min": round(min(vals), 1), "value_max": round(max(vals), 1),
+                           "spread_pct": round(100.0 * (max(vals) - min(vals)) / max(min(vals), 1e-9), 2)}
+    if single:
+        line["single_pair"] = single
     if odd:
         line["loop_ends"] = odd
     if gather_check:

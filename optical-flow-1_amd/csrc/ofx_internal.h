@@ -60,6 +60,8 @@ struct ofx_ctx {
     int concurrency;    // contexts expected to share the device (tuning hint, default 1)
     int lockstep;       // pairs per lockstep group in ofx_tvl1_batch_dev (0 = default)
     int nt_stores;      // fused TV-L1 kernel: 0 (default) non-temporal stores once a launch's working set exceeds the Infinity Cache, 1 always, 2 never
+    int relaxed_dual;   // TV-L1 in double storage: 1 = the fast mode's dual stage (sqrt(x^2 + y^2), one reciprocal per denominator) --
+                        // the "tolerance" mode, AEPE vs the reference ~1e-9..1e-6, not bit-identical; 0 (default) strict
     int warp_lds;       // 1 (default): TV-L1 warp with the taps staged through LDS; 0: gathered from global memory
     int chunk;
     int fixed_work;

@@ -134,7 +134,8 @@ OFX_DEV double div_by_rcp(double n, double d, double r)
 // the double arithmetic buys nothing; hypot is sqrt(x*x + y*y) and each denominator is inverted once
 // (2 divisions instead of 6 per pixel).  This stage is ~60 % of the kernel's VALU work, and the kernel is
 // VALU-bound, so the fast mode runs ~1.5x faster; AEPE vs the double reference stays ~1e-5 (tests).
-template <typename T>
+// STRICT = false with T = double is the "tolerance" mode (option "relaxed_dual"): double storage, the fast mode's dual stage.
+template <typename T, bool STRICT>
 OFX_DEV void tvl1_dual(double2 p1, double2 p2, double2 un, double r1, double r2, double2 dn, bool rig, bool lastrow,
                        double taut, double2 &q1, double2 &q2)
 {
@@ -147,7 +148,7 @@ OFX_DEV void tvl1_dual(double2 p1, double2 p2, double2 un, double r1, double r2,
     const double u2x = rig ? 0.0 : r2 - un.y;
     const double u1y = lastrow ? 0.0 : dn.x - un.x;
     const double u2y = lastrow ? 0.0 : dn.y - un.y;
-    if (sizeof(T) == sizeof(double)) {
+    if (STRICT) {
         const double g1 = hypot_ref(u1x, u1y);
         const double g2 = hypot_ref(u2x, u2y);
         const double ng1 = 1.0 + taut * g1;
@@ -258,7 +259,7 @@ template <typename V> OFX_DEV TriSel<V> pick3(const Tri<V> &t, unsigned code, in
 #else
 #define OFX_ITER1_ATTR
 #endif
-template <typename T>
+template <typename T, bool STRICT>
 __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
     Tri<typename Pix<T>::v2> Ut, Tri<typename Pix<T>::v2> P1t, Tri<typename Pix<T>::v2> P2t,
     const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int check, int slot,
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
         if (y > y0) {
             const double r1 = wave_shift_down(un_prev.x);
             const double r2 = wave_shift_down(un_prev.y);
-            tvl1_dual<T>(p1_prev, p2_prev, un_prev, r1, r2, un, rig, y - 1 == ny - 1, taut, q1, q2);
+            tvl1_dual<T, STRICT>(p1_prev, p2_prev, un_prev, r1, r2, un, rig, y - 1 == ny - 1, taut, q1, q2);
             if (owner) st_p = so - row2;
         }
         // always issued; lanes / steps with nothing to write are out of the buffer's range (ofx_device.h)
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
 #define OFX_ITER2_BOUNDS __launch_bounds__(256)
 #endif
 // The marching loop of the fused kernel.  SA = true also stores the intermediate state u_A / p_A (tvl1_store_a).
-template <typename T, bool NT, bool SA>
+template <typename T, bool NT, bool SA, bool STRICT>
 OFX_DEV void tvl1_iter2_march(const typename Pix<T>::v2 *__restrict__ Uin, const typename Pix<T>::v2 *__restrict__ P1in,
                               const typename Pix<T>::v2 *__restrict__ P2in, const typename Pix<T>::v2 *__restrict__ A,
                               const T *__restrict__ R, typename Pix<T>::v2 *Uout, typename Pix<T>::v2 *P1out,
@@ -434,7 +435,7 @@ OFX_DEV void tvl1_iter2_march(const typename Pix<T>::v2 *__restrict__ Uin, const
         if (y - 1 >= ys && y - 1 <= yend && y - 1 <= ny - 1) {
             const double n1 = wave_shift_down(uA1.x);
             const double n2 = wave_shift_down(uA1.y);
-            tvl1_dual<T>(p0a, p0b, uA1, n1, n2, uA0, rig, y - 1 == ny - 1, taut, pAna, pAnb);
+            tvl1_dual<T, STRICT>(p0a, p0b, uA1, n1, n2, uA0, rig, y - 1 == ny - 1, taut, pAna, pAnb);
             pAna.x = rnd_to<T>(pAna.x); pAna.y = rnd_to<T>(pAna.y);
             pAnb.x = rnd_to<T>(pAnb.x); pAnb.y = rnd_to<T>(pAnb.y);
             if (owner && y - 1 >= y0 && y - 1 < yend) sa2 = so - row2;
@@ -456,7 +457,7 @@ OFX_DEV void tvl1_iter2_march(const typename Pix<T>::v2 *__restrict__ Uin, const
         if (y - 3 >= y0 && y - 3 < yend) {
             const double n1 = wave_shift_down(uB1.x);
             const double n2 = wave_shift_down(uB1.y);
-            tvl1_dual<T>(pA2a, pA2b, uB1, n1, n2, uB0, rig, y - 3 == ny - 1, taut, q1, q2);
+            tvl1_dual<T, STRICT>(pA2a, pA2b, uB1, n1, n2, uB0, rig, y - 3 == ny - 1, taut, q1, q2);
             if (owner) st4 = so - 3 * row2;
         }
 #ifdef OFX_CEIL_ALU   // ceiling experiment: every store dropped (still issued, out of range), loads stay on the first row
@@ -487,7 +488,7 @@ OFX_DEV void tvl1_iter2_march(const typename Pix<T>::v2 *__restrict__ Uin, const
     loop_accumulate(err, k + 1, accB, gw);
 }
 
-template <typename T, bool NT>
+template <typename T, bool NT, bool STRICT>
 __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
     Tri<typename Pix<T>::v2> Ut, Tri<typename Pix<T>::v2> P1t, Tri<typename Pix<T>::v2> P2t,
     const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int k, int nx, int ny,
@@ -542,10 +543,10 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
     if (idle) return;
     // wave-uniform (every wave of the pair reduces the same shards in the same order)
     if (((amask >> g) & 1u) || tvl1_store_a(k, e1, eps2, afac))
-        tvl1_iter2_march<T, NT, true>(Uin, P1in, P2in, A, R, hu.out, h1.out, h2.out, hu.alt, h1.alt, h2.alt, err, k, gw, nx, ny,
+        tvl1_iter2_march<T, NT, true, STRICT>(Uin, P1in, P2in, A, R, hu.out, h1.out, h2.out, hu.alt, h1.alt, h2.alt, err, k, gw, nx, ny,
                                       y0, yend, ys, yl, lef, rig, owner, off, so, up12, up22, cur, l_t, theta, taut);
     else
-        tvl1_iter2_march<T, NT, false>(Uin, P1in, P2in, A, R, hu.out, h1.out, h2.out, hu.alt, h1.alt, h2.alt, err, k, gw, nx, ny,
+        tvl1_iter2_march<T, NT, false, STRICT>(Uin, P1in, P2in, A, R, hu.out, h1.out, h2.out, hu.alt, h1.alt, h2.alt, err, k, gw, nx, ny,
                                        y0, yend, ys, yl, lef, rig, owner, off, so, up12, up22, cur, l_t, theta, taut);
 }
 
@@ -858,8 +859,12 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
     if (sa)
         for (int g = 0; g < G; g++)
             if (ctx->store_a == 2 || (L.last_n[g] >= 1 && L.last_n[g] <= 2)) amask0 |= 1u << g;
+    // strict: the reference's dual update bit for bit (double storage, option "relaxed_dual" off)
+    const bool strict = sizeof(T) == sizeof(double) && !ctx->relaxed_dual;
     auto single = [&](unsigned incode, unsigned runmask, int check, int slot, double thr) -> int {
-        hipLaunchKernelGGL(k_tvl1_iter<T>, dim3(gx1, G), block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A, (const T *) L.R,
+        auto kern = k_tvl1_iter<T, false>;
+        if constexpr (sizeof(T) == sizeof(double)) { if (strict) kern = k_tvl1_iter<T, true>; }
+        hipLaunchKernelGGL(kern, dim3(gx1, G), block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A, (const T *) L.R,
                            ctx->d_err, check, slot, nx, ny, rows, strips_x, strips_pad, l_t, theta, taut, thr, incode, runmask,
                            err_stride);
         OFX_LAUNCH_CHECK(ctx);
@@ -869,14 +874,12 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
         const unsigned incode = code_of((unsigned) (pairs ? k / 2 : k));
         if (cnt == 1) return single(incode, all, k, k, thr);
         const unsigned amask = k == 0 ? amask0 : 0u;
-        if (nt_stores)
-            hipLaunchKernelGGL((k_tvl1_iter2<T, true>), grid2, block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A,
-                               (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x, strips2_pad, l_t, theta, taut, thr,
-                               incode, amask, S.afac, err_stride);
-        else
-            hipLaunchKernelGGL((k_tvl1_iter2<T, false>), grid2, block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A,
-                               (const T *) L.R, ctx->d_err, k, nx, ny, rows2, strips2_x, strips2_pad, l_t, theta, taut, thr,
-                               incode, amask, S.afac, err_stride);
+        auto kern = nt_stores ? k_tvl1_iter2<T, true, false> : k_tvl1_iter2<T, false, false>;
+        if constexpr (sizeof(T) == sizeof(double)) {
+            if (strict) kern = nt_stores ? k_tvl1_iter2<T, true, true> : k_tvl1_iter2<T, false, true>;
+        }
+        hipLaunchKernelGGL(kern, grid2, block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A, (const T *) L.R, ctx->d_err, k, nx,
+                           ny, rows2, strips2_x, strips2_pad, l_t, theta, taut, thr, incode, amask, S.afac, err_stride);
         OFX_LAUNCH_CHECK(ctx);
         return OFX_OK;
     };

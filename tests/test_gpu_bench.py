@@ -64,3 +64,17 @@ def test_bench_4k_batch_workload_shards_pairs_over_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "strong"
     assert d["config"]["workload_name"] == "4k-batch" and d["config"]["pairs_per_gpu"] == 3
     assert d["gather_check"].startswith("ok: 5 payloads")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_4k_batch_workload_on_one_gpu_at_full_size():
+    """`bench.py --workload 4k-batch --steps 4 --gpus 1`: BASELINE config 5's size (3840x2160) on the one GPU, the launch
+    shape roofline_4k quotes (lockstep groups, non-temporal stores); the line must carry the contract keys and a roofline."""
+    d = run_bench(["--gpus", "1", "--workload", "4k-batch", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-sor", "--no-occ",
+                   "--fixed-steps", "1"])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["workload_name"] == "4k-batch" and "3840x2160" in d["config"]["workload"]
+    assert 0 < d["roofline"]["frac"] <= 1.0 and "3840x2160" in d["roofline"]["kernel"]

@@ -337,3 +337,133 @@ def test_stored_intermediate_state_equals_recomputed_iteration(gpu64, orc, synth
             assert np.array_equal(got[mode, k], np.stack([uo, vo], axis=-1).astype(np.float32)), (mode, k)
         odd += int((np.asarray(it) % 2 == 1).sum())
     assert odd > 0              # the case under test really occurs
+
+
+# ---- the launch shapes bench.py times (round 3) ---------------------------------------------------------------------
+# The fused kernel has a non-temporal-store instantiation (k_tvl1_iter2<T, true>) that the library selects once a launch's
+# working set exceeds the Infinity Cache: 1080p groups of >= 2 pairs and every 4K launch, i.e. exactly the launches of the
+# headline and of roofline_4k.  Small images never reach it on their own, so (i) the small group tests force it with option
+# nt_stores = 1, for every store_a mode, and (ii) the timed shapes themselves are checked at full size.
+@pytest.mark.parametrize("G", [1, 3, 5])
+@pytest.mark.parametrize("store_a", [0, 1, 2])
+def test_nt_store_kernel_in_small_groups_equals_oracle(gpu64, orc, synth, G, store_a):
+    import torch
+    nx, ny = 203, 131
+    pairs = [synth.pair("P0" if k % 3 == 2 else "P1", nx, ny, k) for k in range(G)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in pairs]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in pairs]
+    flo = torch.zeros((2, G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    tables = {}
+    for nt in (1, 2):                                      # 1 = always non-temporal, 2 = never
+        gpu64.set_option("nt_stores", nt)
+        gpu64.set_option("store_a", store_a)
+        try:
+            st = gpu64.tvl1_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1],
+                                      [flo[nt - 1, k].data_ptr() for k in range(G)], nx, ny, nscales=4, **PAR)
+            gpu64.synchronize()
+        finally:
+            gpu64.set_option("nt_stores", 0)
+            gpu64.set_option("store_a", 1)
+        tables[nt] = [s.iterations().copy() for s in st]
+    got = flo.cpu().numpy()
+    assert np.array_equal(got[0], got[1])
+    for k in range(G):
+        uo, vo, it, _ = orc.tvl1_multiscale(pairs[k][0], pairs[k][1], nscales=4, **PAR)
+        for nt in (1, 2):
+            assert np.array_equal(tables[nt][k], it), (nt, k)
+        assert np.array_equal(got[0, k], np.stack([uo, vo], axis=-1).astype(np.float32)), k
+
+
+def _solo_flows(gpu, d0, d1, nx, ny, **kw):
+    import torch
+    out = torch.zeros((len(d0), ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    its = []
+    for k in range(len(d0)):
+        gpu.tvl1_multiscale_dev(d0[k].data_ptr(), d1[k].data_ptr(), out[k].data_ptr(), nx, ny, **kw)
+        gpu.synchronize()
+        its.append(gpu.stats().iterations().copy())
+    return out, its
+
+
+@pytest.mark.timeout(900)
+def test_headline_launch_shape_1080p_group_of_5(gpu64, oracle_mod, synth):
+    """bench.py's driver command (`--steps 20`): 1920x1080, lockstep groups of 5 pairs, non-temporal stores selected by the
+    library itself.  Every payload equals the pair solved alone bit for bit, iteration tables too, and pair 0 equals the
+    oracle (all host cores: TV-L1 has no racy loop)."""
+    import torch
+    nx, ny, G = 1920, 1080, 5
+    kw = dict(nscales=5, warps=5, **PAR)
+    host = [synth.pair("P1", nx, ny, k) for k in range(G)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in host]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in host]
+    flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    st = gpu64.tvl1_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1], [flo[k].data_ptr() for k in range(G)],
+                              nx, ny, **kw)
+    gpu64.synchronize()
+    solo, its = _solo_flows(gpu64, d0, d1, nx, ny, **kw)
+    assert torch.equal(flo.view(torch.int32), solo.view(torch.int32))
+    for k in range(G):
+        assert np.array_equal(st[k].iterations(), its[k]), k
+    o = oracle_mod.Oracle()
+    o.set_num_threads(min(oracle_mod.host_cores(), 32))
+    try:
+        uo, vo, it_o, _ = o.tvl1_multiscale(host[0][0], host[0][1], nscales=5, **PAR)
+    finally:
+        o.set_num_threads(1)
+    assert np.array_equal(st[0].iterations(), it_o)
+    assert np.array_equal(flo[0].cpu().numpy(), np.stack([uo, vo], axis=-1).astype(np.float32))
+
+
+@pytest.mark.timeout(900)
+def test_roofline_4k_launch_shape_group_of_4(gpu64, synth):
+    """roofline_4k's launch (3840x2160, 4 pairs per launch, non-temporal stores): payloads and iteration tables equal the
+    pairs solved alone (the solo 4K solve is checked against the oracle in test_full_size_4k_warps5_matches_oracle)."""
+    import torch
+    nx, ny, G = 3840, 2160, 4
+    kw = dict(nscales=5, warps=2, **PAR)
+    dev = torch.device("cuda")
+    pairs = [synth.pair_device("P1", nx, ny, 1 + k, dev) for k in range(G)]
+    d0, d1 = [p[0] for p in pairs], [p[1] for p in pairs]
+    flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    st = gpu64.tvl1_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1], [flo[k].data_ptr() for k in range(G)],
+                              nx, ny, **kw)
+    gpu64.synchronize()
+    solo, its = _solo_flows(gpu64, d0, d1, nx, ny, **kw)
+    assert torch.equal(flo.view(torch.int32), solo.view(torch.int32))
+    for k in range(G):
+        assert np.array_equal(st[k].iterations(), its[k]), k
+
+
+@pytest.mark.timeout(900)
+def test_batch_dev_on_four_contexts_at_1080p_equals_solo(ofx_mod, gpu64, synth):
+    """ofx_tvl1_batch_dev as bench.py calls it: 10 1080p pairs (8 distinct, cycled) over 4 contexts -> groups of 3, 3, 3, 1
+    on their own streams / host threads.  Payloads equal the pairs solved alone; the work record equals the solo tables."""
+    import torch
+    nx, ny, N = 1920, 1080, 10
+    kw = dict(nscales=5, warps=5, **PAR)
+    host = [synth.pair("P1", nx, ny, k) for k in range(8)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in host]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in host]
+    flo = torch.zeros((N, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctxs = [ofx_mod.Ofx(0, ofx_mod.F64) for _ in range(4)]
+    try:
+        for c in ctxs:
+            c.set_option("concurrency", 4)
+        work = ofx_mod.tvl1_batch_dev(ctxs, [d0[i % 8].data_ptr() for i in range(N)], [d1[i % 8].data_ptr() for i in range(N)],
+                                      [flo[i].data_ptr() for i in range(N)], nx, ny, **kw)
+        for c in ctxs:
+            c.synchronize()
+    finally:
+        for c in ctxs:
+            c.close()
+    solo, its = _solo_flows(gpu64, d0, d1, nx, ny, **kw)
+    st = gpu64.stats()
+    for i in range(N):
+        assert torch.equal(flo[i].view(torch.int32), solo[i % 8].view(torch.int32)), i
+        w = sum(int(its[i % 8][s].sum()) * st.nx[s] * st.ny[s] for s in range(5))
+        assert work[i] == w, i
