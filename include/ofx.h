@@ -213,6 +213,11 @@ int ofx_tvl1_iterations(ofx_ctx *ctx, double *u1, double *u2, double *p11, doubl
                         int nx, int ny, double tau, double lambda, double theta, int n_iter,
                         double *error);
 
+/* libm's hypot as the TV-L1 dual update calls it (src/tvl1flow.cpp:172-173), n independent evaluations on the device:
+ * out[k] = hypot(x[k], y[k]) with the operation sequence of glibc >= 2.35, bit-identical to it over the whole
+ * double range.  An operator entry for direct parity tests of the one libm function on the path. */
+int ofx_hypot(ofx_ctx *ctx, const double *x, const double *y, double *out, int n);
+
 /* ---- Horn-Schunck pyramidal (replace src/horn_schunck.h:15-48) --------------------------------*/
 int ofx_hs_single_scale(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v,
                         int nx, int ny, double alpha, int warps, double TOL, int maxiter, int verbose);

@@ -92,6 +92,7 @@ def lib():
         "ofx_dxy": (_i, [_vp, _dp, _dp, _i, _i]),
         "ofx_gaussian": (_i, [_vp, _dp, _i, _i, _d]),
         "ofx_bicubic_at": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _i]),
+        "ofx_hypot": (_i, [_vp, _dp, _dp, _dp, _i]),
         "ofx_bicubic_warp": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i]),
         "ofx_zoom_size": (None, [_i, _i, C.POINTER(_i), C.POINTER(_i), _d]),
         "ofx_zoom_out": (_i, [_vp, _dp, _dp, _i, _i, _d]),
@@ -300,6 +301,12 @@ class Ofx:
         uu, vv = _f64(np.atleast_1d(uu)), _f64(np.atleast_1d(vv))
         out = np.empty(uu.shape)
         self._ck(self.L.ofx_bicubic_at(self.h, _f64(I), uu, vv, out, uu.size, nx, ny, int(border_out)))
+        return out
+
+    def hypot(self, x, y):
+        x, y = _f64(np.atleast_1d(x)).ravel(), _f64(np.atleast_1d(y)).ravel()
+        out = np.empty(x.shape)
+        self._ck(self.L.ofx_hypot(self.h, x, y, out, x.size))
         return out
 
     def bicubic_warp(self, I, u, v, border_out=False):

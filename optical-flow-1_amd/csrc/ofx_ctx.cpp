@@ -71,6 +71,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->relaxed_dual = 0;
     ctx->nt_stores = 0;
     ctx->chunk = 0;             // 0 = pick per level
+    ctx->spin_us = 150;
     ctx->fixed_work = 0;
     ctx->sor_exact = 1;
     ctx->sor_batch = 0;
@@ -195,6 +196,11 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "store_a")) {
         if (value != 0 && value != 1 && value != 2) return ofx_fail(ctx, OFX_ERR_ARG, "store_a must be 0, 1 or 2");
         ctx->store_a = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "spin_us")) {
+        if (value < 0 || value > 1e6) return ofx_fail(ctx, OFX_ERR_ARG, "spin_us out of range");
+        ctx->spin_us = (int) value;
         return OFX_OK;
     }
     if (!strcmp(name, "chunk")) {

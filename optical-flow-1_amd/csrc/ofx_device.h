@@ -169,6 +169,54 @@ OFX_DEV double hypot_kernel(double ax, double ay)
     return h;
 }
 
+// The compiler's own expansions of the f64 square root and quotient WITHOUT their range scaling (v_ldexp of tiny arguments
+// around the rsq iteration; v_div_scale / v_div_fmas / v_div_fixup around the rcp iteration): the same instruction
+// sequence, hence the same bits, wherever that scaling is the identity -- x in [2^-767, 2^1023]; numerator 0 or of
+// magnitude >= 2^-968 with a normal quotient, denominator in [2^-1000, 2^1000], and the sign of a zero quotient not needed.
+OFX_DEV double sqrt_unscaled(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+OFX_DEV double div_unscaled(double n, double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = n * r;
+    const double rem = __builtin_fma(-d, q, n);
+    return __builtin_fma(rem, r, q);
+}
+// hypot_kernel on the common domain ax <= 2^511, ay >= 2^-383 (checked by the caller): ax^2 + ay^2 lies in [2^-766, 2^1023],
+// h in [2^-383, 2^512]; the correction's numerator t1 + t2 is an exact-product residue, 0 or >= 2^-105 h^2 >= 2^-871 in
+// magnitude, its quotient by 2 h is normal, and h - (+-0) = h either way -- so both unscaled expansions apply.
+OFX_DEV double hypot_kernel_common(double ax, double ay)
+{
+    double h = sqrt_unscaled(ax * ax + ay * ay);
+    double t1, t2;
+    if (h <= 2.0 * ay) {
+        const double delta = h - ay;
+        t1 = ax * (2.0 * delta - ax);
+        t2 = (delta - 2.0 * (ax - ay)) * delta;
+    } else {
+        const double delta = h - ax;
+        t1 = 2.0 * delta * (ax - 2.0 * ay);
+        t2 = (4.0 * delta - ay) * ay + delta * delta;
+    }
+    h -= div_unscaled(t1 + t2, 2.0 * h);
+    return h;
+}
+
 OFX_DEV double hypot_ref(double x, double y)
 {
     x = fabs(x);
@@ -176,6 +224,14 @@ OFX_DEV double hypot_ref(double x, double y)
     const double ax = x < y ? y : x;
     const double ay = x < y ? x : y;
     const double SCALE = 0x1p-600, LARGE = 0x1p+511, TINY = 0x1p-459, EPS = 0x1p-54;
+#ifndef OFX_HYPOT_GENERAL_ONLY
+    // The common domain first (flow gradients are never 1e-115 or 1e153): there the general code below takes neither
+    // scaling branch and reduces to exactly these two lines.  Everything else -- zeros included -- goes the general way.
+    if (ax <= LARGE && ay >= 0x1p-383) {
+        if (ax >= ay / EPS) return ax + ay;
+        return hypot_kernel_common(ax, ay);
+    }
+#endif
     if (ax > LARGE) {
         if (ay <= ax * EPS) return ax + ay;
         return hypot_kernel(ax * SCALE, ay * SCALE) / SCALE;

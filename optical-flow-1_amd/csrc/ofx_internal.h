@@ -23,7 +23,8 @@ struct OfxIterState {
     double error;    // value of the stopping criterion after iteration n
     int    apred;    // TV-L1 fused pairs: n is odd and the launch that ran iteration n - 1 had predicted the stop and
                      // stored its intermediate state (tvl1_store_a in ofx_tvl1.hip, same formula)
-    int    pad_;
+    int    seq;      // host copy only: written LAST (after a system-scope fence) with the poll's sequence number, so the host
+                     // can spin on it instead of sleeping in hipEventSynchronize (0 = not published yet)
 };
 
 struct OfxSlab {
@@ -64,6 +65,8 @@ struct ofx_ctx {
                         // the "tolerance" mode, AEPE vs the reference ~1e-9..1e-6, not bit-identical; 0 (default) strict
     int warp_lds;       // 1 (default): TV-L1 warp with the taps staged through LDS; 0: gathered from global memory
     int chunk;
+    int spin_us;        // convergence polls: microseconds the host spins on the pinned record before it falls back to
+                        // hipEventSynchronize (default 150; 0 = never spin)
     int fixed_work;
     int sor_exact;      // 1: reference sweep order, windowed launches; 2: same, one launch per time step; 0: colour order
     int sor_batch;      // sweeps in flight per batch in exact mode (0 = default)

@@ -58,12 +58,11 @@ struct LoopSpec {
 
 int ofx_loop_reserve(ofx_ctx *ctx, int max_iter);                      // err slots for max_iter sweeps
 // G problems in lockstep: problem g owns err slots [g * slots_per_problem, ...) and state entry g.
+// seq: number the records carry when they are complete (never 0); ofx_loop_wait_poll(slot, G, seq) waits for them
 int ofx_loop_finalize_group(ofx_ctx *ctx, const LoopSpec &L, int G, int slots_per_problem, int start, int launched,
-                            OfxIterState *host_slot);
-static inline int ofx_loop_finalize(ofx_ctx *ctx, const LoopSpec &L, int start, int launched, OfxIterState *host_slot)
-{
-    return ofx_loop_finalize_group(ctx, L, 1, 0, start, launched, host_slot);
-}
+                            OfxIterState *host_slot, int seq);
+int ofx_loop_wait_poll(ofx_ctx *ctx, int slot, int G, int seq);
+static inline int ofx_poll_seq(const ofx_ctx *ctx) { return (int) (ctx->poll_seq & 0x3FFFFFFF) + 1; }
 
 // Runs the loop for G independent problems of the same size in LOCKSTEP (TV-L1: G image pairs solved by
 // the same launches, blockIdx.y = problem; the SOR solvers use G = 1).  Problem g accumulates into err slots
@@ -112,7 +111,7 @@ static int ofx_run_loop_group_impl(ofx_ctx *ctx, const LoopSpec &L, int G, Launc
     // other contexts share the device (option "concurrency" > 1) their work fills such gaps, so nothing is
     // launched speculatively: one outstanding poll.
     const int max_out = ctx->concurrency > 1 ? 1 : 2;
-    int launched = 0, head = 0, tail = 0, slot_of[2] = {0, 0};
+    int launched = 0, head = 0, tail = 0, slot_of[2] = {0, 0}, seq_of[2] = {0, 0};
     bool stop = false;
     OfxIterState fin[OFX_MAX_GROUP];
     int chunk = S.chunk < 1 ? 1 : S.chunk;
@@ -126,15 +125,17 @@ static int ofx_run_loop_group_impl(ofx_ctx *ctx, const LoopSpec &L, int G, Launc
                 OFX_TRY(launch(launched, cnt, S.thr));
                 launched += cnt;
             }
+            const int seq = ofx_poll_seq(ctx);
             const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
-            OFX_TRY(ofx_loop_finalize_group(ctx, S, G, per, first, launched, &ctx->h_state[slot * OFX_MAX_GROUP]));
+            OFX_TRY(ofx_loop_finalize_group(ctx, S, G, per, first, launched, &ctx->h_state[slot * OFX_MAX_GROUP], seq));
             slot_of[head & 1] = slot;
+            seq_of[head & 1] = seq;
             OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
             head++;
         }
         if (tail == head) break;
         const int slot = slot_of[tail & 1];
-        OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
+        OFX_TRY(ofx_loop_wait_poll(ctx, slot, G, seq_of[tail & 1]));
         bool all = true;
         for (int g = 0; g < G; g++) {
             fin[g] = ctx->h_state[slot * OFX_MAX_GROUP + g];

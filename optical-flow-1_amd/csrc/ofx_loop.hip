@@ -6,14 +6,21 @@
 // value at exit.
 __global__ __launch_bounds__(1024) void k_loop_finalize(const double *__restrict__ err, int slots_per_problem, int start,
                                                         int launched, int max_iter, int size, double thr, int crit,
-                                                        double afac, OfxIterState *st, OfxIterState *host_st)
+                                                        double afac, OfxIterState *st, OfxIterState *host_st, int seq)
 {
     extern __shared__ double s_err[];
     err += (size_t) blockIdx.x * slots_per_problem * OFX_NSHARD;
     st += blockIdx.x;
     host_st += blockIdx.x;
     if (st->done) {                                         // an earlier chunk already ended the loop
-        if (threadIdx.x == 0) *host_st = *st;
+        if (threadIdx.x == 0) {
+            host_st->n = st->n;
+            host_st->error = st->error;
+            host_st->apred = st->apred;
+            host_st->done = st->done;
+            __threadfence_system();                         // the record before its sequence number (the host may be spinning on it)
+            __hip_atomic_store(&host_st->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -40,20 +47,22 @@ __global__ __launch_bounds__(1024) void k_loop_finalize(const double *__restrict
             st->done = done;
             st->error = error;
             st->apred = apred;
-            host_st->n = n;                                 // pinned host memory: visible once the kernel retires
+            host_st->n = n;                                 // pinned host memory: visible once the kernel retires ...
             host_st->error = error;
             host_st->apred = apred;
             host_st->done = done;
+            __threadfence_system();                         // ... and, for a host that spins on `seq`, as soon as seq is
+            __hip_atomic_store(&host_st->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
 int ofx_loop_finalize_group(ofx_ctx *ctx, const LoopSpec &L, int G, int slots_per_problem, int start, int launched,
-                            OfxIterState *host_slot)
+                            OfxIterState *host_slot, int seq)
 {
     const size_t shmem = sizeof(double) * (size_t) (launched - start);
     hipLaunchKernelGGL(k_loop_finalize, dim3(G), dim3(1024), shmem, ctx->stream, (const double *) ctx->d_err,
-                       slots_per_problem, start, launched, L.max_iter, L.size, L.thr, L.crit, L.afac, ctx->d_state, host_slot);
+                       slots_per_problem, start, launched, L.max_iter, L.size, L.thr, L.crit, L.afac, ctx->d_state, host_slot, seq);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
     return OFX_OK;
@@ -68,5 +77,27 @@ int ofx_loop_reserve(ofx_ctx *ctx, int max_iter)
     ctx->d_err_cap = 0;
     OFX_HIP(ctx, hipMalloc((void **) &ctx->d_err, sizeof(double) * (size_t) max_iter * OFX_NSHARD));
     ctx->d_err_cap = max_iter;
+    return OFX_OK;
+}
+
+// Wait for the poll record of `slot` (G problems) that finalize launch number `seq` publishes.  The host first spins on the
+// records' sequence numbers in pinned memory -- the finalize kernel writes them last, behind a system-scope fence, so a
+// record whose number is there is complete -- for at most ctx->spin_us microseconds: that sees the result ~2 us after
+// the kernel wrote it, where hipEventSynchronize needs 20-40 us to wake the thread.  A chunk that takes longer than that is
+// long enough for the wake-up not to matter: fall back to the event.
+int ofx_loop_wait_poll(ofx_ctx *ctx, int slot, int G, int seq)
+{
+    if (ctx->spin_us > 0) {
+        const double t_end = ofx_now_ms() + ctx->spin_us * 1e-3;
+        volatile OfxIterState *rec = ctx->h_state + (size_t) slot * OFX_MAX_GROUP;
+        for (int spins = 0;; spins++) {
+            bool all = true;
+            for (int g = 0; g < G && all; g++) all = __atomic_load_n((const int *) &rec[g].seq, __ATOMIC_ACQUIRE) == seq;
+            if (all) return OFX_OK;
+            if ((spins & 63) == 63 && ofx_now_ms() > t_end) break;
+            __builtin_ia32_pause();
+        }
+    }
+    OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
     return OFX_OK;
 }

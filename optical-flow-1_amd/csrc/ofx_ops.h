@@ -62,7 +62,7 @@ template <typename T> int op_minmax(ofx_ctx *ctx, const T *x, int size, double *
 
 // pa = (f, centred dx) pairs, pb = centred dy: one pair gather + one scalar gather per bicubic tap serve the
 // three warps of (f, fx, fy) (see bicubic_sample3 in ofx_device.h for why not one padded 4-vector)
-template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v2 *pa, T *pb, int nx, int ny);
+template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v2 *pa, T *pb, int nx, int ny, int G = 1);
 
 // Shared pyramid prologue (src/tvl1flow.cpp:236-280 == horn_schunck_pyramidal.cpp:279-323 ==
 // brox_optic_flow_spatial.cpp:467-509): joint normalisation, presmoothing, zoom_out chain.
@@ -80,6 +80,17 @@ size_t op_pyramid_scratch_doubles();
 template <typename T>
 int op_build_pyramid_into(ofx_ctx *ctx, const T *dA, const T *dB, int nscales, double zfactor, double presmooth_sigma,
                           const std::vector<ImgLevel<T>> &lv, T *tmpA, T *tmpB, double *scr);
+
+// device pointers of the caller's G image pairs, passed to kernels by value
+struct OfxGroupPtrs {
+    const void *a[OFX_MAX_GROUP];
+    const void *b[OFX_MAX_GROUP];
+};
+// pyramids of the G pairs of a lockstep group, one launch per step for all 2 G images (see ofx_ops.hip)
+template <typename T>
+int op_build_pyramid_group(ofx_ctx *ctx, int G, const void *const *dA, const void *const *dB, int nscales, double zfactor,
+                           double presmooth_sigma, const int *nxs, const int *nys, T *const *lvA, T *const *lvB, T *tmpA,
+                           T *tmpB, double *scr);
 
 #define OFX_LAUNCH_CHECK(ctx)                                                                    \
     do {                                                                                         \

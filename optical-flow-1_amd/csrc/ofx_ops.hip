@@ -104,9 +104,9 @@ template <typename T> int op_fill2(ofx_ctx *ctx, typename Pix<T>::v2 *dst, size_
 // ---- image_normalization_2 (src/utils.cpp:283-326, getminmax :509-525) -----------------------------
 // min/max are exact (order-independent); two-stage reduction: per-block partials, then one block.
 #define MM_BLOCKS 1024
+#define MM_SCR (2 * MM_BLOCKS + 2)      // doubles of scratch per (pair of) image(s): partial minima, partial maxima, {min, max}
 template <typename T>
-__global__ void k_minmax_partial(const T *__restrict__ I1, const T *__restrict__ I2, int size,
-                                 double *__restrict__ part /* [2][MM_BLOCKS] */)
+OFX_DEV void minmax_partial_block(const T *__restrict__ I1, const T *__restrict__ I2, int size, double *__restrict__ part)
 {
     double lo = ldw(I1), hi = lo;
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < (size_t) size;
@@ -127,8 +127,7 @@ __global__ void k_minmax_partial(const T *__restrict__ I1, const T *__restrict__
         part[MM_BLOCKS + blockIdx.x] = hi;
     }
 }
-
-__global__ void k_minmax_final(const double *__restrict__ part, int nblocks, double *__restrict__ mm)
+OFX_DEV void minmax_final_block(const double *__restrict__ part, int nblocks, double *__restrict__ mm)
 {
     double lo = part[0], hi = part[MM_BLOCKS];
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
@@ -147,10 +146,9 @@ __global__ void k_minmax_final(const double *__restrict__ part, int nblocks, dou
         mm[1] = hi;
     }
 }
-
 template <typename T>
-__global__ void k_normalize2(const T *__restrict__ I1, const T *__restrict__ I2, T *__restrict__ o1,
-                             T *__restrict__ o2, int size, const double *__restrict__ mm)
+OFX_DEV void normalize2_px(const T *__restrict__ I1, const T *__restrict__ I2, T *__restrict__ o1, T *__restrict__ o2, int size,
+                           const double *__restrict__ mm)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t) size) return;
@@ -163,6 +161,42 @@ __global__ void k_normalize2(const T *__restrict__ I1, const T *__restrict__ I2,
         stn(o1 + i, a);
         stn(o2 + i, b);
     }
+}
+
+template <typename T>
+__global__ void k_minmax_partial(const T *__restrict__ I1, const T *__restrict__ I2, int size,
+                                 double *__restrict__ part /* [2][MM_BLOCKS] */)
+{
+    minmax_partial_block<T>(I1, I2, size, part);
+}
+__global__ void k_minmax_final(const double *__restrict__ part, int nblocks, double *__restrict__ mm)
+{
+    minmax_final_block(part, nblocks, mm);
+}
+template <typename T>
+__global__ void k_normalize2(const T *__restrict__ I1, const T *__restrict__ I2, T *__restrict__ o1,
+                             T *__restrict__ o2, int size, const double *__restrict__ mm)
+{
+    normalize2_px<T>(I1, I2, o1, o2, size, mm);
+}
+// the same three kernels for the G pairs of a lockstep group in one launch each (blockIdx.y = pair); the inputs are the
+// caller's separate device images, the outputs level arrays that hold the pairs back to back
+template <typename T> __global__ void k_minmax_partial_g(OfxGroupPtrs P, int size, double *__restrict__ scr)
+{
+    const int g = blockIdx.y;
+    minmax_partial_block<T>((const T *) P.a[g], (const T *) P.b[g], size, scr + (size_t) g * MM_SCR);
+}
+__global__ void k_minmax_final_g(double *__restrict__ scr, int nblocks)
+{
+    double *s = scr + (size_t) blockIdx.x * MM_SCR;
+    minmax_final_block(s, nblocks, s + 2 * MM_BLOCKS);
+}
+template <typename T>
+__global__ void k_normalize2_g(OfxGroupPtrs P, T *__restrict__ o1, T *__restrict__ o2, int size, const double *__restrict__ scr)
+{
+    const int g = blockIdx.y;
+    normalize2_px<T>((const T *) P.a[g], (const T *) P.b[g], o1 + (size_t) g * size, o2 + (size_t) g * size, size,
+                     scr + (size_t) g * MM_SCR + 2 * MM_BLOCKS);
 }
 
 template <typename T>
@@ -202,8 +236,15 @@ int ofx_gauss_taps(double sigma, GaussTaps *t)
 // right of it it IS repeated (t=n -> n-1).
 OFX_DEV int gauss_reflect(int t, int n) { return t < 0 ? -t : (t >= n ? 2 * n - 1 - t : t); }
 
+// Planes of a batched launch: blockIdx.z in [0, 2 G) = image (A, B) x pair; the G planes of an image are `stride` apart
+template <typename T> struct OfxPlanes2 {
+    T     *a, *b;
+    int    G;
+    size_t stride;
+    OFX_DEV T *at(int z) const { return (z < G ? a : b) + (size_t) (z < G ? z : z - G) * stride; }
+};
 template <typename T, bool ALONG_X>
-__global__ void k_gauss_pass(const T *__restrict__ in, T *__restrict__ out, int nx, int ny, GaussTaps taps)
+OFX_DEV void gauss_pass_px(const T *__restrict__ in, T *__restrict__ out, int nx, int ny, const GaussTaps &taps)
 {
     const int j = blockIdx.x * BX + threadIdx.x;
     const int i = blockIdx.y * BY + threadIdx.y;
@@ -220,6 +261,16 @@ __global__ void k_gauss_pass(const T *__restrict__ in, T *__restrict__ out, int 
                                 ldw(in + (size_t) gauss_reflect(i + k, ny) * nx + j));
     }
     stn(out + p, sum);
+}
+template <typename T, bool ALONG_X>
+__global__ void k_gauss_pass(const T *__restrict__ in, T *__restrict__ out, int nx, int ny, GaussTaps taps)
+{
+    gauss_pass_px<T, ALONG_X>(in, out, nx, ny, taps);
+}
+template <typename T, bool ALONG_X>
+__global__ void k_gauss_pass_g(OfxPlanes2<const T> in, OfxPlanes2<T> out, int nx, int ny, GaussTaps taps)
+{
+    gauss_pass_px<T, ALONG_X>(in.at(blockIdx.z), out.at(blockIdx.z), nx, ny, taps);
 }
 
 template <typename T> int op_gaussian(ofx_ctx *ctx, T *I, T *tmp, int nx, int ny, double sigma)
@@ -243,8 +294,7 @@ template <typename T> int op_gaussian(ofx_ctx *ctx, T *I, T *tmp, int nx, int ny
 
 // ---- bicubic resampling: zoom_out / zoom_in (src/zoom.cpp:41-78,132-155) ---------------------------
 template <typename T>
-__global__ void k_resample(const T *__restrict__ in, T *__restrict__ out, int nx, int ny, int nxx, int nyy,
-                           double fx, double fy)
+OFX_DEV void resample_px(const T *__restrict__ in, T *__restrict__ out, int nx, int ny, int nxx, int nyy, double fx, double fy)
 {
     const int j1 = blockIdx.x * BX + threadIdx.x;
     const int i1 = blockIdx.y * BY + threadIdx.y;
@@ -252,6 +302,17 @@ __global__ void k_resample(const T *__restrict__ in, T *__restrict__ out, int nx
     const double i2 = i1 / fy, j2 = j1 / fx;
     const BicubicTaps t = bicubic_taps(j2, i2, nx, ny);
     stn(out + (size_t) i1 * nxx + j1, bicubic_sample(in, t, nx));
+}
+template <typename T>
+__global__ void k_resample(const T *__restrict__ in, T *__restrict__ out, int nx, int ny, int nxx, int nyy,
+                           double fx, double fy)
+{
+    resample_px<T>(in, out, nx, ny, nxx, nyy, fx, fy);
+}
+template <typename T>
+__global__ void k_resample_g(OfxPlanes2<const T> in, OfxPlanes2<T> out, int nx, int ny, int nxx, int nyy, double fx, double fy)
+{
+    resample_px<T>(in.at(blockIdx.z), out.at(blockIdx.z), nx, ny, nxx, nyy, fx, fy);
 }
 
 template <typename T>
@@ -495,6 +556,10 @@ __global__ void k_grad_pack(const T *__restrict__ f, typename Pix<T>::v2 *__rest
     const int j = blockIdx.x * BX + threadIdx.x;
     const int i = blockIdx.y * BY + threadIdx.y;
     if (j >= nx || i >= ny) return;
+    const size_t zoff = (size_t) blockIdx.z * nx * ny;      // plane of a lockstep group
+    f += zoff;
+    pa += zoff;
+    pb += zoff;
     const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
     const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
     const size_t p = (size_t) i * nx + j;
@@ -504,9 +569,12 @@ __global__ void k_grad_pack(const T *__restrict__ f, typename Pix<T>::v2 *__rest
     stn(pb + p, fy);
 }
 
-template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v2 *pa, T *pb, int nx, int ny)
+// G planes back to back (blockIdx.z = plane)
+template <typename T> int op_grad_pack(ofx_ctx *ctx, const T *f, typename Pix<T>::v2 *pa, T *pb, int nx, int ny, int G)
 {
-    hipLaunchKernelGGL(k_grad_pack<T>, grid2d(nx, ny), block2d(), 0, ctx->stream, f, pa, pb, nx, ny);
+    dim3 g = grid2d(nx, ny);
+    g.z = G;
+    hipLaunchKernelGGL(k_grad_pack<T>, g, block2d(), 0, ctx->stream, f, pa, pb, nx, ny);
     OFX_LAUNCH_CHECK(ctx);
     return OFX_OK;
 }
@@ -530,7 +598,7 @@ int op_pyramid_sizes(ofx_ctx *ctx, int nxx, int nyy, int nscales, double zfactor
     return OFX_OK;
 }
 
-size_t op_pyramid_scratch_doubles() { return (size_t) 2 * MM_BLOCKS + 2; }
+size_t op_pyramid_scratch_doubles() { return (size_t) MM_SCR; }
 
 // lv[s] = sizes and DESTINATION arrays of every level (caller-allocated); tmpA / tmpB: full-size scratch
 // images, scr: op_pyramid_scratch_doubles() doubles.
@@ -545,6 +613,62 @@ int op_build_pyramid_into(ofx_ctx *ctx, const T *dA, const T *dB, int nscales, d
     for (int s = 1; s < nscales; s++) {
         OFX_TRY(op_zoom_out<T>(ctx, lv[s - 1].A, lv[s].A, tmpA, tmpB, lv[s - 1].nx, lv[s - 1].ny, zfactor));
         OFX_TRY(op_zoom_out<T>(ctx, lv[s - 1].B, lv[s].B, tmpA, tmpB, lv[s - 1].nx, lv[s - 1].ny, zfactor));
+    }
+    return OFX_OK;
+}
+
+// The same prologue for the G pairs of a lockstep group with ONE launch per step for all 2 G images (per pair it is 39
+// launches, most of them tiny): lvA[s] / lvB[s] = level arrays holding the G images back to back, tmpA / tmpB = scratch
+// for 2 G full-size images each, scr = G * op_pyramid_scratch_doubles() doubles.  Same per-pixel arithmetic as
+// op_build_pyramid_into; zoom_out's scratch copy (zoom.cpp:54-57) is not made -- the first Gaussian pass reads the level itself.
+template <typename T>
+int op_build_pyramid_group(ofx_ctx *ctx, int G, const void *const *dA, const void *const *dB, int nscales, double zfactor,
+                           double sigma, const int *nxs, const int *nys, T *const *lvA, T *const *lvB, T *tmpA, T *tmpB,
+                           double *scr)
+{
+    if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "pyramid group of %d", G);
+    const int nxx = nxs[0], nyy = nys[0], size = nxx * nyy;
+    OfxGroupPtrs P;
+    for (int g = 0; g < OFX_MAX_GROUP; g++) { P.a[g] = g < G ? dA[g] : nullptr; P.b[g] = g < G ? dB[g] : nullptr; }
+    int nb = grid1d((size_t) size);
+    if (nb > MM_BLOCKS) nb = MM_BLOCKS;
+    hipLaunchKernelGGL(k_minmax_partial_g<T>, dim3(nb, G), dim3(256), 0, ctx->stream, P, size, scr);
+    OFX_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_minmax_final_g, dim3(G), dim3(256), 0, ctx->stream, scr, nb);
+    OFX_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_normalize2_g<T>, dim3(grid1d((size_t) size), G), dim3(256), 0, ctx->stream, P, lvA[0], lvB[0], size,
+                       (const double *) scr);
+    OFX_LAUNCH_CHECK(ctx);
+    auto gauss = [&](const T *ia, const T *ib, T *oa, T *ob, T *ta, T *tb, int nx, int ny, double sg) -> int {
+        GaussTaps taps;
+        if (ofx_gauss_taps(sg, &taps) != OFX_OK)
+            return ofx_fail(ctx, OFX_ERR_ARG, "gaussian: sigma %g needs more than %d taps", sg, OFX_GAUSS_MAX_TAPS);
+        if (taps.size >= nx || taps.size >= ny)
+            return ofx_fail(ctx, OFX_ERR_SIGMA, "GaussianSmooth: sigma too large (radius %d, image %dx%d)", taps.size, nx, ny);
+        const size_t st = (size_t) nx * ny;
+        dim3 g = grid2d(nx, ny);
+        g.z = 2 * G;
+        hipLaunchKernelGGL((k_gauss_pass_g<T, true>), g, block2d(), 0, ctx->stream, OfxPlanes2<const T>{ia, ib, G, st},
+                           OfxPlanes2<T>{ta, tb, G, st}, nx, ny, taps);
+        OFX_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL((k_gauss_pass_g<T, false>), g, block2d(), 0, ctx->stream, OfxPlanes2<const T>{ta, tb, G, st},
+                           OfxPlanes2<T>{oa, ob, G, st}, nx, ny, taps);
+        OFX_LAUNCH_CHECK(ctx);
+        return OFX_OK;
+    };
+    // scratch: first half = the A images of the group, second half = the B images
+    OFX_TRY(gauss(lvA[0], lvB[0], lvA[0], lvB[0], tmpA, tmpA + (size_t) G * size, nxx, nyy, sigma));
+    const double zsigma = 0.6 * sqrt(1.0 / (zfactor * zfactor) - 1.0);          // ZOOM_SIGMA_ZERO, zoom.cpp:15,60
+    for (int s = 1; s < nscales; s++) {
+        const int nx = nxs[s - 1], ny = nys[s - 1];
+        const size_t st = (size_t) nx * ny;
+        OFX_TRY(gauss(lvA[s - 1], lvB[s - 1], tmpB, tmpB + (size_t) G * st, tmpA, tmpA + (size_t) G * st, nx, ny, zsigma));
+        dim3 g = grid2d(nxs[s], nys[s]);
+        g.z = 2 * G;
+        hipLaunchKernelGGL(k_resample_g<T>, g, block2d(), 0, ctx->stream,
+                           OfxPlanes2<const T>{tmpB, tmpB + (size_t) G * st, G, st},
+                           OfxPlanes2<T>{lvA[s], lvB[s], G, (size_t) nxs[s] * nys[s]}, nx, ny, nxs[s], nys[s], zfactor, zfactor);
+        OFX_LAUNCH_CHECK(ctx);
     }
     return OFX_OK;
 }
@@ -619,7 +743,9 @@ template <typename T> int op_minmax(ofx_ctx *ctx, const T *x, int size, double *
     template int op_second_derivative<T>(ofx_ctx *, const T *, T *, int, int, int);                                   \
     template int op_bicubic_warp<T>(ofx_ctx *, const T *, const T *, const T *, T *, int, int, int);                  \
     template int op_bicubic_at<T>(ofx_ctx *, const T *, const double *, const double *, double *, int, int, int, int);           \
-    template int op_grad_pack<T>(ofx_ctx *, const T *, Pix<T>::v2 *, T *, int, int);                                            \
+    template int op_grad_pack<T>(ofx_ctx *, const T *, Pix<T>::v2 *, T *, int, int, int);                                       \
+    template int op_build_pyramid_group<T>(ofx_ctx *, int, const void *const *, const void *const *, int, double, double,       \
+                                           const int *, const int *, T *const *, T *const *, T *, T *, double *);              \
     template int op_bicubic_at_color<T>(ofx_ctx *, const T *, const double *, const double *, double *, int, int, int, int, int, int); \
     template int op_gradient_dz<T>(ofx_ctx *, const T *, T *, int, int, int);                                                   \
     template int op_minmax<T>(ofx_ctx *, const T *, int, double *);                                                             \

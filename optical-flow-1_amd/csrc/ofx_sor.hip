@@ -467,8 +467,9 @@ static int sor_window_loop(ofx_ctx *ctx, int G, int size, int ny, double TOL, in
             OFX_TRY(launch(w, B, (int) (s_hi - s_lo + 1), active, per * OFX_NSHARD));
         }
         LS.max_iter = ns;
+        const int seq = ofx_poll_seq(ctx);
         const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
-        OFX_TRY(ofx_loop_finalize_group(ctx, LS, G, per, 0, ns, &ctx->h_state[slot * OFX_MAX_GROUP]));
+        OFX_TRY(ofx_loop_finalize_group(ctx, LS, G, per, 0, ns, &ctx->h_state[slot * OFX_MAX_GROUP], seq));
         OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
         OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
         for (int g = 0; g < G; g++) {
@@ -523,7 +524,7 @@ static int sor_exact_loop(ofx_ctx *ctx, int size, double TOL, int maxiter, int q
         }
         LS.max_iter = ns;
         const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
-        OFX_TRY(ofx_loop_finalize(ctx, LS, 0, ns, &ctx->h_state[slot * OFX_MAX_GROUP]));
+        OFX_TRY(ofx_loop_finalize_group(ctx, LS, 1, 0, 0, ns, &ctx->h_state[slot * OFX_MAX_GROUP], ofx_poll_seq(ctx)));
         OFX_HIP(ctx, hipEventRecord(ctx->ev_poll[slot], ctx->stream));
         OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));
         *out = ctx->h_state[slot * OFX_MAX_GROUP];
@@ -831,21 +832,15 @@ static int hs_pyramidal_dev(ofx_ctx *ctx, int G, const T *const *dI1, const T *c
     lv.resize(nscales);
     for (int s = 0; s < nscales; s++) OFX_TRY(hs_level_alloc<T>(ctx, lv[s], nxs[s], nys[s], G, true));
     {                                                                                                  // :279-317
-        T *tmpA, *tmpB;
+        T *tmpA, *tmpB;                                   // all 2 G images of the group per launch (op_build_pyramid_group)
         double *scr;
-        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &tmpA));
-        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &tmpB));
-        OFX_TRY(ofx_alloc(ctx, op_pyramid_scratch_doubles(), &scr));
-        std::vector<ImgLevel<T>> img(nscales);
-        for (int g = 0; g < G; g++) {
-            for (int s = 0; s < nscales; s++) {
-                img[s].nx = nxs[s];
-                img[s].ny = nys[s];
-                img[s].A = lv[s].I1 + g * lv[s].n();
-                img[s].B = lv[s].I2 + g * lv[s].n();
-            }
-            OFX_TRY(op_build_pyramid_into<T>(ctx, dI1[g], dI2[g], nscales, zfactor, HS_PRESMOOTH_SIGMA, img, tmpA, tmpB, scr));
-        }
+        OFX_TRY(ofx_alloc(ctx, (size_t) 2 * G * nx * ny, &tmpA));
+        OFX_TRY(ofx_alloc(ctx, (size_t) 2 * G * nx * ny, &tmpB));
+        OFX_TRY(ofx_alloc(ctx, (size_t) G * op_pyramid_scratch_doubles(), &scr));
+        std::vector<T *> lA(nscales), lB(nscales);
+        for (int s = 0; s < nscales; s++) { lA[s] = lv[s].I1; lB[s] = lv[s].I2; }
+        OFX_TRY(op_build_pyramid_group<T>(ctx, G, (const void *const *) dI1, (const void *const *) dI2, nscales, zfactor,
+                                          HS_PRESMOOTH_SIGMA, nxs.data(), nys.data(), lA.data(), lB.data(), tmpA, tmpB, scr));
     }
     HsLevel<T> &C = lv[nscales - 1];
     OFX_TRY(op_fill2<T>(ctx, C.U, C.n() * G));                                                          // :320-323
@@ -1556,21 +1551,15 @@ static int brox_spatial_dev(ofx_ctx *ctx, int G, const T *const *dI1, const T *c
     lv.resize(nscales);
     for (int s = 0; s < nscales; s++) OFX_TRY(brox_level_alloc<T>(ctx, lv[s], nxs[s], nys[s], G));
     {                                                                                              // :467-504
-        T *tmpA, *tmpB;
+        T *tmpA, *tmpB;                                   // all 2 G images of the group per launch (op_build_pyramid_group)
         double *scr;
-        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &tmpA));
-        OFX_TRY(ofx_alloc(ctx, (size_t) nx * ny, &tmpB));
-        OFX_TRY(ofx_alloc(ctx, op_pyramid_scratch_doubles(), &scr));
-        std::vector<ImgLevel<T>> img(nscales);
-        for (int g = 0; g < G; g++) {
-            for (int s = 0; s < nscales; s++) {
-                img[s].nx = nxs[s];
-                img[s].ny = nys[s];
-                img[s].A = lv[s].I1 + g * lv[s].n();
-                img[s].B = lv[s].I2 + g * lv[s].n();
-            }
-            OFX_TRY(op_build_pyramid_into<T>(ctx, dI1[g], dI2[g], nscales, nu, BROX_SIGMA, img, tmpA, tmpB, scr));
-        }
+        OFX_TRY(ofx_alloc(ctx, (size_t) 2 * G * nx * ny, &tmpA));
+        OFX_TRY(ofx_alloc(ctx, (size_t) 2 * G * nx * ny, &tmpB));
+        OFX_TRY(ofx_alloc(ctx, (size_t) G * op_pyramid_scratch_doubles(), &scr));
+        std::vector<T *> lA(nscales), lB(nscales);
+        for (int s = 0; s < nscales; s++) { lA[s] = lv[s].I1; lB[s] = lv[s].I2; }
+        OFX_TRY(op_build_pyramid_group<T>(ctx, G, (const void *const *) dI1, (const void *const *) dI2, nscales, nu,
+                                          BROX_SIGMA, nxs.data(), nys.data(), lA.data(), lB.data(), tmpA, tmpB, scr));
     }
     BroxLevel<T> &C = lv[nscales - 1];
     OFX_TRY(op_fill2<T>(ctx, C.U, C.n() * G));                                                     // :507-509

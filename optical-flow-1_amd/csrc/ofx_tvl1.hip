@@ -692,6 +692,48 @@ __global__ __launch_bounds__(WARP_NT) WARP_ATTR void k_tvl1_warp_lds(
     stn(Rg + goff + p, (I1w - I1wx * u.x - I1wy * u.y - ldw(I0g + goff + p)));       // :107-108
 }
 
+// zoom_in of the flows of a whole group (src/zoom.cpp:132-155 + the `*= 1 / zfactor` of src/tvl1flow.cpp:302-309; the per-
+// pixel arithmetic of k_zoom_in_flow, ofx_ops.hip): pair g reads its live buffer of the coarse level's rotation and writes
+// buffer 0 of the fine level
+template <typename T>
+__global__ void k_tvl1_zoom_in_g(Tri<typename Pix<T>::v2> Ut, unsigned curcode, typename Pix<T>::v2 *__restrict__ Uout, int nx,
+                                 int ny, int nxx, int nyy, double fx, double fy, double scale)
+{
+    const int j1 = blockIdx.x * 64 + threadIdx.x;
+    const int i1 = blockIdx.y * 4 + threadIdx.y;
+    if (j1 >= nxx || i1 >= nyy) return;
+    const int g = blockIdx.z;
+    const typename Pix<T>::v2 *__restrict__ U = pick3(Ut, curcode, g, (size_t) nx * ny).in;
+    const double i2 = i1 / fy, j2 = j1 / fx;
+    const BicubicTaps t = bicubic_taps(j2, i2, nx, ny);
+    double c1[4], c2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double2 v0 = ldw2(U + (size_t) t.row[0] * nx + t.col[k]);
+        const double2 v1 = ldw2(U + (size_t) t.row[1] * nx + t.col[k]);
+        const double2 v2 = ldw2(U + (size_t) t.row[2] * nx + t.col[k]);
+        const double2 v3 = ldw2(U + (size_t) t.row[3] * nx + t.col[k]);
+        c1[k] = cubic_cell(v0.x, v1.x, v2.x, v3.x, t.fy);
+        c2[k] = cubic_cell(v0.y, v1.y, v2.y, v3.y, t.fy);
+    }
+    double2 r;
+    r.x = cubic_cell(c1[0], c1[1], c1[2], c1[3], t.fx) * scale;
+    r.y = cubic_cell(c2[0], c2[1], c2[2], c2[3], t.fx) * scale;
+    stn2(Uout + (size_t) g * nxx * nyy + (size_t) i1 * nxx + j1, r);
+}
+
+// the .flo payloads of a whole group: (u, v) -> float32 pairs (the cast of src/tvl1flow_main.cpp:209-213), pair g from its
+// live buffer into the caller's g-th output array
+template <typename T>
+__global__ void k_tvl1_to_flo_g(Tri<typename Pix<T>::v2> Ut, unsigned curcode, OfxGroupPtrs out, size_t n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = blockIdx.y;
+    const double2 v = ldw2(pick3(Ut, curcode, g, n).in + i);
+    ((float2 *) out.a[g])[i] = make_float2((float) v.x, (float) v.y);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 // One level of a lockstep group: every array holds G pairs back to back (pair g at element g * nx * ny).
 template <typename T> struct Tvl1Level {
@@ -920,7 +962,7 @@ static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params
     const dim3 g2(ofx_cdiv(nx, OFX_WARP_BX), ofx_cdiv(ny, OFX_WARP_BY), G), b2(OFX_WARP_BX, OFX_WARP_BY);
     if (nx < 2 || ny < 2) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: level %dx%d too small", nx, ny);
 
-    for (int g = 0; g < G; g++) OFX_TRY(op_grad_pack<T>(ctx, L.I1 + g * n, L.pa + g * n, L.pb + g * n, nx, ny));   // :84
+    OFX_TRY(op_grad_pack<T>(ctx, L.I1, L.pa, L.pb, nx, ny, G));                                                    // :84
     // p = 0 in the buffer each pair's u lives in (:87-90)
     for (int h = 0; h < 3; h++) {
         bool used = false;
@@ -989,20 +1031,13 @@ static int tvl1_multiscale_dev(ofx_ctx *ctx, int G, const T *const *dI0, const T
     {                                                                                              // :255-275
         T *tmpA, *tmpB;
         double *scr;
-        OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpA));
-        OFX_TRY(ofx_alloc(ctx, (size_t) nxx * nyy, &tmpB));
-        OFX_TRY(ofx_alloc(ctx, op_pyramid_scratch_doubles(), &scr));
-        std::vector<ImgLevel<T>> img(nscales);
-        for (int g = 0; g < G; g++) {
-            for (int s = 0; s < nscales; s++) {
-                img[s].nx = nxs[s];
-                img[s].ny = nys[s];
-                img[s].A = lv[s].I0 + g * lv[s].n();
-                img[s].B = lv[s].I1 + g * lv[s].n();
-            }
-            OFX_TRY(op_build_pyramid_into<T>(ctx, dI0[g], dI1[g], nscales, zfactor, TVL1_PRESMOOTHING_SIGMA, img, tmpA,
-                                             tmpB, scr));
-        }
+        OFX_TRY(ofx_alloc(ctx, (size_t) 2 * G * nxx * nyy, &tmpA));
+        OFX_TRY(ofx_alloc(ctx, (size_t) 2 * G * nxx * nyy, &tmpB));
+        OFX_TRY(ofx_alloc(ctx, (size_t) G * op_pyramid_scratch_doubles(), &scr));
+        std::vector<T *> lA(nscales), lB(nscales);
+        for (int s = 0; s < nscales; s++) { lA[s] = lv[s].I0; lB[s] = lv[s].I1; }
+        OFX_TRY(op_build_pyramid_group<T>(ctx, G, (const void *const *) dI0, (const void *const *) dI1, nscales, zfactor,
+                                          TVL1_PRESMOOTHING_SIGMA, nxs.data(), nys.data(), lA.data(), lB.data(), tmpA, tmpB, scr));
     }
     Tvl1Level<T> &C = lv[nscales - 1];
     OFX_TRY(op_fill2<T>(ctx, C.U[0], C.n() * G));                                                // :278-280
@@ -1012,9 +1047,13 @@ static int tvl1_multiscale_dev(ofx_ctx *ctx, int G, const T *const *dI0, const T
         OFX_TRY(tvl1_single_scale_dev<T>(ctx, lv[s], P, s, stats));
         if (!s) break;
         lv[s - 1].cur = 0;
-        for (int g = 0; g < G; g++)
-            OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].Ucur(g), lv[s - 1].U[0] + g * lv[s - 1].n(),
-                                       lv[s].nx, lv[s].ny, lv[s - 1].nx, lv[s - 1].ny, 1.0 / zfactor));   // :302-309
+        {                                                                                        // :302-309, all pairs in one launch
+            const int nxf = lv[s - 1].nx, nyf = lv[s - 1].ny;
+            hipLaunchKernelGGL(k_tvl1_zoom_in_g<T>, dim3(ofx_cdiv(nxf, 64), ofx_cdiv(nyf, 4), G), dim3(64, 4), 0, ctx->stream,
+                               lv[s].Ut(), lv[s].cur, lv[s - 1].U[0], lv[s].nx, lv[s].ny, nxf, nyf, (double) nxf / lv[s].nx,
+                               (double) nyf / lv[s].ny, 1.0 / zfactor);
+            OFX_LAUNCH_CHECK(ctx);
+        }
     }
     return OFX_OK;
 }
@@ -1085,8 +1124,11 @@ static int tvl1_group_devapi(ofx_ctx *ctx, int G, const void *const *dI0, const 
     OFX_TRY(tvl1_multiscale_dev<T>(ctx, G, (const T *const *) dI0, (const T *const *) dI1, nx, ny, P, nscales, zfactor, lv,
                                    stats));
     const size_t n = (size_t) nx * ny;
-    for (int g = 0; g < G; g++)
-        OFX_TRY(op_to_flo<T>(ctx, lv[0].Ucur(g), (float2 *) d_flo[g], n));
+    OfxGroupPtrs out;
+    for (int g = 0; g < OFX_MAX_GROUP; g++) { out.a[g] = g < G ? d_flo[g] : nullptr; out.b[g] = nullptr; }
+    hipLaunchKernelGGL(k_tvl1_to_flo_g<T>, dim3((unsigned) ((n + 255) / 256), G), dim3(256), 0, ctx->stream, lv[0].Ut(), lv[0].cur,
+                       out, n);
+    OFX_LAUNCH_CHECK(ctx);
     return OFX_OK;
 }
 
@@ -1256,8 +1298,9 @@ extern "C" int ofx_tvl1_batch_group_size(ofx_ctx *const *ctxs, int n_ctx, int n_
     for (int s = 0; s < nscales; s++) px += (double) nxs[s] * nys[s];
     const double elem = ctxs[0]->precision == OFX_F32 ? 4.0 : 8.0;
     // tvl1_level_alloc: I0, I1, pb, R (1 element per pixel each) + pa, U[3], P1[3], P2[3], A (2 each) = 26 per level
-    const double per_pair = 26.0 * px * elem;
-    const double per_ctx = 2.0 * (double) nx * ny * elem + 64e6;   // pyramid temporaries, error slots, arena slack
+    // + the pyramid temporaries: two scratch arrays of 2 full-size images per pair (op_build_pyramid_group)
+    const double per_pair = (26.0 * px + 4.0 * (double) nx * ny) * elem;
+    const double per_ctx = 64e6;                                    // error slots, arena slack
     size_t mfree = 0, mtotal = 0;
     int dev_now = 0;
     (void) hipGetDevice(&dev_now);
@@ -1273,6 +1316,30 @@ extern "C" int ofx_tvl1_batch_group_size(ofx_ctx *const *ctxs, int n_ctx, int n_
     const int rounds = (n_pairs + n_ctx * cap - 1) / (n_ctx * cap);
     G = (n_pairs + n_ctx * rounds - 1) / (n_ctx * rounds);
     return G < 1 ? 1 : G;
+}
+
+// libm's hypot as the dual update uses it (src/tvl1flow.cpp:172-173), n values: the device restatement of glibc's algorithm
+// exposed for direct testing over the whole double range
+__global__ void k_hypot(const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hypot_ref(x[i], y[i]);
+}
+extern "C" int ofx_hypot(ofx_ctx *ctx, const double *x, const double *y, double *out, int n)
+{
+    OFX_ENTER(ctx);
+    if (!x || !y || !out || n < 1) return ofx_fail(ctx, OFX_ERR_ARG, "hypot: NULL pointer / n < 1");
+    double *dx, *dy, *dz;
+    OFX_TRY(ofx_alloc(ctx, (size_t) n, &dx));
+    OFX_TRY(ofx_alloc(ctx, (size_t) n, &dy));
+    OFX_TRY(ofx_alloc(ctx, (size_t) n, &dz));
+    OFX_HIP(ctx, hipMemcpyAsync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    OFX_HIP(ctx, hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_hypot, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const double *) dx, (const double *) dy, dz, n);
+    OFX_LAUNCH_CHECK(ctx);
+    OFX_HIP(ctx, hipMemcpyAsync(out, dz, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return OFX_OK;
 }
 
 // ---- batch of pairs: lockstep groups, one worker thread per context --------------------------------------

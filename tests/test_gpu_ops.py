@@ -104,3 +104,27 @@ def test_colour_sequence_and_minmax_operators(gpu64, orc, ofx_mod):
     assert np.array_equal(gpu64.zoom_out_color(one, 0.5)[..., 0], orc.zoom_out(one[..., 0], 0.5))
     with pytest.raises(ofx_mod.OfxError):
         gpu64.zoom_out_color(img, 0.5)                                        # nz > 1: undefined in the reference
+
+
+def test_hypot_is_glibc_hypot_over_the_whole_range(gpu64):
+    """ofx_hypot = the device's restatement of glibc's hypot (src/tvl1flow.cpp:172-173 calls libm).  The common domain
+    (ax <= 2^511, ay >= 2^-383) runs the compiler's sqrt / division expansions without their range scaling; everything else
+    the general code.  Both against the libm of this box (numpy.hypot calls it), bit for bit: magnitudes from denormal to
+    1e300, the domain borders, ratios around 2^54, zeros, exact triples, equal arguments."""
+    rng = np.random.default_rng(11)
+    n = 400000
+    xs = [rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 3, n), rng.standard_normal(n) * 10.0 ** rng.uniform(-320, 305, n)]
+    ys = [rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 3, n), rng.standard_normal(n) * 10.0 ** rng.uniform(-320, 305, n)]
+    # around the borders of the common domain and of the general code's own branches
+    for e in (-1074, -1022, -600, -460, -459, -458, -384, -383, -382, -54, 0, 54, 510, 511, 512, 600, 1023):
+        m = 1.0 + rng.random(4000)
+        xs.append(np.ldexp(m, e))
+        ys.append(np.ldexp(1.0 + rng.random(4000), e + rng.integers(-60, 2, 4000)))
+    xs.append(np.array([0.0, -0.0, 3.0, 5.0, 8.0, 1e-200, 2.5, 0.0, 1.0, 1e308]))
+    ys.append(np.array([0.0, 7.5, 4.0, 12.0, 15.0, 0.0, 2.5, -0.0, 2.0 ** -54, 1e308]))
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    with np.errstate(over="ignore"):
+        want = np.hypot(x, y)
+    got = gpu64.hypot(x, y)
+    bad = np.flatnonzero(got.view(np.int64) != want.view(np.int64))
+    assert bad.size == 0, (bad.size, x[bad[:5]], y[bad[:5]], got[bad[:5]], want[bad[:5]])

@@ -467,3 +467,23 @@ def test_batch_dev_on_four_contexts_at_1080p_equals_solo(ofx_mod, gpu64, synth):
         assert torch.equal(flo[i].view(torch.int32), solo[i % 8].view(torch.int32)), i
         w = sum(int(its[i % 8][s].sum()) * st.nx[s] * st.ny[s] for s in range(5))
         assert work[i] == w, i
+
+
+@pytest.mark.parametrize("pair", ["P0", "P1"])
+def test_relaxed_dual_mode_stays_within_the_stated_tolerance(gpu64, orc, synth, pair):
+    """Option relaxed_dual = 1 (the f64 "tolerance" mode: double storage, sqrt(x^2 + y^2) and one reciprocal per denominator in
+    the dual update instead of the glibc-exact hypot and four IEEE divisions).  NOT bit-identical; the bar is north_star's:
+    average end-point error against the reference < 1e-4 px (measured ~1e-8), iteration counts within a few per loop."""
+    I0, I1 = synth.pair(pair, 640, 480)
+    uo, vo, it_o, _ = orc.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+    gpu64.set_option("relaxed_dual", 1)
+    try:
+        ug, vg = gpu64.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+        it_g = gpu64.stats().iterations().copy()
+    finally:
+        gpu64.set_option("relaxed_dual", 0)
+    assert aepe(ug, vg, uo, vo) < 1e-4                     # the stated tolerance
+    assert np.abs(it_g - np.asarray(it_o)).max() <= 4
+    us, vs = gpu64.tvl1_multiscale(I0, I1, nscales=5, **PAR)          # back in strict mode: bit-identical again
+    assert np.array_equal(gpu64.stats().iterations(), it_o)
+    assert np.abs(us - uo).max() < 1e-9 and np.abs(vs - vo).max() < 1e-9
