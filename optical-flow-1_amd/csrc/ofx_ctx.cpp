@@ -69,6 +69,8 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->lockstep = 0;
     ctx->warp_lds = 1;
     ctx->relaxed_dual = 0;
+    ctx->tile = 0;              // measured: no faster than the marching strips on the small levels, off by default
+    ctx->tile_max_px = 0;
     ctx->nt_stores = 0;
     ctx->chunk = 0;             // 0 = pick per level
     ctx->spin_us = 150;
@@ -78,6 +80,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->sor_window = 0;
     ctx->sor_rows = 0;
     ctx->sor_spw = 0;
+    ctx->sor_lds = 1;
     ctx->mem_budget = 0;
     ctx->poll_seq = 0;
     ctx->errmsg[0] = 0;
@@ -154,6 +157,16 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
         ctx->concurrency = (int) value;
         return OFX_OK;
     }
+    if (!strcmp(name, "tile")) {
+        if (value != 0 && value != 4 && value != 6) return ofx_fail(ctx, OFX_ERR_ARG, "tile must be 0, 4 or 6");
+        ctx->tile = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "tile_max_px")) {
+        if (value < 0) return ofx_fail(ctx, OFX_ERR_ARG, "tile_max_px out of range");
+        ctx->tile_max_px = value;
+        return OFX_OK;
+    }
     if (!strcmp(name, "relaxed_dual")) { ctx->relaxed_dual = value != 0; return OFX_OK; }
     if (!strcmp(name, "warp_lds")) { ctx->warp_lds = value != 0; return OFX_OK; }
     if (!strcmp(name, "nt_stores")) { ctx->nt_stores = (int) value; return (value >= 0 && value <= 2) ? OFX_OK : ofx_fail(ctx, OFX_ERR_ARG, "nt_stores = 0 | 1 | 2"); }
@@ -170,6 +183,11 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "sor_rows")) {
         if (value < 0 || value > 4096) return ofx_fail(ctx, OFX_ERR_ARG, "sor_rows out of range");
         ctx->sor_rows = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "sor_lds")) {
+        if (value != 0 && value != 1 && value != 2) return ofx_fail(ctx, OFX_ERR_ARG, "sor_lds must be 0, 1 or 2");
+        ctx->sor_lds = (int) value;
         return OFX_OK;
     }
     if (!strcmp(name, "sor_spw")) {

@@ -63,6 +63,8 @@ struct ofx_ctx {
     int nt_stores;      // fused TV-L1 kernel: 0 (default) non-temporal stores once a launch's working set exceeds the Infinity Cache, 1 always, 2 never
     int relaxed_dual;   // TV-L1 in double storage: 1 = the fast mode's dual stage (sqrt(x^2 + y^2), one reciprocal per denominator) --
                         // the "tolerance" mode, AEPE vs the reference ~1e-9..1e-6, not bit-identical; 0 (default) strict
+    int tile;           // TV-L1 small levels: K iterations per launch on 2-D tiles (k_tvl1_tile): 4 | 6 | 0 = off (default)
+    double tile_max_px; // ... for levels of at most this many pixels x pairs (0 = default 200 000)
     int warp_lds;       // 1 (default): TV-L1 warp with the taps staged through LDS; 0: gathered from global memory
     int chunk;
     int spin_us;        // convergence polls: microseconds the host spins on the pinned record before it falls back to
@@ -72,6 +74,7 @@ struct ofx_ctx {
     int sor_batch;      // sweeps in flight per batch in exact mode (0 = default)
     int sor_window;     // time steps per launch of the windowed exact mode (0 = 8)
     int sor_rows;       // rows per block (workgroup) of a sweep in the windowed exact mode (0 = 64)
+    int sor_lds;        // windowed exact sweeps with the launch window staged in LDS (1 default; 0 = the per-step global round trip)
     int sor_spw;        // sweeps per workgroup of the windowed exact kernels (0 = automatic: 1 alone, 2 in lockstep groups)
     double mem_budget;  // bytes all contexts of a batch may use for level arrays (0 = half of the free device memory)
     unsigned long long poll_seq;

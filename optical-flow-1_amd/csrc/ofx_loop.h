@@ -52,6 +52,8 @@ struct LoopSpec {
     int    chunk;      // sweeps per poll
     bool   fixed;      // run exactly max_iter sweeps (stopping test disabled)
     bool   pairs;      // the solver fuses two sweeps per launch where it can (TV-L1)
+    int    fuse = 0;   // > 2: the solver fuses this many sweeps per launch (TV-L1 tile kernel of the small levels); a loop that
+                       // stops inside a launch unit is finished by redo(), which re-runs the unit's first sweeps from its input
     double afac = 0.0; // pairs only: a fused launch whose previous error is <= thr * afac also stores the state between
                        // its two sweeps (0 = never); the finalize kernel reports whether the stopping launch did
 };
@@ -70,7 +72,9 @@ static inline int ofx_poll_seq(const ofx_ctx *ctx) { return (int) (ctx->poll_seq
 // continue; the host stops enqueueing when every problem is done.
 //   launch(k, count, thr) must enqueue every kernel of sweeps k .. k+count-1 of ALL problems on ctx->stream
 // (count is 2 only when L.pairs and at least two sweeps remain; pairs always start at an even k); kernels
-// take (ctx->d_err, k, thr) and use the helpers above.  With L.pairs the second sweep of a pair runs even
+// take (ctx->d_err, k, thr) and use the helpers above (L.fuse > 2: count is up to L.fuse, units start at multiples of it, and
+// redo(k_of) must re-run the first n_g - k0 sweeps of the unit that contains sweep k_of[g] = n_g - 1 from that unit's input).
+// With L.pairs the second sweep of a pair runs even
 // when the first one ended the loop; if that happens for any problem (n odd), redo(k_of) is called ONCE with
 // k_of[g] = n_g - 1 for those problems and -1 for the others, and must recompute sweep k_of[g] of each such
 // problem alone from the pair's untouched input buffers.  Problems whose stopping launch had stored its intermediate
@@ -115,13 +119,14 @@ static int ofx_run_loop_group_impl(ofx_ctx *ctx, const LoopSpec &L, int G, Launc
     bool stop = false;
     OfxIterState fin[OFX_MAX_GROUP];
     int chunk = S.chunk < 1 ? 1 : S.chunk;
-    if (S.pairs) chunk += chunk & 1;
+    const int F = S.fuse > 2 ? S.fuse : (S.pairs ? 2 : 1);       // sweeps per launch unit; units start at multiples of F
+    chunk = (chunk + F - 1) / F * F;
     for (;;) {
         while (launched < S.max_iter && head - tail < max_out) {
             const int first = launched;
             const int c = (S.max_iter - launched < chunk) ? S.max_iter - launched : chunk;
             while (launched < first + c) {
-                const int cnt = (S.pairs && first + c - launched >= 2) ? 2 : 1;
+                const int cnt = (first + c - launched < F) ? first + c - launched : F;
                 OFX_TRY(launch(launched, cnt, S.thr));
                 launched += cnt;
             }
@@ -153,8 +158,14 @@ static int ofx_run_loop_group_impl(ofx_ctx *ctx, const LoopSpec &L, int G, Launc
     int redo_k[OFX_MAX_GROUP];
     bool any_redo = false;
     for (int g = 0; g < G; g++) {
-        bool r = S.pairs && (fin[g].n & 1) && fin[g].n != S.max_iter;
-        const bool stored = r && took_alt && (fin[g].apred || (fin[g].n == 1 && ((amask0 >> g) & 1u)));
+        // the loop ended inside launch unit j = (n - 1) / F unless n is that unit's last sweep (units are F sweeps, the last
+        // one of the loop what is left of max_iter): F = 2 -> n odd and not max_iter
+        bool r = false;
+        if (F > 1 && fin[g].n > 0) {
+            const int k0 = (fin[g].n - 1) / F * F, cnt = (S.max_iter - k0 < F) ? S.max_iter - k0 : F;
+            r = fin[g].n - k0 != cnt;
+        }
+        const bool stored = r && F == 2 && took_alt && (fin[g].apred || (fin[g].n == 1 && ((amask0 >> g) & 1u)));
         if (took_alt) took_alt[g] = stored ? 1 : 0;
         r = r && !stored;
         redo_k[g] = r ? fin[g].n - 1 : -1;

@@ -106,6 +106,21 @@ template <typename T, bool COH, bool SNAP, class Lay = LayRow> struct UGlobal {
     typename Pix<T>::v2 *U, *snap;
     Lay lay;
     OFX_DEV double2 get(int ii, int jj) const { return ldu2<COH>(U + lay.idx(ii, jj)); }
+    // the constant operands of pixel (i, j): HS (A, dif)
+    OFX_DEV void coef(const typename Pix<T>::v2 *__restrict__ A, const T *__restrict__ Dif, int i, int j, double2 &a, double &dif) const
+    {
+        const size_t p = lay.idx(i, j);
+        a = ldw2(A + p);
+        dif = ldw(Dif + p);
+    }
+    // Brox: psi_s of pixel (ii, jj); (CO, Dm) of pixel (i, j)
+    OFX_DEV double psi(const T *__restrict__ Psis, int ii, int jj) const { return ldw(Psis + lay.idx(ii, jj)); }
+    OFX_DEV void coef4(const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm, int i, int j, double4 &co, double &D) const
+    {
+        const size_t p = lay.idx(i, j);
+        co = ldw4(CO + p);
+        D = ldw(Dm + p);
+    }
     OFX_DEV void put(int i, int j, double2 v) const
     {
         const size_t p = lay.idx(i, j);
@@ -152,7 +167,6 @@ OFX_DEV HsOps hs_point_load(const Acc &acc, const typename Pix<T>::v2 *__restric
 {
     const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
     const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
-    const size_t p = acc.lay.idx(i, j);
     HsOps o;
     o.p1 = acc.get(iu, jl); o.p2 = acc.get(iu, jr);
     o.p3 = acc.get(id, jl); o.p4 = acc.get(id, jr);
@@ -163,8 +177,7 @@ OFX_DEV HsOps hs_point_load(const Acc &acc, const typename Pix<T>::v2 *__restric
     o.p5 = acc.get(iu, j); o.p6 = acc.get(i, jl);
     o.p7 = acc.get(id, j); o.p8 = acc.get(i, jr);
     o.c = acc.get(i, j);
-    o.a = ldw2(A + p);
-    o.dif = ldw(Dif + p);
+    acc.coef(A, Dif, i, j, o.a, o.dif);
     return o;
 }
 template <typename T, class Acc>
@@ -396,6 +409,124 @@ __global__ __launch_bounds__(MAXT) void k_hs_window(typename Pix<T>::v2 *Ug, typ
         if (live[u]) loop_accumulate(err, s0 + u, e[u], b * 4 + (threadIdx.x >> 6));
 }
 
+// ---- windowed exact mode with the launch window staged in LDS ---------------------------------------------------------------
+// k_hs_window pays one global round trip per time step: the step's stores have to reach L2 (s_waitcnt vmcnt(0)) before the
+// barrier lets the next step load them -- ~1.5 us per step for ~200 instructions of work.  The schedule guarantees that
+// everything a workgroup takes from ANOTHER workgroup was written in an earlier launch and is overwritten in a later one, so
+// a workgroup can fetch everything its KW steps will touch when the launch starts -- all loads in flight together, one
+// memory latency per launch -- and run the steps without global loads: the unknowns live in an LDS window (neighbours are
+// LDS reads; an update goes to LDS for the workgroup's own later steps and, without waiting, to the in-place array and the
+// sweep's snapshot for everybody else; the per-step barrier waits for LDS only), the constant operands of the KW pixels a
+// thread will update wait in LDS slots of its own.  What the KW steps [q0, q0 + KW) of (sweep, row block b) touch
+// (tools/check_sor_schedule.py --cover enumerates it, tests/test_host_logic.py checks it): unknowns on hyperplanes
+// q0 - 7 .. q0 + KW + 2 of the skewed coordinate c i + j (the border pixels run up to 7 steps behind their own coordinate),
+// rows b R - 2 .. b R + R.  Same per-pixel function, same operands: bit-identical to k_hs_window.
+template <typename T, int KW> struct HsWinLds {
+    static constexpr int NH = KW + 10;          // hyperplanes of unknowns in the window
+    static constexpr int BACK = 7;              // window starts at q0 - BACK
+};
+template <typename T, bool SNAP> struct ULds {
+    typename Pix<T>::v2 *U, *snap;               // global arrays (hyperplane-major), written through
+    double2 *win;                                // [NH][nr]  unknowns
+    int nr, row0, h0;                            // LDS rows, image row of LDS row 0, hyperplane of LDS plane 0
+    LaySkew lay;
+    double2 a;                                   // constant operands of the pixel being updated (set per step)
+    double dif;
+    OFX_DEV double2 get(int ii, int jj) const { return win[(2 * ii + jj - h0) * nr + (ii - row0)]; }
+    OFX_DEV void coef(const typename Pix<T>::v2 *, const T *, int, int, double2 &a_, double &dif_) const { a_ = a; dif_ = dif; }
+    OFX_DEV void put(int i, int j, double2 v) const
+    {
+        win[(2 * i + j - h0) * nr + (i - row0)] = v;
+        const size_t p = lay.idx(i, j);
+        stn2(U + p, v);
+        if (SNAP) stn2(snap + p, v);
+    }
+};
+// the pixel plane item r updates at local step q in row block b, if any (the rule of k_hs_window)
+OFX_DEV bool hs_window_pixel(const SorWin &w, int b, int r, int q, int qmax, int nx, int ny, int &pi, int &pj)
+{
+    return q >= 0 && q <= qmax && r >= 0 && r != ny + 2 && hs_plane_item(r, q, nx, ny, 0, pi, pj) &&
+           (r < ny || sor_border_block(pi, ny, w.R) == b);
+}
+template <typename T, int KW, int MAXT>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_hs_window_lds(
+    typename Pix<T>::v2 *Ug, typename Pix<T>::v2 *snap, const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Difg,
+    double *__restrict__ errg, SorWin w, SorGrp grp, int s_cnt, int nx, int ny, double alpha2)
+{
+    using W = HsWinLds<T, KW>;
+    extern __shared__ double2 hs_lds[];
+    const int b = blockIdx.x, s = w.s_first + blockIdx.y, g = blockIdx.z;
+    if (!((grp.runmask >> g) & 1u)) return;                      // this pair's solve has already stopped
+    const int qmax = 2 * ny + nx - 2;
+    const int q0 = w.tau0 - w.lag_s * s - w.lag_b * b;
+    if (q0 > qmax || q0 + KW - 1 < 0) return;                    // no step of this (sweep, block) in the window: uniform
+    typename Pix<T>::v2 *U = Ug + g * grp.npix;
+    const typename Pix<T>::v2 *__restrict__ A = Ag + g * grp.npix;
+    const T *__restrict__ Dif = Difg + g * grp.npix;
+    typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) s * grp.npix;
+    double *__restrict__ err = errg + (size_t) g * grp.err_stride;
+    const int nr = w.R + 3, row0 = b * w.R - 2, h0 = q0 - W::BACK, t = threadIdx.x;
+    const int nt = blockDim.x;
+    double2 *win = hs_lds;                                       // [NH][nr] unknowns
+    double2 *ca = hs_lds + W::NH * nr;                           // [KW][nt] (I2wx, I2wy) of the pixel thread t updates at step k
+    double *cd = reinterpret_cast<double *>(ca + KW * nt);       // [KW][nt] dif
+    const LaySkew lay = {ny, HS_PLANE_C_SKEW};
+    const int r = sor_window_item(w, b, t, ny);
+    // ---- fetch: thread t brings LDS row t (image row row0 + t) of every hyperplane of the window and the constant operands of
+    // the KW pixels it will update; every load unconditional (entries outside the image / steps without a pixel read a
+    // harmless address and are never used) and issued before the first use: one memory latency for the whole launch
+    double2 u_in[W::NH], a_in[KW];
+    double d_in[KW];
+    {
+        const int i = row0 + t, ic = i < 0 ? 0 : (i > ny - 1 ? ny - 1 : i);
+        const int hmax = 2 * (ny - 1) + nx - 1;
+#pragma unroll
+        for (int k = 0; k < W::NH; k++) {
+            const int h = h0 + k, hc = h < 0 ? 0 : (h > hmax ? hmax : h);
+            u_in[k] = ldw2(U + (size_t) hc * ny + ic);
+        }
+#pragma unroll
+        for (int k = 0; k < KW; k++) {
+            int pi, pj;
+            const bool have = hs_window_pixel(w, b, r, q0 + k, qmax, nx, ny, pi, pj);
+            const size_t p = have ? lay.idx(pi, pj) : 0;
+            a_in[k] = ldw2(A + p);
+            d_in[k] = ldw(Dif + p);
+        }
+        if (t < nr) {
+#pragma unroll
+            for (int k = 0; k < W::NH; k++) win[k * nr + t] = u_in[k];
+        }
+#pragma unroll
+        for (int k = 0; k < KW; k++) { ca[k * nt + t] = a_in[k]; cd[k * nt + t] = d_in[k]; }     // this thread's own slots
+    }
+    __syncthreads();
+    ULds<T, true> acc = {U, mysnap, win, nr, row0, h0, lay, make_double2(0.0, 0.0), 0.0};
+    double e = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < KW; k++) {
+        const int q = q0 + k;
+        int pi, pj;
+        if (hs_window_pixel(w, b, r, q, qmax, nx, ny, pi, pj)) {
+            acc.a = ca[k * nt + t];
+            acc.dif = cd[k * nt + t];
+            e += hs_point_acc<T>(acc, A, Dif, pi, pj, nx, ny, alpha2);
+        }
+        if (q >= 0 && q <= qmax && r == ny + 2) {                // the corner item: up to four pixels, one after the other
+            for (int corner = 0; corner < 4; corner++)
+                if (hs_plane_item(r, q, nx, ny, corner, pi, pj) && sor_border_block(pi, ny, w.R) == b) {
+                    const size_t p = lay.idx(pi, pj);            // four pixels per sweep: their operands come from memory
+                    acc.a = ldw2(A + p);
+                    acc.dif = ldw(Dif + p);
+                    e += hs_point_acc<T>(acc, A, Dif, pi, pj, nx, ny, alpha2);
+                }
+        }
+        // the next step reads this step's LDS writes: wait for LDS only (the global stores drain on their own)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    loop_accumulate(err, s, e, b * 4 + (t >> 6));
+}
+
 // Batch driver of the windowed exact mode.  launch(w, blocks, sweeps) enqueues one window over `blocks` row
 // blocks x `sweeps` sweeps starting at w.s_first; take(n) makes snapshot n - 1 the current state.  Same contract
 // as sor_exact_loop.  Spacing: lag_b = K between the row blocks of a sweep, lag_s = 2 K + C between sweeps (K + C
@@ -406,7 +537,8 @@ __global__ __launch_bounds__(MAXT) void k_hs_window(typename Pix<T>::v2 *Ug, typ
 // lag_f = K steps behind frame o - 1 and the sweeps move lag_f (nz - 1) further apart.
 template <class WindowFn, class TakeFn>
 static int sor_window_loop(ofx_ctx *ctx, int G, int size, int ny, double TOL, int maxiter, int qmax, int C, int batch,
-                           WindowFn launch, TakeFn take, int *n_out, double *err_out, int nz = 1, int *hint = nullptr)
+                           WindowFn launch, TakeFn take, int *n_out, double *err_out, int nz = 1, int *hint = nullptr,
+                           int Kdef = 0)          // Kdef: the caller's default steps per launch (0 = the rule below)
 {
     // G problems in lockstep (SorGrp): launch(w, blocks, sweeps, runmask, err_stride) serves every problem whose bit
     // is set; take(g, n) makes snapshot n - 1 of problem g its current state.  All problems start together, so the
@@ -417,7 +549,7 @@ static int sor_window_loop(ofx_ctx *ctx, int G, int size, int ny, double TOL, in
     // workgroups anyway and runs 6-10 % faster with 125 rows (+ the 3 border items = two full waves); 8 steps per launch,
     // 4 for the 4-neighbour stencil in a group (its sweeps are spaced C = 2 apart, so the 2 K lag dominates the pipeline).
     SorWin w;
-    w.K = ctx->sor_window > 0 ? ctx->sor_window : ((G >= 4 && C <= 2) ? 4 : 8);
+    w.K = ctx->sor_window > 0 ? ctx->sor_window : (Kdef > 0 ? Kdef : ((G >= 4 && C <= 2) ? 4 : 8));
     w.R = ctx->sor_rows > 0 ? ctx->sor_rows : (G >= 4 ? 125 : 64);
     if (w.R < 2) w.R = 2;
     if (w.R > 1021) w.R = 1021;                                  // R + 3 threads per workgroup
@@ -582,6 +714,11 @@ static int sor_pick_spw(const ofx_ctx *ctx, int G)
     if (ctx->sor_spw == 1 || ctx->sor_spw == 2 || ctx->sor_spw == 4) return ctx->sor_spw;
     return 1;
 }
+// Which windowed kernel: option "sor_lds" = 0 the per-step global round trip (k_*_window), 2 the LDS-staged launch window
+// (k_*_window_lds), 1 (default) by measurement: the LDS window for a lone solve -- a latency chain, where one memory latency
+// per launch instead of one per step counts -- and the global kernels for lockstep groups of 4 pairs and more, which are
+// bound by resident waves (28 per CU at 64 VGPRs and no LDS against a few LDS-limited workgroups).
+static bool sor_use_lds(const ofx_ctx *ctx, int G) { return ctx->sor_lds == 2 || (ctx->sor_lds == 1 && G < 4); }
 static int sor_window_threads(int n_items)
 {
     const int t = ofx_cdiv(n_items, 64) * 64;
@@ -682,6 +819,29 @@ static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L, const HsParams &P, i
             auto window = [&](const SorWin &w, int blocks, int sweeps, unsigned runmask, int err_stride) -> int {
                 const SorGrp grp = {runmask, err_stride, ps, snap_stride};
                 const int spw = sor_pick_spw(ctx, G);
+                const size_t lds_need = (size_t) (w.R + 3) * (w.K + 10) * sizeof(double2) +
+                                        (size_t) sor_window_threads(w.R + 3) * w.K * (sizeof(double2) + sizeof(double));
+                if (sor_use_lds(ctx, G) && (w.K == 8 || w.K == 16 || w.K == 24) && w.R + 3 <= 256 && lds_need <= 160 * 1024) {
+                    // the launch window staged in LDS (k_hs_window_lds): one sweep per workgroup, steps on LDS only
+                    const dim3 grid(blocks, sweeps, G), blk(sor_window_threads(w.R + 3));
+                    const int nr = w.R + 3;
+#define OFX_HS_WINL(K_)                                                                                                        \
+    do {                                                                                                                       \
+        const size_t lds = (size_t) nr * HsWinLds<T, K_>::NH * sizeof(double2) + (size_t) blk.x * K_ * (sizeof(double2) + sizeof(double)); \
+        if (lds > 160 * 1024) return ofx_fail(ctx, OFX_ERR_ARG, "hs: window of %d steps x %d rows does not fit the LDS", K_, w.R); \
+        if (lds > 64 * 1024)                                                                                                   \
+            OFX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hs_window_lds<T, K_, 256>),                      \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                          \
+        hipLaunchKernelGGL((k_hs_window_lds<T, K_, 256>), grid, blk, lds, ctx->stream, L.Us, L.Snap, L.As, (const T *) L.Difs, \
+                           ctx->d_err, w, grp, sweeps, nx, ny, alpha2);                                                        \
+    } while (0)
+                    if (w.K == 8) OFX_HS_WINL(8);
+                    else if (w.K == 16) OFX_HS_WINL(16);
+                    else OFX_HS_WINL(24);
+#undef OFX_HS_WINL
+                    OFX_LAUNCH_CHECK(ctx);
+                    return OFX_OK;
+                }
                 const dim3 grid(blocks, ofx_cdiv(sweeps, spw), G), blk(sor_window_threads(w.R + 3));
                 // workgroups of up to 128 threads (the default geometries) are compiled without the 128-VGPR cap that a
                 // 1024-thread bound implies: two sweeps per workgroup keep their operands in registers instead of spilling
@@ -706,7 +866,7 @@ static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L, const HsParams &P, i
                 return OFX_OK;
             };
             OFX_TRY(sor_window_loop(ctx, G, nx * ny, ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, batch, window, take,
-                                    niter, error, 1, &L.sweep_hint));
+                                    niter, error, 1, &L.sweep_hint, sor_use_lds(ctx, G) ? 16 : 0));
             OFX_TRY((op_skew<typename Pix<T>::v2, false>(ctx, L.Us, L.U, nx, ny, HS_PLANE_C_SKEW, G)));
         } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
             // one launch per time step (option sor_exact = 2): the reference implementation of the exact schedule
@@ -1161,21 +1321,30 @@ struct BroxOps {
     double4 co;
     double  D;
 };
+// psi1..4 through a sweep accessor (UGlobal: the arrays; BLds: the launch window in LDS); brox_psi4_lay's arithmetic
+template <typename T, class Acc> OFX_DEV Psi4 brox_psi4_acc(const Acc &acc, const T *Psis, int i, int j, int nx, int ny)
+{
+    const double c = acc.psi(Psis, i, j);
+    Psi4 r;
+    r.p1 = (i < ny - 1) ? 0.5 * (acc.psi(Psis, i + 1, j) + c) : 0.0;
+    r.p2 = (i > 0) ? 0.5 * (acc.psi(Psis, i - 1, j) + c) : 0.0;
+    r.p3 = (j < nx - 1) ? 0.5 * (acc.psi(Psis, i, j + 1) + c) : 0.0;
+    r.p4 = (j > 0) ? 0.5 * (acc.psi(Psis, i, j - 1) + c) : 0.0;
+    return r;
+}
 template <typename T, class Acc>
 OFX_DEV BroxOps brox_point_load(const Acc &acc, const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
                                 const T *__restrict__ Psis, int i, int j, int nx, int ny)
 {
-    const size_t p = acc.lay.idx(i, j);
     BroxOps o;
-    o.s = brox_psi4_lay(Psis, acc.lay, i, j, nx, ny);
+    o.s = brox_psi4_acc<T>(acc, Psis, i, j, nx, ny);
     // a missing neighbour is addressed as the pixel itself (offset 0) with psi = 0, :332-388
     o.c = acc.get(i, j);
     o.dn = (i < ny - 1) ? acc.get(i + 1, j) : o.c;
     o.up = (i > 0) ? acc.get(i - 1, j) : o.c;
     o.rt = (j < nx - 1) ? acc.get(i, j + 1) : o.c;
     o.lf = (j > 0) ? acc.get(i, j - 1) : o.c;
-    o.co = ldw4(CO + p);
-    o.D = ldw(Dm + p);
+    acc.coef4(CO, Dm, i, j, o.co, o.D);
     return o;
 }
 template <typename T, class Acc>
@@ -1343,6 +1512,119 @@ __global__ __launch_bounds__(MAXT) void k_brox_window(typename Pix<T>::v2 *DUg, 
         if (live[u]) loop_accumulate(err, s0 + u, e[u], b * 4 + (threadIdx.x >> 6));
 }
 
+// The Brox sweep with its launch window in LDS (see k_hs_window_lds).  What the KW steps of (sweep, row block b) touch
+// (tools/check_sor_schedule.py --cover): unknowns and psi_s on hyperplanes q0 - 4 .. q0 + KW of the skewed coordinate i + j,
+// rows b R - 2 .. b R + R -- an LDS window each; (CO, Dm) of the KW pixels a thread updates -- LDS slots of its own.
+template <typename T, int KW> struct BroxWinLds {
+    static constexpr int NH = KW + 5;
+    static constexpr int BACK = 4;
+    static size_t bytes(int nr, int nt)
+    {
+        return (size_t) nt * KW * (sizeof(double4) + sizeof(double)) + (size_t) nr * NH * (sizeof(double2) + sizeof(double));
+    }
+};
+template <typename T, bool SNAP> struct BLds {
+    typename Pix<T>::v2 *U, *snap;
+    double2 *win;                                // [NH][nr] (du, dv)
+    const double *ps;                            // [NH][nr] psi_s
+    int nr, row0, h0;
+    LaySkew lay;
+    double4 co;                                  // constant operands of the pixel being updated (set per step)
+    double  D;
+    OFX_DEV double2 get(int ii, int jj) const { return win[(ii + jj - h0) * nr + (ii - row0)]; }
+    OFX_DEV double psi(const T *, int ii, int jj) const { return ps[(ii + jj - h0) * nr + (ii - row0)]; }
+    OFX_DEV void coef4(const typename Pix<T>::v4 *, const T *, int, int, double4 &c, double &D_) const { c = co; D_ = D; }
+    OFX_DEV void put(int i, int j, double2 v) const
+    {
+        win[(i + j - h0) * nr + (i - row0)] = v;
+        const size_t p = lay.idx(i, j);
+        stn2(U + p, v);
+        if (SNAP) stn2(snap + p, v);
+    }
+};
+OFX_DEV bool brox_window_pixel(const SorWin &w, int b, int r, int q, int qmax, int nx, int ny, int &pi, int &pj)
+{
+    return q >= 0 && q <= qmax && r >= 0 && r != ny + 2 && brox_plane_item(r, q, nx, ny, 0, pi, pj) &&
+           (r < ny || sor_border_block(pi, ny, w.R) == b);
+}
+template <typename T, int KW, int MAXT>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_brox_window_lds(
+    typename Pix<T>::v2 *DUg, typename Pix<T>::v2 *snap, const typename Pix<T>::v4 *__restrict__ COg, const T *__restrict__ Dmg,
+    const T *__restrict__ Psisg, double *__restrict__ errg, SorWin w, SorGrp grp, int s_cnt, int nx, int ny, double alpha)
+{
+    using W = BroxWinLds<T, KW>;
+    extern __shared__ double4 brox_lds[];
+    const int b = blockIdx.x, s = w.s_first + blockIdx.y, g = blockIdx.z;
+    if (!((grp.runmask >> g) & 1u)) return;
+    const int qmax = ny + nx - 2;
+    const int q0 = w.tau0 - w.lag_s * s - w.lag_b * b;
+    if (q0 > qmax || q0 + KW - 1 < 0) return;
+    typename Pix<T>::v2 *DU = DUg + g * grp.npix;
+    const typename Pix<T>::v4 *__restrict__ CO = COg + g * grp.npix;
+    const T *__restrict__ Dm = Dmg + g * grp.npix;
+    const T *__restrict__ Psis = Psisg + g * grp.npix;
+    typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) s * grp.npix;
+    double *__restrict__ err = errg + (size_t) g * grp.err_stride;
+    const int nr = w.R + 3, row0 = b * w.R - 2, h0 = q0 - W::BACK, t = threadIdx.x, nt = blockDim.x;
+    double4 *cco = brox_lds;                                     // [KW][nt]: 32-byte entries first (alignment)
+    double2 *win = reinterpret_cast<double2 *>(cco + KW * nt);   // [NH][nr]
+    double *ps = reinterpret_cast<double *>(win + W::NH * nr);   // [NH][nr]
+    double *cdm = ps + W::NH * nr;                               // [KW][nt]
+    const LaySkew lay = {ny, BROX_PLANE_C_SKEW};
+    const int r = sor_window_item(w, b, t, ny);
+    {
+        const int i = row0 + t, ic = i < 0 ? 0 : (i > ny - 1 ? ny - 1 : i);
+        const int hmax = (ny - 1) + nx - 1;
+        double2 u_in[W::NH];
+        double p_in[W::NH], d_in[KW];
+        double4 c_in[KW];
+#pragma unroll
+        for (int k = 0; k < W::NH; k++) {
+            const int h = h0 + k, hc = h < 0 ? 0 : (h > hmax ? hmax : h);
+            u_in[k] = ldw2(DU + (size_t) hc * ny + ic);
+            p_in[k] = ldw(Psis + (size_t) hc * ny + ic);
+        }
+#pragma unroll
+        for (int k = 0; k < KW; k++) {
+            int pi, pj;
+            const bool have = brox_window_pixel(w, b, r, q0 + k, qmax, nx, ny, pi, pj);
+            const size_t p = have ? lay.idx(pi, pj) : 0;
+            c_in[k] = ldw4(CO + p);
+            d_in[k] = ldw(Dm + p);
+        }
+        if (t < nr) {
+#pragma unroll
+            for (int k = 0; k < W::NH; k++) { win[k * nr + t] = u_in[k]; ps[k * nr + t] = p_in[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < KW; k++) { cco[k * nt + t] = c_in[k]; cdm[k * nt + t] = d_in[k]; }
+    }
+    __syncthreads();
+    BLds<T, true> acc = {DU, mysnap, win, ps, nr, row0, h0, lay, make_double4(0.0, 0.0, 0.0, 0.0), 0.0};
+    double e = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < KW; k++) {
+        const int q = q0 + k;
+        int pi, pj;
+        if (brox_window_pixel(w, b, r, q, qmax, nx, ny, pi, pj)) {
+            acc.co = cco[k * nt + t];
+            acc.D = cdm[k * nt + t];
+            e += brox_point_acc<T>(acc, CO, Dm, Psis, pi, pj, nx, ny, alpha);
+        }
+        if (q >= 0 && q <= qmax && r == ny + 2) {
+            for (int corner = 0; corner < 4; corner++)
+                if (brox_plane_item(r, q, nx, ny, corner, pi, pj) && sor_border_block(pi, ny, w.R) == b) {
+                    const size_t p = lay.idx(pi, pj);
+                    acc.co = ldw4(CO + p);
+                    acc.D = ldw(Dm + p);
+                    e += brox_point_acc<T>(acc, CO, Dm, Psis, pi, pj, nx, ny, alpha);
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    loop_accumulate(err, s, e, b * 4 + (t >> 6));
+}
+
 // u += du, v += dv, :398-401
 template <typename T>
 __global__ void k_brox_add(typename Pix<T>::v2 *__restrict__ U, const typename Pix<T>::v2 *__restrict__ DU, int n)
@@ -1457,6 +1739,27 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
                 auto window = [&](const SorWin &w, int blocks, int sweeps, unsigned runmask, int err_stride) -> int {
                     const SorGrp grp = {runmask, err_stride, ps, snap_stride};
                     const int spw = sor_pick_spw(ctx, G);
+                    const size_t lds_need = (size_t) sor_window_threads(w.R + 3) * w.K * (sizeof(double4) + sizeof(double)) +
+                                            (size_t) (w.R + 3) * (w.K + 5) * (sizeof(double2) + sizeof(double));
+                    if (sor_use_lds(ctx, G) && (w.K == 4 || w.K == 8 || w.K == 16) && w.R + 3 <= 256 && lds_need <= 160 * 1024) {
+                        const dim3 grid(blocks, sweeps, G), blk(sor_window_threads(w.R + 3));
+#define OFX_BROX_WINL(K_)                                                                                                      \
+    do {                                                                                                                       \
+        const size_t lds = BroxWinLds<T, K_>::bytes(w.R + 3, (int) blk.x);                                                     \
+        if (lds > 160 * 1024) return ofx_fail(ctx, OFX_ERR_ARG, "brox: window of %d steps x %d rows does not fit the LDS", K_, w.R); \
+        if (lds > 64 * 1024)                                                                                                   \
+            OFX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_brox_window_lds<T, K_, 256>),                    \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                          \
+        hipLaunchKernelGGL((k_brox_window_lds<T, K_, 256>), grid, blk, lds, ctx->stream, L.DUs, L.Snap, L.COs, (const T *) L.Dms, \
+                           (const T *) L.Psiss, ctx->d_err, w, grp, sweeps, nx, ny, P.alpha);                                  \
+    } while (0)
+                        if (w.K == 4) OFX_BROX_WINL(4);
+                        else if (w.K == 8) OFX_BROX_WINL(8);
+                        else OFX_BROX_WINL(16);
+#undef OFX_BROX_WINL
+                        OFX_LAUNCH_CHECK(ctx);
+                        return OFX_OK;
+                    }
                     const dim3 grid(blocks, ofx_cdiv(sweeps, spw), G), blk(sor_window_threads(w.R + 3));
 #define OFX_BROX_WIN(SPW_, MAXT_)                                                                                        \
     hipLaunchKernelGGL((k_brox_window<T, SPW_, MAXT_>), grid, blk, 0, ctx->stream, L.DUs, L.Snap, L.COs, (const T *) L.Dms, \
@@ -1479,7 +1782,7 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
                     return OFX_OK;
                 };
                 OFX_TRY(sor_window_loop(ctx, G, n, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
-                                        take, nsor, error, 1, &L.sweep_hint));
+                                        take, nsor, error, 1, &L.sweep_hint, sor_use_lds(ctx, G) ? 16 : 0));
                 OFX_TRY((op_skew<typename Pix<T>::v2, false>(ctx, L.DUs, L.DU, nx, ny, BROX_PLANE_C_SKEW, G)));
             } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
                 const size_t ub = (size_t) n * sizeof(typename Pix<T>::v2);

@@ -550,6 +550,90 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
                                        y0, yend, ys, yl, lef, rig, owner, off, so, up12, up22, cur, l_t, theta, taut);
 }
 
+// ---- K iterations per launch on a 2-D tile: the small pyramid levels ---------------------------------------------------
+// On a level of a few thousand pixels a launch of the marching kernels is a latency chain: a strip of r rows takes r + 5
+// dependent marching steps of ~2.4 us while most of the chip idles (120x68: 6 us per iteration).  Here the rows are spread
+// over the waves of a workgroup instead: a workgroup owns a region of 64 columns x TILE_RH rows, ONE PIXEL PER THREAD (wave =
+// row, lane = column), the state of its pixel in registers, horizontal neighbours through wave shifts, vertical neighbours
+// through LDS (p12 / p22 to the row below before the primal stage, u_new to the row above before the dual stage: two
+// barriers per iteration).  K iterations run back to back; the dependency cone of an iteration is one pixel in every
+// direction, so the outer K pixels of the region are a recomputed halo and the workgroup stores the inner (64 - 2 K) x
+// (TILE_RH - 2 K) pixels (at the image border the boundary rules cut the cone, nothing more is needed).  Same per-pixel
+// functions in the same order as the marching kernels: bit-identical.  The stopping test looks at the K error slots of the
+// previous launch; a loop that ends inside a launch is finished by re-running the first n - k0 iterations of that launch
+// from its (untouched) input buffers: `nit` holds the iteration count of every pair, 4 bits each.
+#define TILE_RH 16
+template <typename T, bool STRICT, int K>
+__global__ __launch_bounds__(64 * TILE_RH) void k_tvl1_tile(
+    Tri<typename Pix<T>::v2> Ut, Tri<typename Pix<T>::v2> P1t, Tri<typename Pix<T>::v2> P2t,
+    const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int k0, int check, int slot0,
+    int nx, int ny, int tiles_x, double l_t, double theta, double taut, double eps2, unsigned incode, unsigned runmask,
+    unsigned long long nit, int err_stride)
+{
+    using v2 = typename Pix<T>::v2;
+    __shared__ double2 s_p[2][TILE_RH][64];                  // (p12, p22) of every row, double-buffered over iterations
+    __shared__ double2 s_u[2][TILE_RH][64];                  // u_new of every row
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = blockIdx.y;
+    if (!((runmask >> g) & 1u)) return;
+    const int niter = (int) ((nit >> (4 * g)) & 15ull);
+    const size_t npix = (size_t) nx * ny;
+    const TriSel<v2> hu = pick3(Ut, incode, g, npix), h1 = pick3(P1t, incode, g, npix), h2 = pick3(P2t, incode, g, npix);
+    double *__restrict__ err = errg + (size_t) g * err_stride;
+    // error shards of the previous launch's K iterations (fetched first, tested after the loads are issued)
+    double prev[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) prev[i] = (check && k0 - i > 0) ? loop_fetch_prev(err, k0 - i) : 0.0;
+
+    constexpr int OW = 64 - 2 * K, OH = TILE_RH - 2 * K;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int c = tx * OW - K + lane, y = ty * OH - K + w;
+    const int cc = c < 0 ? 0 : (c > nx - 1 ? nx - 1 : c), yc = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
+    const bool inside = (c >= 0) && (c < nx) && (y >= 0) && (y < ny);
+    const bool owner = inside && lane >= K && lane < 64 - K && w >= K && w < TILE_RH - K;
+    const bool lef = (c == 0), rig = (c == nx - 1), top = (y == 0), bot = (y == ny - 1);
+    const size_t p = (size_t) yc * nx + cc;
+    double2 u = ldw2(hu.in + p), p1 = ldw2(h1.in + p), p2 = ldw2(h2.in + p);
+    const double2 a = ldw2(Ag + (size_t) g * npix + p);
+    const double r = ldw(Rg + (size_t) g * npix + p);
+    if (check) {                                            // stopping test of src/tvl1flow.cpp:113 -- the same decision in every wave
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if (k0 - i > 0 && !(loop_error_from_sum(wave_allreduce_sum(prev[i]), nx * ny, OFX_CRIT_MEAN) > eps2)) return;
+    }
+    double acc[K];
+#pragma unroll
+    for (int it = 0; it < K; it++) {
+        acc[it] = 0.0;
+        if (it < niter) {                                    // niter is uniform over the workgroup: the barriers below are, too
+            s_p[it & 1][w][lane] = make_double2(p1.y, p2.y);
+            __syncthreads();
+            const double2 up = s_p[it & 1][w > 0 ? w - 1 : 0][lane];     // row 0 of the region: halo (or the image's top row)
+            const double l11 = wave_shift_up(p1.x), l21 = wave_shift_up(p2.x);
+            const double2 un = tvl1_primal<T>(u, a, r, p1, p2, l11, l21, up.x, up.y, lef, rig, top, bot, l_t, theta);
+            if (owner) acc[it] = (un.x - u.x) * (un.x - u.x) + (un.y - u.y) * (un.y - u.y);   // :159-160
+            s_u[it & 1][w][lane] = un;
+            __syncthreads();
+            const double2 dn = s_u[it & 1][w < TILE_RH - 1 ? w + 1 : w][lane];
+            const double r1 = wave_shift_down(un.x), r2 = wave_shift_down(un.y);
+            double2 q1, q2;
+            tvl1_dual<T, STRICT>(p1, p2, un, r1, r2, dn, rig, bot, taut, q1, q2);
+            u = un;
+            p1 = make_double2(rnd_to<T>(q1.x), rnd_to<T>(q1.y));
+            p2 = make_double2(rnd_to<T>(q2.x), rnd_to<T>(q2.y));
+        }
+    }
+    if (owner) {
+        const size_t po = (size_t) y * nx + c;
+        stn2(hu.out + po, u);
+        stn2(h1.out + po, p1);
+        stn2(h2.out + po, p2);
+    }
+#pragma unroll
+    for (int it = 0; it < K; it++)
+        if (it < niter) loop_accumulate(err, slot0 + it, acc[it], blockIdx.x * TILE_RH + w);
+}
+
 // Warp + linearisation (src/tvl1flow.cpp:94-109): the three bicubic warps of I1, I1x, I1y share one
 // set of tap indices and one 4-wide gather per tap; writes A = (I1wx, I1wy) and R = rho_c.
 // Thread block of the warp kernel: BX x BY pixels, a wave covers BX x (64 / BX) of them.
@@ -852,6 +936,22 @@ static int tvl1_pick_chunk(const ofx_ctx *ctx, int nx, int ny, int G)
     return c < 4 ? 4 : (c > 50 ? 50 : c);
 }
 
+// Levels the tile kernel serves: option "tile" = 0 never, K = 4 | 6 fused iterations when the group's level has at most
+// "tile_max_px" pixels (default: 4 iterations up to 200 000 pixels x pairs -- 480x270 alone, 240x135 in a group of 5).
+static int tvl1_pick_tile(const ofx_ctx *ctx, int nx, int ny, int G)
+{
+    if (!ctx->tile || !ctx->fuse2) return 0;
+    const double lim = ctx->tile_max_px > 0 ? ctx->tile_max_px : 200000.0;
+    if ((double) nx * ny * G > lim) return 0;
+    return ctx->tile == 6 ? 6 : 4;
+}
+
+template <typename T> struct Tvl1Level;
+struct Tvl1Params;
+template <typename T>
+static int tvl1_run_iterations_tile(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, LoopSpec S, int K, int *n_out,
+                                    double *err_out, float *ms_out, int *alt_out);
+
 // The inner loop of one warp (src/tvl1flow.cpp:111-182) for all pairs of the group in lockstep.  On return
 // L.cur points at the halves holding the results; n_out[g] / err_out[g] are what the reference prints.
 template <typename T>
@@ -879,6 +979,9 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
     S.chunk = tvl1_pick_chunk(ctx, nx, ny, G);
     S.fixed = P.fixed;
     S.pairs = pairs;
+    // small levels: K iterations per launch on 2-D tiles (k_tvl1_tile) instead of the marching strips
+    const int tileK = tvl1_pick_tile(ctx, nx, ny, G);
+    if (tileK) return tvl1_run_iterations_tile<T>(ctx, L, P, S, tileK, n_out, err_out, ms_out, alt_out);
     const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
     const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
     // one launch touches 15 storage elements per pixel; beyond the Infinity Cache its output is streamed out
@@ -947,6 +1050,73 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
         cur |= ((b0[g] + units + (took_alt[g] ? 1u : 0u)) % 3u) << (2 * g);
         L.last_n[g] = n_out[g];
         if (alt_out) alt_out[g] = (pairs && (n_out[g] & 1) && n_out[g] != S.max_iter) ? (took_alt[g] ? 2 : 1) : 0;
+    }
+    L.cur = cur;
+    return OFX_OK;
+}
+
+// tvl1_run_iterations through k_tvl1_tile: launch unit j = iterations [j K, j K + K) reads buffer (b_g + j) % 3 and writes
+// (b_g + j + 1) % 3; a loop that ends inside a unit is finished by one more launch that re-runs the unit's first n - j K
+// iterations from its input (every pair with its own count).
+template <typename T>
+static int tvl1_run_iterations_tile(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, LoopSpec S, int K, int *n_out,
+                                    double *err_out, float *ms_out, int *alt_out)
+{
+    const int nx = L.nx, ny = L.ny, G = L.G;
+    const double l_t = P.lambda * P.theta, taut = P.tau / P.theta, theta = P.theta;
+    const bool strict = sizeof(T) == sizeof(double) && !ctx->relaxed_dual;
+    const int OW = 64 - 2 * K, OH = TILE_RH - 2 * K;
+    const int tiles_x = ofx_cdiv(nx, OW), tiles_y = ofx_cdiv(ny, OH);
+    const dim3 grid((unsigned) (tiles_x * tiles_y), G), block(64 * TILE_RH);
+    S.pairs = false;
+    S.fuse = K;
+    S.afac = 0.0;
+    // a launch of K iterations takes ~2 us + K x 1.5 us whatever the level's size; one poll per ~40 us
+    if (ctx->chunk <= 0) S.chunk = 6 * K;
+    const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
+    const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
+    unsigned b0[OFX_MAX_GROUP];
+    for (int g = 0; g < G; g++) b0[g] = L.curidx(g);
+    auto go = [&](int k0, int check, int slot0, double thr, unsigned incode, unsigned runmask, unsigned long long nit) -> int {
+        auto kern = K == 6 ? k_tvl1_tile<T, false, 6> : k_tvl1_tile<T, false, 4>;
+        if constexpr (sizeof(T) == sizeof(double)) {
+            if (strict) kern = K == 6 ? k_tvl1_tile<T, true, 6> : k_tvl1_tile<T, true, 4>;
+        }
+        hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A, (const T *) L.R, ctx->d_err, k0, check,
+                           slot0, nx, ny, tiles_x, l_t, theta, taut, thr, incode, runmask, nit, err_stride);
+        OFX_LAUNCH_CHECK(ctx);
+        return OFX_OK;
+    };
+    auto launch = [&](int k, int cnt, double thr) -> int {
+        unsigned incode = 0;
+        unsigned long long nit = 0;
+        for (int g = 0; g < G; g++) {
+            incode |= ((b0[g] + (unsigned) (k / K)) % 3u) << (2 * g);
+            nit |= (unsigned long long) cnt << (4 * g);
+        }
+        return go(k, 1, k, thr, incode, all, nit);
+    };
+    auto redo = [&](const int *k_of) -> int {
+        unsigned incode = 0, runmask = 0;
+        unsigned long long nit = 0;
+        for (int g = 0; g < G; g++) {
+            if (k_of[g] < 0) continue;
+            const int n = k_of[g] + 1, j = (n - 1) / K;
+            runmask |= 1u << g;
+            incode |= ((b0[g] + (unsigned) j) % 3u) << (2 * g);
+            nit |= (unsigned long long) (n - j * K) << (4 * g);
+        }
+        // no stopping test; the errors go to the scratch slot behind the loop's own (all K of them into it: never read)
+        return go(0, 0, S.max_iter, -1.0, incode, runmask, nit);
+    };
+    int took_alt[OFX_MAX_GROUP];
+    OFX_TRY(ofx_run_loop_group(ctx, S, G, launch, redo, n_out, err_out, ms_out, 0u, took_alt));
+    unsigned cur = 0;
+    for (int g = 0; g < G; g++) {
+        const unsigned units = (unsigned) ((n_out[g] + K - 1) / K);
+        cur |= ((b0[g] + units) % 3u) << (2 * g);
+        L.last_n[g] = n_out[g];
+        if (alt_out) alt_out[g] = 0;
     }
     L.cur = cur;
     return OFX_OK;
@@ -1116,19 +1286,55 @@ extern "C" int ofx_tvl1_multiscale(ofx_ctx *ctx, const double *I0, const double 
 }
 
 // G device-resident pairs in lockstep; stats = G records
+// Is p device memory of this context's GPU?  Everything else -- another GPU's memory, pinned or pageable host memory -- is
+// reached through a staging copy (hipMemcpyDefault resolves the direction; between GPUs it is a peer copy over xGMI).
+static bool ofx_ptr_is_local(const ofx_ctx *ctx, const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void) hipGetLastError();                              // pageable host memory is unknown to the runtime
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice && a.device == ctx->device;
+}
+
 template <typename T>
-static int tvl1_group_devapi(ofx_ctx *ctx, int G, const void *const *dI0, const void *const *dI1, void *const *d_flo,
+static int tvl1_group_devapi(ofx_ctx *ctx, int G, const void *const *dI0_in, const void *const *dI1_in, void *const *d_flo_in,
                              int nx, int ny, const Tvl1Params &P, int nscales, double zfactor, ofx_stats *stats)
 {
+    const size_t n = (size_t) nx * ny;
+    // Images and payloads that do not live on this context's GPU (a batch spread over several GPUs by ofx_tvl1_batch_dev, or
+    // host buffers) are staged: in through arena buffers before the solve, out after it, all on the context's stream.
+    const void *dI0[OFX_MAX_GROUP], *dI1[OFX_MAX_GROUP];
+    void *d_flo[OFX_MAX_GROUP];
+    for (int g = 0; g < G; g++) {
+        const void *src[2] = {dI0_in[g], dI1_in[g]};
+        const void **dst[2] = {&dI0[g], &dI1[g]};
+        for (int k = 0; k < 2; k++) {
+            if (ofx_ptr_is_local(ctx, src[k])) { *dst[k] = src[k]; continue; }
+            T *stage;
+            OFX_TRY(ofx_alloc(ctx, n, &stage));
+            OFX_HIP(ctx, hipMemcpyAsync(stage, src[k], n * sizeof(T), hipMemcpyDefault, ctx->stream));
+            *dst[k] = stage;
+        }
+        d_flo[g] = d_flo_in[g];
+        if (!ofx_ptr_is_local(ctx, d_flo_in[g])) {
+            float2 *stage;
+            OFX_TRY(ofx_alloc(ctx, n, &stage));
+            d_flo[g] = stage;
+        }
+    }
     std::vector<Tvl1Level<T>> lv;
     OFX_TRY(tvl1_multiscale_dev<T>(ctx, G, (const T *const *) dI0, (const T *const *) dI1, nx, ny, P, nscales, zfactor, lv,
                                    stats));
-    const size_t n = (size_t) nx * ny;
     OfxGroupPtrs out;
     for (int g = 0; g < OFX_MAX_GROUP; g++) { out.a[g] = g < G ? d_flo[g] : nullptr; out.b[g] = nullptr; }
     hipLaunchKernelGGL(k_tvl1_to_flo_g<T>, dim3((unsigned) ((n + 255) / 256), G), dim3(256), 0, ctx->stream, lv[0].Ut(), lv[0].cur,
                        out, n);
     OFX_LAUNCH_CHECK(ctx);
+    for (int g = 0; g < G; g++)
+        if (d_flo[g] != d_flo_in[g])
+            OFX_HIP(ctx, hipMemcpyAsync(d_flo_in[g], d_flo[g], n * sizeof(float2), hipMemcpyDefault, ctx->stream));
     return OFX_OK;
 }
 
@@ -1353,8 +1559,11 @@ extern "C" int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *c
                                   double *work_pix_iters)
 {
     if (!ctxs || n_ctx < 1 || n_pairs < 0 || !dI0 || !dI1 || !d_flo) return OFX_ERR_ARG;
+    // The contexts may live on DIFFERENT GPUs of the node (one process, one host thread per context): a group whose images
+    // are not on its context's GPU is staged there and its payloads are copied back into the caller's arrays (tvl1_group_devapi)
+    // -- the C caller's multi-GPU path, no launcher and no collective library needed (pairs are independent).
     for (int w = 0; w < n_ctx; w++)
-        if (!ctxs[w] || ctxs[w]->device != ctxs[0]->device || ctxs[w]->precision != ctxs[0]->precision) return OFX_ERR_ARG;
+        if (!ctxs[w] || ctxs[w]->precision != ctxs[0]->precision) return OFX_ERR_ARG;
     const int G = ofx_tvl1_batch_group_size(ctxs, n_ctx, n_pairs, nx, ny, nscales, zfactor);
     if (G < 1) return G < 0 ? -G : OFX_ERR_ARG;                 // negative = -status of the failing check
     const int n_groups = (n_pairs + G - 1) / G;

@@ -17,6 +17,25 @@ from conftest import aepe
 
 pytestmark = pytest.mark.gpu
 
+# The windowed exact sweeps exist twice: with one global round trip per time step (k_hs_window / k_brox_window, what lockstep
+# groups of >= 4 pairs use) and with the launch window staged in LDS (k_*_window_lds, what a lone solve uses).  Every test
+# runs with both forced (option sor_lds = 0 / 2), the full-size configurations with the default choice only.
+SOR_DEFAULT_ONLY = ("test_cfg3", "test_cfg4", "test_hs_classic")
+
+
+@pytest.fixture(autouse=True, params=[0, 2], ids=["global", "lds"])
+def sor_kernel(request, gpu64, gpu32):
+    if request.node.name.startswith(SOR_DEFAULT_ONLY):
+        if request.param == 0:
+            pytest.skip("full-size case: default kernel choice only")
+        yield 1
+        return
+    for c in (gpu64, gpu32):
+        c.set_option("sor_lds", request.param)
+    yield request.param
+    for c in (gpu64, gpu32):
+        c.set_option("sor_lds", 1)
+
 
 @pytest.fixture()
 def colour_orc(orc, gpu64):
@@ -180,7 +199,8 @@ def test_sor_f32_storage(gpu32, orc, synth):
 
 
 # ---- the two implementations of the exact schedule ----------------------------------------------------------
-@pytest.mark.parametrize("mode,window,rows", [(2, 0, 0), (1, 1, 2), (1, 5, 3), (1, 8, 7), (1, 32, 0), (1, 200, 16), (1, 8, 1000)])
+@pytest.mark.parametrize("mode,window,rows", [(2, 0, 0), (1, 1, 2), (1, 5, 3), (1, 8, 7), (1, 32, 0), (1, 200, 16), (1, 8, 1000),
+                                              (1, 4, 5), (1, 16, 0), (1, 16, 9), (1, 24, 6), (1, 8, 125), (1, 16, 253)])
 def test_exact_schedule_variants_agree_with_reference(gpu64, orc, synth, mode, window, rows):
     """sor_exact = 2: one launch per time step; sor_exact = 1: K time steps per launch (windowed, one workgroup
     per (sweep, row block), snapshots instead of rollback).  Both must reproduce the reference order for any window

@@ -13,6 +13,24 @@ pytestmark = pytest.mark.gpu
 
 PAR = dict(tau=0.25, lam=0.15, theta=0.3)
 
+# Option "tile" = 4 | 6 runs levels of at most 200 000 pixels x pairs with K iterations per launch on 2-D tiles (k_tvl1_tile)
+# instead of the marching-strip kernels (default, tile = 0: the tile kernel measured no faster).  Most images of this file are
+# small enough for the tile kernel at every level, so every test runs twice -- tile = 0 and tile = 4 -- except the full-size
+# ones, which run with the default only.
+FULL_SIZE_ONLY_DEFAULT = ("test_full_size", "test_4k_size", "test_headline_launch_shape", "test_roofline_4k_launch_shape",
+                          "test_batch_dev_on_four_contexts", "test_f32_mode_is_as_accurate", "test_tile_kernel")
+
+
+@pytest.fixture(autouse=True, params=[0, 4], ids=["strips", "tile4"])
+def tile_mode(request, gpu64, gpu32):
+    if request.param != 0 and request.node.name.startswith(FULL_SIZE_ONLY_DEFAULT):
+        pytest.skip("full-size case: default tile setting only")
+    for c in (gpu64, gpu32):
+        c.set_option("tile", request.param)
+    yield request.param
+    for c in (gpu64, gpu32):
+        c.set_option("tile", 0)
+
 
 def linearised_state(orc, synth, nx, ny, seed=0):
     """A realistic inner-loop state: warp a synthetic pair with a small random flow."""
@@ -487,3 +505,90 @@ def test_relaxed_dual_mode_stays_within_the_stated_tolerance(gpu64, orc, synth, 
     us, vs = gpu64.tvl1_multiscale(I0, I1, nscales=5, **PAR)          # back in strict mode: bit-identical again
     assert np.array_equal(gpu64.stats().iterations(), it_o)
     assert np.abs(us - uo).max() < 1e-9 and np.abs(vs - vo).max() < 1e-9
+
+
+@pytest.mark.parametrize("K", [4, 6])
+@pytest.mark.parametrize("nx,ny", [(5, 4), (52, 4), (53, 5), (56, 8), (57, 9), (104, 17), (113, 16), (240, 135), (447, 301)])
+def test_tile_kernel_iterations_bitexact(gpu64, orc, synth, K, nx, ny):
+    """k_tvl1_tile (K = 4 / 6 iterations per launch, output tiles of (64 - 2 K) x (16 - 2 K) pixels): sizes around the tile
+    pitch, iteration counts that end a launch unit early (1, K - 1, K, K + 1, 2 K + 3), against the oracle bit for bit."""
+    u1, u2, p, I1wx, I1wy, rho_c, grad = linearised_state(orc, synth, max(nx, 8), max(ny, 8), seed=5)
+    u1, u2, I1wx, I1wy, rho_c, grad = (np.ascontiguousarray(a[:ny, :nx]) for a in (u1, u2, I1wx, I1wy, rho_c, grad))
+    p = [np.ascontiguousarray(a[:ny, :nx]) for a in p]
+    gpu64.set_option("tile", K)
+    gpu64.set_option("tile_max_px", 1e9)
+    try:
+        for n_iter in (1, K - 1, K, K + 1, 2 * K + 3):
+            go = [x.copy() for x in (u1, u2, *p)]
+            gg = [x.copy() for x in (u1, u2, *p)]
+            e_o = orc.tvl1_iterations(*go, I1wx, I1wy, rho_c, grad, PAR["tau"], PAR["lam"], PAR["theta"], n_iter)
+            e_g = gpu64.tvl1_iterations(*gg, I1wx, I1wy, rho_c, PAR["tau"], PAR["lam"], PAR["theta"], n_iter)
+            for name, a, b in zip(("u1", "u2", "p11", "p12", "p21", "p22"), gg, go):
+                assert np.array_equal(a, b), "%s differs after %d iterations: max %g" % (name, n_iter, np.abs(a - b).max())
+            assert abs(e_g - e_o) <= 1e-12 * max(abs(e_o), 1e-300)
+    finally:
+        gpu64.set_option("tile", 0)
+        gpu64.set_option("tile_max_px", 0)
+
+
+@pytest.mark.parametrize("K", [4, 6])
+@pytest.mark.parametrize("G", [1, 5, 16])
+def test_tile_kernel_groups_stop_inside_launch_units(gpu64, orc, synth, K, G):
+    """whole solves with the tile kernel at EVERY level (tile_max_px lifted): loops that end inside a launch unit are finished
+    by the re-run of the unit's first iterations, every pair of a group with its own count; tables and .flo payloads
+    against the oracle"""
+    import torch
+    nx, ny = 150, 97
+    pairs = [synth.pair("P0" if k % 3 == 2 else "P1", nx, ny, k) for k in range(G)]
+    d0 = [torch.from_numpy(q[0]).cuda() for q in pairs]
+    d1 = [torch.from_numpy(q[1]).cuda() for q in pairs]
+    flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    gpu64.set_option("tile", K)
+    gpu64.set_option("tile_max_px", 1e9)
+    try:
+        st = gpu64.tvl1_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1],
+                                  [flo[k].data_ptr() for k in range(G)], nx, ny, nscales=3, **PAR)
+        gpu64.synchronize()
+    finally:
+        gpu64.set_option("tile", 0)
+        gpu64.set_option("tile_max_px", 0)
+    got = flo.cpu().numpy()
+    rem = set()
+    for k in range(G):
+        uo, vo, it, _ = orc.tvl1_multiscale(pairs[k][0], pairs[k][1], nscales=3, **PAR)
+        assert np.array_equal(st[k].iterations(), it), k
+        assert np.array_equal(got[k], np.stack([uo, vo], axis=-1).astype(np.float32)), k
+        rem.update(int(x) % K for x in np.asarray(it).ravel())
+    assert len(rem) > 1            # the loops really end at different positions inside a launch unit
+
+
+def test_batch_dev_stages_images_that_are_not_on_the_contexts_gpu(ofx_mod, gpu64, synth):
+    """ofx_tvl1_batch_dev accepts contexts on different GPUs (the C caller's multi-GPU path): a group whose images / payload
+    arrays are not device memory of its context's GPU is staged through the context's arena and copied back.  On the one-GPU
+    box the foreign memory is the host's -- pageable numpy arrays in, a pinned torch tensor and a pageable array out --; the
+    payloads must equal the device-resident solves.  (Peer copies between GPUs take the same hipMemcpyDefault path;
+    unmeasured on hardware here.)"""
+    import torch
+    nx, ny, N = 160, 120, 5
+    kw = dict(nscales=3, warps=3, **PAR)
+    host = [synth.pair("P1", nx, ny, k) for k in range(N)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in host]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in host]
+    want, _ = _solo_flows(gpu64, d0, d1, nx, ny, **kw)
+    pinned = torch.zeros((N, ny, nx, 2), dtype=torch.float32).pin_memory()
+    pageable = np.zeros((N, ny, nx, 2), dtype=np.float32)
+    h0 = [np.ascontiguousarray(p[0]) for p in host]
+    h1 = [np.ascontiguousarray(p[1]) for p in host]
+    ctxs = [ofx_mod.Ofx(0, ofx_mod.F64) for _ in range(2)]
+    try:
+        for out_ptrs in ([pinned[k].data_ptr() for k in range(N)], [pageable[k].ctypes.data for k in range(N)]):
+            # inputs: pairs 0, 1 pageable host arrays, pair 2 device-resident, pairs 3, 4 mixed
+            i0 = [h0[0].ctypes.data, h0[1].ctypes.data, d0[2].data_ptr(), d0[3].data_ptr(), h0[4].ctypes.data]
+            i1 = [h1[0].ctypes.data, h1[1].ctypes.data, d1[2].data_ptr(), h1[3].ctypes.data, d1[4].data_ptr()]
+            ofx_mod.tvl1_batch_dev(ctxs, i0, i1, out_ptrs, nx, ny, **kw)
+        assert np.array_equal(pinned.numpy().view(np.int32), want.cpu().numpy().view(np.int32))
+        assert np.array_equal(pageable.view(np.int32), want.cpu().numpy().view(np.int32))
+    finally:
+        for c in ctxs:
+            c.close()

@@ -158,6 +158,27 @@ def test_windowed_sor_schedule_is_valid():
             assert mod.check(nx, ny, K, B, solver, 2) == 0
 
 
+def test_lds_windows_of_the_sor_kernels_cover_every_access():
+    """k_hs_window_lds / k_brox_window_lds copy a launch's working set into LDS when the launch starts.  The windows they
+    stage -- HsWinLds: unknowns on hyperplanes q0 - 7 .. q0 + K + 2, coefficients q0 - 7 .. q0 + K - 1; BroxWinLds: q0 - 4 ..
+    q0 + K and q0 - 4 .. q0 + K - 1; rows b R - 2 .. b R + R -- must contain everything the K steps touch, border pixels
+    included (tools/check_sor_schedule.py cover() enumerates the accesses; also for K = 16 / 24, the new defaults)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_sor_schedule", os.path.join(ROOT, "tools", "check_sor_schedule.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for solver, back, ahead in (("hs", 7, 2), ("brox", 4, 0)):
+        for nx, ny, R in [(23, 30, 8), (9, 12, 3), (40, 17, 5), (5, 5, 2), (3, 3, 2), (12, 40, 64)]:
+            for K in (4, 8, 16, 24):
+                hmin, hmax, rmin, rmax, cmin, cmax = mod.cover(nx, ny, K, R, solver)
+                assert hmin >= -back and hmax <= K + ahead, (solver, nx, ny, R, K, hmin, hmax)
+                assert rmin >= -2 and rmax <= R, (solver, nx, ny, R, K, rmin, rmax)
+                assert cmin >= -back and cmax <= K - 1, (solver, nx, ny, R, K, cmin, cmax)
+    for solver in ("hs", "brox"):                          # the schedule itself with the larger windows
+        for nx, ny, K, B in [(23, 30, 16, 3), (16, 9, 24, 2), (9, 12, 16, 1)]:
+            assert mod.check(nx, ny, K, B, solver, 2) == 0
+
+
 def test_flo_reader_on_the_reference_own_flow_file(io):
     """tests/golden/ipol_tvl1flow_3_uv.flo is the one data file the reference ships (3rdparty/tvl1flow_3/uv.flo,
     a 256x256 flow written by the IPOL original's iio; its input images were removed upstream, so it pins the

@@ -24,6 +24,7 @@ for a in sys.argv[1:]:
     if a.startswith("--grid="):                              # e.g. --grid=1x16,2x16
         GRID = [tuple(int(x) for x in g.split("x")) for g in a.split("=")[1].split(",")]
 nowarm = "--no-warm" in sys.argv
+OPTS = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--opt=")]      # --opt=name=value for every context
 for name, (nx, ny), bpp, kw in CONFIGS:
     if only and name not in only:
         continue
@@ -36,6 +37,8 @@ for name, (nx, ny), bpp, kw in CONFIGS:
         ctxs = [ofx.Ofx(0, ofx.F64) for _ in range(nctx)]
         for c in ctxs:
             c.set_option("lockstep", G)
+            for o in OPTS:
+                c.set_option(o.split("=")[0], float(o.split("=")[1]))
         n = max(NPAIRS, nctx * G)
         args = ([t[0].data_ptr() for t in ins[:n]], [t[1].data_ptr() for t in ins[:n]], [flo[k].data_ptr() for k in range(n)], nx, ny)
         if not nowarm:

@@ -82,7 +82,68 @@ def check(nx, ny, K, B, solver, m, verbose=False):
                     if verbose and bad<4: print("viol",solver,nx,ny,K,B,m,(i,j),(ii,jj),tx,ty,before)
     return bad
 
+def cover(nx, ny, K, R, solver):
+    """What the K steps of one launch of a (sweep, row block) workgroup touch, relative to the launch's first local step q0
+    and the block's first row b R: (hmin, hmax) = range of (skewed hyperplane c i + j) - q0 over all unknowns read or
+    written, (rmin, rmax) = range of row - b R, (cmin, cmax) = hyperplane range of the updated pixels themselves (their
+    coefficients).  k_hs_window_lds / k_brox_window_lds stage exactly these windows in LDS (HsWinLds / BroxWinLds)."""
+    if solver == "hs":
+        cs = 2
+        def pos(i, j):
+            if (i, j) == (0, 0): return 7
+            if (i, j) == (0, nx - 1): return nx + 4
+            if (i, j) == (ny - 1, 0): return 2 * ny + 1
+            if (i, j) == (ny - 1, nx - 1): return 2 * ny + nx - 2
+            if i == 0: return j + 4
+            if i == ny - 1: return 2 * (ny - 1) + j
+            if j == 0: return 2 * i + 4
+            if j == nx - 1: return 2 * i + nx + 1
+            return 2 * i + j
+        nbrs = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1), (0, 0)]
+    else:
+        cs = 1
+        def pos(i, j):
+            if (i, j) == (0, 0): return 4
+            if (i, j) == (0, nx - 1): return nx + 1
+            if (i, j) == (ny - 1, 0): return ny + 1
+            if (i, j) == (ny - 1, nx - 1): return ny + nx - 2
+            if i == 0: return j + 2
+            if i == ny - 1: return ny - 1 + j
+            if j == 0: return i + 2
+            if j == nx - 1: return i + nx - 1
+            return i + j
+        nbrs = [(-1, 0), (0, -1), (0, 1), (1, 0), (0, 0)]
+    def blk(i, j):                                   # the kernels' rule (sor_window_item / sor_border_block)
+        if i == 0 and (j == 0 or j == nx - 1): r = min(2, ny - 1)
+        elif i == ny - 1: r = ny - 1
+        elif i == 0: r = 0
+        elif j == 0 or j == nx - 1: r = min(i + 1, ny - 1)
+        else: r = i
+        return r // R
+    big = 10 ** 9
+    hmin = rmin = cmin = big
+    hmax = rmax = cmax = -big
+    for i in range(ny):
+        for j in range(nx):
+            b, q = blk(i, j), pos(i, j)
+            for q0 in range(q - K + 1, q + 1):       # the launch may start up to K - 1 steps before this pixel's step
+                for di, dj in nbrs:
+                    ii, jj = min(max(i + di, 0), ny - 1), min(max(j + dj, 0), nx - 1)
+                    d = cs * ii + jj - q0
+                    hmin, hmax = min(hmin, d), max(hmax, d)
+                    rmin, rmax = min(rmin, ii - b * R), max(rmax, ii - b * R)
+                d = cs * i + j - q0
+                cmin, cmax = min(cmin, d), max(cmax, d)
+    return hmin, hmax, rmin, rmax, cmin, cmax
+
+
 if __name__ == "__main__":
+    if "--cover" in sys.argv:
+        for solver in ("hs", "brox"):
+            for nx, ny, R in [(23, 52, 8), (40, 31, 7), (64, 64, 16), (17, 9, 3), (9, 33, 64), (5, 5, 2), (3, 3, 2), (100, 20, 5)]:
+                for K in (4, 8, 16, 24):
+                    print(solver, "%dx%d" % (nx, ny), "R", R, "K", K, cover(nx, ny, K, R, solver))
+        sys.exit(0)
     bad = 0
     for solver in ("hs", "brox"):
         for nx, ny in [(23, 52), (36, 37), (7, 9), (5, 5), (40, 11), (12, 64), (3, 8)]:
