@@ -42,6 +42,12 @@ sys.path.insert(0, ROOT)
 PAR = dict(tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5, epsilon=0.01)
 ELEM = {"f64": 8.0, "f32": 4.0}
 HBM_PEAK_GBS = 8000.0
+ARITH = {"strict": "f64 storage and arithmetic, every per-pixel operation in the reference's IEEE order (glibc-exact hypot, IEEE divisions): "
+                   "flows and iteration tables bit-identical to the reference (tests/test_gpu_tvl1.py)",
+         "tolerance": "f64 storage and arithmetic; in the dual update sqrt(x^2 + y^2) for libm's hypot and one reciprocal per denominator "
+                      "(rsq / rcp + Newton steps, <= 1 ulp each), primal division by reciprocal: not bit-identical -- AEPE vs the "
+                      "reference ~1e-12 px on every BASELINE config (profiles/r03_*_relaxed_dual_accuracy.jsonl, bar: 1e-4), iteration "
+                      "tables equal on all of them"}
 WORKLOADS = {"1080p": (1920, 1080), "4k-batch": (3840, 2160)}
 
 
@@ -54,12 +60,17 @@ def parse():
                     help="repetitions of the timed K-step region (each one bracketed by barrier + sync); the median one is reported")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--mode", choices=["tolerance", "strict"], default="tolerance",
+                    help="f64 arithmetic of the headline: 'tolerance' = the dual update without its last-bit fidelity (sqrt(x^2+y^2), "
+                         "reciprocals; AEPE vs the reference ~1e-12, north_star's bar 1e-4), 'strict' = bit-identical to the "
+                         "reference.  The other mode is measured beside it (object `strict` / `tolerance`)")
     ap.add_argument("--nx", type=int, default=0, help="override the workload's image width (tests / rehearsals)")
     ap.add_argument("--ny", type=int, default=0)
     ap.add_argument("--pair", default="P1")
     ap.add_argument("--fixed-steps", type=int, default=2, help="fixed-work passes for the roofline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-4k", action="store_true", help="skip the roofline_4k leg")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the leg that repeats the timed command in the other f64 mode")
     ap.add_argument("--no-single", action="store_true", help="skip the single_pair leg (one pair at a time, device-resident and host entry)")
     ap.add_argument("--no-sor", action="store_true", help="skip the sor leg (BASELINE configs 3 / 4)")
     ap.add_argument("--no-occ", action="store_true", help="skip the occ leg (TV-L1 with occlusions, SURVEY 8f.1)")
@@ -128,9 +139,10 @@ def split_rounds(n, rounds, nstreams):
     return out
 
 
-def cpu_baseline(synth, nx, ny, pair):
+def cpu_baseline(synth, nx, ny, pair, gpu_flows=None):
     """Reference (oracle/_ref) on the host cores: a bounded sample of the 1080p workload (4 pairs through the multiscale
-    call) + the inner loop alone."""
+    call) + the inner loop alone.  gpu_flows(k, I0, I1) -> {mode: (u, v)}: the GPU's flows of the same pairs, compared with
+    the reference's (AEPE, the parity bar of north_star)."""
     import oracle
     if oracle.have_ref():
         cpu = oracle.Ref()
@@ -145,14 +157,25 @@ def cpu_baseline(synth, nx, ny, pair):
     NPAIR = 4
     pairs = [synth.pair(pair, nx, ny, k) for k in range(NPAIR)]
     t0 = time.perf_counter()
+    ref_flows = []
     for I0, I1 in pairs:
-        cpu.tvl1_multiscale(I0, I1, **PAR)
+        r_ = cpu.tvl1_multiscale(I0, I1, **PAR)
+        ref_flows.append((r_[0], r_[1]))
     t_ms = time.perf_counter() - t0
     log("cpu_baseline: %d multiscale calls %.2f s" % (NPAIR, t_ms))
     out = {"unit": "Mpix*warp-iters/s", "cores": cores, "kind": cpu.kind,
            "sample": "%d pairs %s %dx%d (batch variants 0..%d), same parameters, Dual_TVL1_optic_flow_multiscale (%.2f s)"
                      % (NPAIR, pair, nx, ny, NPAIR - 1, t_ms), "seconds": round(t_ms, 3),
            "build": "-O3 -fopenmp, generic x86-64"}
+    if gpu_flows is not None:
+        par = {}
+        for k, ((I0, I1), (ur, vr)) in enumerate(zip(pairs, ref_flows)):
+            for mode, (ug, vg) in gpu_flows(k, I0, I1).items():
+                e = par.setdefault(mode, {"aepe_max": 0.0, "max_abs": 0.0})
+                e["aepe_max"] = max(e["aepe_max"], float(np.mean(np.hypot(ug - ur, vg - vr))))
+                e["max_abs"] = max(e["max_abs"], float(max(np.abs(ug - ur).max(), np.abs(vg - vr).max())))
+        out["gpu_vs_this_reference_run"] = dict(par, pairs=NPAIR, tolerance_aepe=1e-4,
+                                                note="flows of the same %d pairs on the GPU against the reference's, per f64 mode" % NPAIR)
     # work of those calls: iteration counts from the port (bit-identical loop, OMP_NUM_THREADS=1 parity-tested)
     if port is not None:
         port.set_num_threads(cores)
@@ -189,7 +212,7 @@ def load_pmc():
         return {}
 
 
-def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None):
+def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None, mode="strict"):
     """Fixed-work passes with HIP events (on the library's stream) around the iteration launches of every level: of ONE pair
     alone (per-level table, `single_pair`), and -- group = (G, solve_group) -- of a lockstep group of G pairs, which is how
     the timed region launches the kernel (one launch = G pairs; blockIdx.y/z = pair).  The roofline is quoted on the group
@@ -253,13 +276,32 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None):
             "algorithmic_equivalent_frac": round(equiv / HBM_PEAK_GBS, 4),
             "algorithmic_equivalent_note": "SURVEY 8(d): 15 elements/px per ITERATION x 2 iterations per launch; the rate an "
                                            "unfused kernel would need -- may exceed the HBM peak, not a bandwidth",
-            "mpix_iters_per_s": round(2.0 * G * nx * ny / us_launch, 1)}
+            "mpix_iters_per_s": round(2.0 * G * nx * ny / us_launch, 1), "arithmetic_mode": mode if precision == "f64" else "f32"}
     if group:
         a1 = fused / (us_single * 1e-6) / 1e9
         roof["single_pair"] = {"avg_launch_us": round(us_single, 3), "achieved": round(a1, 1), "frac": round(a1 / HBM_PEAK_GBS, 4),
                                "note": "the same kernel launched for one pair alone: start-up and drain of every launch exposed "
                                        "(at 1080p one pair is 2880 waves, less than one round of the 3072 wave slots)"}
     pmc = load_pmc()
+    # round-3 counter passes on the group launches, per f64 mode (tools/pmc_round3.sh): preferred when they cover this launch
+    try:
+        r3 = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_group_launches.json"))).get("%dx%d_group%d_%s" % (nx, ny, G, mode))
+    except Exception:
+        r3 = None
+    if r3 and precision == "f64":
+        roof["traffic"] = r3["bytes_per_launch"]
+        roof["traffic_source"] = ("profiles/r03_pmc_group_launches.json (builder-run rocprofv3 --pmc passes on the same launch shape and "
+                                  "mode, FETCH_SIZE doubled per MI355X_MICROARCH.md; not measured by this run)")
+        roof["hbm_frac_counter"] = round(r3["bytes_per_launch"] / (us_launch * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        roof["traffic_over_compulsory"] = round(r3["traffic_over_fused_compulsory"], 4)
+        roof["valu_active"] = round(r3["valu_active_fraction"], 3)
+        roof["limiter"] = ("strict kernel: co-limited by FP64 issue (VALU active 0.70) and memory (counter traffic 5.6-5.7 TB/s at the counter "
+                           "pass's launch time)" if mode == "strict" else
+                           "tolerance kernel: memory-bound -- counter traffic 6.0 (1080p) / 6.3 (4K) TB/s at the counter pass's launch time, "
+                           "the rate the guide gives as achievable for HBM3E on this part; VALU active 0.45-0.48")
+        levels = [{"size": "%dx%d" % (st.nx[s_], st.ny[s_]), "iter_us": round(lv_ms[s_] * 1e3 / max(lv_n[s_], 1), 2),
+                   "ms_per_step": round(lv_ms[s_] / passes, 2)} for s_ in range(ns)]
+        return roof, levels, work, secs
     key = "%s_%dx%d" % (precision, nx, ny)
     tr = pmc.get("bytes_per_launch_group%d_%s" % (G, key)) if G > 1 else pmc.get("bytes_per_launch_" + key)
     src = "profiles/pmc_traffic.json (builder-run rocprofv3 --pmc passes, not measured by this run)"
@@ -273,11 +315,17 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None):
         roof["traffic"] = tr
         roof["traffic_source"] = src
         roof["hbm_frac_counter"] = round(tr / (us_launch * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-        if "valu_active_fraction" in det:
+        if "valu_active_fraction" in det and mode == "strict":
             roof["valu_active"] = round(det["valu_active_fraction"], 3)
+        if mode != "strict":
+            roof["traffic_source"] += "; counter passes ran the strict kernel, which moves the same streams"
     lim = pmc.get("limiter_" + key) or pmc.get("limiter")
-    if lim:
+    if lim and mode == "strict":
         roof["limiter"] = lim
+    elif mode == "tolerance":
+        roof["limiter"] = ("tolerance-mode kernel: ~30 % fewer FP64 instructions than the strict one (no glibc-exact hypot, reciprocals "
+                           "instead of IEEE quotients), same memory streams -- closer to the memory ceiling of the strict kernel's "
+                           "co-limited profile (profiles/r02_a_iter2_ceilings_alu_mem.txt)")
     levels = [{"size": "%dx%d" % (st.nx[s_], st.ny[s_]), "iter_us": round(lv_ms[s_] * 1e3 / max(lv_n[s_], 1), 2),
                "ms_per_step": round(lv_ms[s_] / passes, 2)} for s_ in range(ns)]
     return roof, levels, work, secs
@@ -422,6 +470,7 @@ def main():
             c_.set_option("chunk", a.chunk)
         if a.rows2:
             c_.set_option("rows_per_wave2", a.rows2)
+        c_.set_option("relaxed_dual", 1 if a.mode == "tolerance" else 0)
         for kv in a.opt:
             c_.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     nrounds = a.rounds if a.rounds > 0 else (2 if (world > 1 and nsteps >= 32) else 1)
@@ -569,6 +618,24 @@ def main():
         odd = {"loops": gsz * PAR["nscales"] * PAR["warps"], "odd_stops": sum(s_.odd_stops for s_ in st_),
                "served_from_stored_state": sum(s_.odd_stops_stored for s_ in st_)}
 
+    # ---- the other f64 mode on the same command (same pairs, same grouping, same repetitions) ---------------------------------
+    other = None
+    other_name = "strict" if a.mode == "tolerance" else "tolerance"
+    if world == 1 and nsteps > 0 and not a.no_other_mode:
+        for c_ in ctxs:
+            c_.set_option("relaxed_dual", 1 if other_name == "tolerance" else 0)
+        run_pairs(0, min(in_flight, max(nsteps, 1)))            # warm
+        oreps = [timed_region() for _ in range(max(1, a.reps))]
+        osec = sorted(r_[0] for r_ in oreps)
+        omid = osec[(len(osec) - 1) // 2]
+        owork = oreps[0][2]
+        other = {"value": round(owork / omid / 1e6, 1), "unit": "Mpix*warp-iters/s", "ms_per_step": round(omid / max(nsteps, 1) * 1e3, 3),
+                 "seconds": [round(x, 5) for x in osec], "pix_iters_per_step": owork / max(nsteps, 1),
+                 "arithmetic": ARITH[other_name]}
+        for c_ in ctxs:
+            c_.set_option("relaxed_dual", 1 if a.mode == "tolerance" else 0)
+        log("%s mode on the same command: %.1f (median of %s s)" % (other_name, other["value"], other["seconds"]))
+
     # ---- one pair at a time (BASELINE configs[0] / [1] read literally: what bin/tvl1flow runs) ---------------------------
     single = None
     if rank == 0 and nsteps > 0 and not a.no_single:
@@ -630,7 +697,7 @@ def main():
         def grp():
             return ctx.tvl1_group_dev([dI0s[var_of(i)].data_ptr() for i in range(gsz)], [dI1s[var_of(i)].data_ptr() for i in range(gsz)],
                                       [flo[i].data_ptr() for i in range(gsz)], nx, ny, **PAR)
-        roof, levels, fw, tf = roofline_of(ctx, one, a.precision, nx, ny, a.fixed_steps, (gsz, grp) if gsz > 1 else None)
+        roof, levels, fw, tf = roofline_of(ctx, one, a.precision, nx, ny, a.fixed_steps, (gsz, grp) if gsz > 1 else None, a.mode)
         ctx.set_option("concurrency", a.concurrency or nstreams)
         log("fixed-work pass: %d steps in %.3f s" % (a.fixed_steps, tf))
         fixed = {"value": round(fw_par / tq / 1e6, 1), "unit": "Mpix*warp-iters/s",
@@ -654,7 +721,7 @@ def main():
             def grp4k():
                 return ctx.tvl1_group_dev([j0.data_ptr()] + [t[0].data_ptr() for t in jj], [j1.data_ptr()] + [t[1].data_ptr() for t in jj],
                                           [f4.data_ptr()] + [t.data_ptr() for t in ff], 3840, 2160, **PAR)
-            roof4k, lv4, fw4, tf4 = roofline_of(ctx, one4k, a.precision, 3840, 2160, 1, (g4, grp4k))
+            roof4k, lv4, fw4, tf4 = roofline_of(ctx, one4k, a.precision, 3840, 2160, 1, (g4, grp4k), a.mode)
             del jj, ff
             roof4k["single_pair_fixed_work"] = {"value": round(fw4 / tf4 / 1e6, 1), "unit": "Mpix*warp-iters/s", "levels": lv4}
             ctx.set_option("concurrency", a.concurrency or nstreams)
@@ -674,7 +741,15 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cnx, cny = WORKLOADS["1080p"] if strong else (nx, ny)
-        cpu = cpu_baseline(synth, cnx, cny, a.pair)
+
+        def gpu_flows(k, I0, I1):
+            res = {}
+            for m_ in ("strict", "tolerance"):
+                ctx.set_option("relaxed_dual", 1 if m_ == "tolerance" else 0)
+                res[m_] = ctx.tvl1_multiscale(I0, I1, **PAR)
+            ctx.set_option("relaxed_dual", 1 if a.mode == "tolerance" else 0)
+            return res
+        cpu = cpu_baseline(synth, cnx, cny, a.pair, gpu_flows if a.precision == "f64" else None)
 
     if world > 1:
         dist.barrier()
@@ -697,6 +772,7 @@ def main():
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": a.precision, "data": "synthetic",
         "config": {"workload": wl, "workload_name": a.workload,
+                   "arithmetic_mode": a.mode if a.precision == "f64" else "f32 fast mode", "arithmetic": ARITH[a.mode] if a.precision == "f64" else "float storage",
                    "pairs_per_gpu": slots, "pairs_in_flight_per_gpu": min(in_flight, max(nsteps, 1)), "lockstep_group": lockstep,
                    "streams_per_gpu": nstreams, "distinct_pairs": total_steps if strong else nvar,
                    "rounds_per_gpu": [c for _, c in rounds],
@@ -710,6 +786,8 @@ def main():
     line["repetitions"] = {"n": len(rep_s), "seconds": [round(x, 5) for x in rep_s], "reported": "median repetition",
                            "value_min": round(min(vals), 1), "value_max": round(max(vals), 1),
                            "spread_pct": round(100.0 * (max(vals) - min(vals)) / max(min(vals), 1e-9), 2)}
+    if other:
+        line[other_name] = other
     if single:
         line["single_pair"] = single
     if odd:

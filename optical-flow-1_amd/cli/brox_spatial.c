@@ -65,6 +65,7 @@ int main(int argc, char *argv[])
     if (s != OFX_OK) fprintf(stderr, "ERROR: %s (%s)\n", ofx_strerror(s), ofx_last_error(ctx));
     else (void) cli_save_flow(outfile, u, v, nx, ny);
     free(u); free(v); free(I1); free(I2);
+    cli_write_stats(ctx, argv[0]);
     ofx_ctx_destroy(ctx);
     return 0;
 }

@@ -90,6 +90,7 @@ int main(int argc, char *argv[])
         }
     }
     free(u); free(v); free(I);
+    cli_write_stats(ctx, argv[0]);
     ofx_ctx_destroy(ctx);
     return 0;
 }

@@ -34,6 +34,7 @@ int main(int argc, char *argv[])
         rc = EXIT_FAILURE;
     }
     free(u); free(a); free(b);
+    cli_write_stats(ctx, argv[0]);
     ofx_ctx_destroy(ctx);
     return rc;
 }

@@ -65,6 +65,7 @@ int main(int argc, char *argv[])
         rc = EXIT_FAILURE;
     }
     free(u); free(I1); free(I2);
+    cli_write_stats(ctx, argv[0]);
     ofx_ctx_destroy(ctx);
     return rc;
 }

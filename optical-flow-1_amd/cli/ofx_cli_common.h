@@ -9,7 +9,8 @@
 #include "ofx.h"
 #include "ofx_io.h"
 
-/* OFX_DEVICE = GPU index (default 0); OFX_PRECISION = f64 (default, strict) | f32 (float storage) */
+/* OFX_DEVICE = GPU index (default 0); OFX_PRECISION = f64 (default, strict) | f32 (float storage); OFX_TOLERANCE=1: the f64
+ * tolerance mode of the TV-L1 dual update (option relaxed_dual; not byte-identical .flo files); OFX_STATS: see cli_write_stats */
 static ofx_ctx *cli_context(void)
 {
     const char *d = getenv("OFX_DEVICE"), *p = getenv("OFX_PRECISION");
@@ -21,7 +22,36 @@ static ofx_ctx *cli_context(void)
         fprintf(stderr, "ERROR: cannot create a GPU context on device %d: %s\n", dev, ofx_strerror(s));
         return NULL;
     }
+    if (getenv("OFX_STATS")) ofx_set_option(ctx, "profile", 1);       /* HIP-event times of the iteration launches per scale */
+    if (getenv("OFX_TOLERANCE")) ofx_set_option(ctx, "relaxed_dual", atoi(getenv("OFX_TOLERANCE")) != 0);
     return ctx;
+}
+
+/* OFX_STATS=path (or "-" for stderr): the work record of the solve as one JSON object -- what the reference only prints as
+ * text when `verbose` (src/tvl1flow.cpp:184-188,284-286: scale sizes, iterations and error per warp), plus the kernel time
+ * of the iteration launches per scale and the wall time of the call.  Nothing is written when the variable is unset. */
+__attribute__((unused)) static void cli_write_stats(const ofx_ctx *ctx, const char *program)
+{
+    const char *path = getenv("OFX_STATS");
+    ofx_stats st;
+    if (!path || !*path || ofx_get_stats(ctx, &st) != OFX_OK) return;
+    FILE *f = strcmp(path, "-") ? fopen(path, "w") : stderr;
+    if (!f) { fprintf(stderr, "warning: cannot write OFX_STATS file \"%s\"\n", path); return; }
+    const char *base = strrchr(program, '/');
+    fprintf(f, "{\"program\": \"%s\", \"nscales\": %d, \"solves_per_scale\": %d, \"work_pix_iters\": %.17g, \"total_ms\": %.6g, "
+               "\"odd_stops\": %d, \"odd_stops_served_from_stored_state\": %d, \"scales\": [",
+            base ? base + 1 : program, st.nscales, st.nsolves, st.work_pix_iters, st.total_ms, st.odd_stops, st.odd_stops_stored);
+    const int ns = st.nscales < OFX_MAX_SCALES ? st.nscales : OFX_MAX_SCALES;
+    const int nw = st.nsolves < OFX_MAX_SOLVES ? st.nsolves : OFX_MAX_SOLVES;
+    for (int s = 0; s < ns; s++) {
+        fprintf(f, "%s{\"scale\": %d, \"nx\": %d, \"ny\": %d, \"iterations\": [", s ? ", " : "", s, st.nx[s], st.ny[s]);
+        for (int w = 0; w < nw; w++) fprintf(f, "%s%d", w ? ", " : "", st.iters[s][w]);
+        fprintf(f, "], \"error\": [");
+        for (int w = 0; w < nw; w++) fprintf(f, "%s%.17g", w ? ", " : "", st.error[s][w]);
+        fprintf(f, "], \"iteration_kernel_ms\": %.6g}", st.iter_ms[s]);
+    }
+    fprintf(f, "]}\n");
+    if (f != stderr) fclose(f);
 }
 
 /* ---- positional, optional, silently-corrected arguments ----------------------------------------------------------------

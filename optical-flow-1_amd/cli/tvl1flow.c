@@ -73,6 +73,7 @@ int main(int argc, char *argv[])
         rc = EXIT_FAILURE;
     }
     free(u); free(I0); free(I1);
+    cli_write_stats(ctx, argv[0]);
     ofx_ctx_destroy(ctx);
     return rc;
 }

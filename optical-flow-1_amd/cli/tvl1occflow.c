@@ -90,7 +90,8 @@ int main(int argc, char *argv[])
             }
         }
         free(u); free(occ);
-        ofx_ctx_destroy(ctx);
+        cli_write_stats(ctx, argv[0]);
+    ofx_ctx_destroy(ctx);
     }
     for (int k = 0; k < 4; k++) free(img[k]);
     return rc;

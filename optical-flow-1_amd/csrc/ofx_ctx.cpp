@@ -68,6 +68,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->concurrency = 1;
     ctx->lockstep = 0;
     ctx->warp_lds = 1;
+    ctx->gauss_fused = 1;
     ctx->relaxed_dual = 0;
     ctx->tile = 0;              // measured: no faster than the marching strips on the small levels, off by default
     ctx->tile_max_px = 0;
@@ -168,6 +169,7 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
         return OFX_OK;
     }
     if (!strcmp(name, "relaxed_dual")) { ctx->relaxed_dual = value != 0; return OFX_OK; }
+    if (!strcmp(name, "gauss_fused")) { ctx->gauss_fused = value != 0; return OFX_OK; }
     if (!strcmp(name, "warp_lds")) { ctx->warp_lds = value != 0; return OFX_OK; }
     if (!strcmp(name, "nt_stores")) { ctx->nt_stores = (int) value; return (value >= 0 && value <= 2) ? OFX_OK : ofx_fail(ctx, OFX_ERR_ARG, "nt_stores = 0 | 1 | 2"); }
     if (!strcmp(name, "lockstep")) {

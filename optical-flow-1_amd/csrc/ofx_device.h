@@ -186,6 +186,14 @@ OFX_DEV double sqrt_unscaled(double x)
     d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
 }
+OFX_DEV double rcp_newton(double d)              // 1 / d to <= 1 ulp for normal d well inside the exponent range
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
 OFX_DEV double div_unscaled(double n, double d)
 {
     double r = __builtin_amdgcn_rcp(d);

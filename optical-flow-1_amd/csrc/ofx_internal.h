@@ -65,6 +65,7 @@ struct ofx_ctx {
                         // the "tolerance" mode, AEPE vs the reference ~1e-9..1e-6, not bit-identical; 0 (default) strict
     int tile;           // TV-L1 small levels: K iterations per launch on 2-D tiles (k_tvl1_tile): 4 | 6 | 0 = off (default)
     double tile_max_px; // ... for levels of at most this many pixels x pairs (0 = default 200 000)
+    int gauss_fused;    // pyramids of lockstep groups: row + column pass of the Gaussian in one launch through LDS (1 default)
     int warp_lds;       // 1 (default): TV-L1 warp with the taps staged through LDS; 0: gathered from global memory
     int chunk;
     int spin_us;        // convergence polls: microseconds the host spins on the pinned record before it falls back to

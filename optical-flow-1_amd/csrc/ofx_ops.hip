@@ -273,6 +273,51 @@ __global__ void k_gauss_pass_g(OfxPlanes2<const T> in, OfxPlanes2<T> out, int nx
     gauss_pass_px<T, ALONG_X>(in.at(blockIdx.z), out.at(blockIdx.z), nx, ny, taps);
 }
 
+// Both passes in one launch for the pyramids of a lockstep group: a block brings a (GXY_TH + 2 r) x (64 + 2 r) region of the
+// input into LDS (reflected indices resolved while loading), runs the row pass on all of its rows, then the column pass on the
+// GXY_TH inner ones -- the intermediate image never touches memory (the two-pass form writes and re-reads it: 4 plane moves
+// instead of 2).  Per pixel the same sums in the same order as k_gauss_pass, the intermediate rounded to the storage type as
+// the two-pass form stores it.  in != out (neighbouring blocks read what a block would overwrite).  Radius <= GXY_RMAX.
+#define GXY_TH 32
+#define GXY_RMAX 8
+template <typename T>
+__global__ __launch_bounds__(256) void k_gauss_xy_g(OfxPlanes2<const T> in_p, OfxPlanes2<T> out_p, int nx, int ny, GaussTaps taps)
+{
+    __shared__ double s_in[(GXY_TH + 2 * GXY_RMAX) * (64 + 2 * GXY_RMAX)];
+    __shared__ double s_mid[(GXY_TH + 2 * GXY_RMAX) * 64];
+    const T *__restrict__ in = in_p.at(blockIdx.z);
+    T *__restrict__ out = out_p.at(blockIdx.z);
+    const int R = taps.size - 1, W = 64 + 2 * R, H = GXY_TH + 2 * R;
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * GXY_TH;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int k = tid; k < W * H; k += 256) {
+        const int r = k / W, c = k - r * W;
+        // rows / columns beyond the image on the far side of a border block are never used: clamp them into range
+        int i = gauss_reflect(i0 - R + r, ny), j = gauss_reflect(j0 - R + c, nx);
+        i = i < 0 ? 0 : (i > ny - 1 ? ny - 1 : i);
+        j = j < 0 ? 0 : (j > nx - 1 ? nx - 1 : j);
+        s_in[r * W + c] = ldw(in + (size_t) i * nx + j);
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < H; r += 4) {                   // row pass, :541-575
+        const double *row = s_in + r * W + R + threadIdx.x;
+        double sum = taps.B[0] * row[0];
+        for (int k = 1; k < taps.size; k++) sum += taps.B[k] * (row[-k] + row[k]);
+        s_mid[r * 64 + threadIdx.x] = sizeof(T) == sizeof(float) ? (double) (float) sum : sum;
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    if (j >= nx) return;
+    for (int r = threadIdx.y; r < GXY_TH; r += 4) {              // column pass, :577-611
+        const int i = i0 + r;
+        if (i >= ny) break;
+        const double *col = s_mid + (r + R) * 64 + threadIdx.x;
+        double sum = taps.B[0] * col[0];
+        for (int k = 1; k < taps.size; k++) sum += taps.B[k] * (col[-k * 64] + col[k * 64]);
+        stn(out + (size_t) i * nx + j, sum);
+    }
+}
+
 template <typename T> int op_gaussian(ofx_ctx *ctx, T *I, T *tmp, int nx, int ny, double sigma)
 {
     GaussTaps taps;
@@ -636,9 +681,42 @@ int op_build_pyramid_group(ofx_ctx *ctx, int G, const void *const *dA, const voi
     OFX_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_minmax_final_g, dim3(G), dim3(256), 0, ctx->stream, scr, nb);
     OFX_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_normalize2_g<T>, dim3(grid1d((size_t) size), G), dim3(256), 0, ctx->stream, P, lvA[0], lvB[0], size,
+    // fused row + column pass (k_gauss_xy_g) when the radius allows: it cannot work in place, so the normalised images go to
+    // the scratch array and the presmoothing writes the level
+    GaussTaps t0;
+    const double zsigma = 0.6 * sqrt(1.0 / (zfactor * zfactor) - 1.0);          // ZOOM_SIGMA_ZERO, zoom.cpp:15,60
+    bool fused = ctx->gauss_fused != 0 && ofx_gauss_taps(sigma, &t0) == OFX_OK && t0.size - 1 <= GXY_RMAX;
+    if (fused && nscales > 1) fused = ofx_gauss_taps(zsigma, &t0) == OFX_OK && t0.size - 1 <= GXY_RMAX;
+    T *n0 = fused ? tmpA : lvA[0], *n1 = fused ? tmpA + (size_t) G * size : lvB[0];
+    hipLaunchKernelGGL(k_normalize2_g<T>, dim3(grid1d((size_t) size), G), dim3(256), 0, ctx->stream, P, n0, n1, size,
                        (const double *) scr);
     OFX_LAUNCH_CHECK(ctx);
+    auto gauss_xy = [&](const T *ia, const T *ib, T *oa, T *ob, int nx, int ny, double sg) -> int {
+        GaussTaps taps;
+        if (ofx_gauss_taps(sg, &taps) != OFX_OK)
+            return ofx_fail(ctx, OFX_ERR_ARG, "gaussian: sigma %g needs more than %d taps", sg, OFX_GAUSS_MAX_TAPS);
+        if (taps.size >= nx || taps.size >= ny)
+            return ofx_fail(ctx, OFX_ERR_SIGMA, "GaussianSmooth: sigma too large (radius %d, image %dx%d)", taps.size, nx, ny);
+        const size_t st = (size_t) nx * ny;
+        hipLaunchKernelGGL(k_gauss_xy_g<T>, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, GXY_TH), 2 * G), dim3(64, 4), 0, ctx->stream,
+                           OfxPlanes2<const T>{ia, ib, G, st}, OfxPlanes2<T>{oa, ob, G, st}, nx, ny, taps);
+        OFX_LAUNCH_CHECK(ctx);
+        return OFX_OK;
+    };
+    if (fused) {
+        OFX_TRY(gauss_xy(n0, n1, lvA[0], lvB[0], nxx, nyy, sigma));
+        for (int s = 1; s < nscales; s++) {
+            const int nx = nxs[s - 1], ny = nys[s - 1];
+            const size_t st = (size_t) nx * ny;
+            OFX_TRY(gauss_xy(lvA[s - 1], lvB[s - 1], tmpB, tmpB + (size_t) G * st, nx, ny, zsigma));
+            dim3 g = grid2d(nxs[s], nys[s]);
+            g.z = 2 * G;
+            hipLaunchKernelGGL(k_resample_g<T>, g, block2d(), 0, ctx->stream, OfxPlanes2<const T>{tmpB, tmpB + (size_t) G * st, G, st},
+                               OfxPlanes2<T>{lvA[s], lvB[s], G, (size_t) nxs[s] * nys[s]}, nx, ny, nxs[s], nys[s], zfactor, zfactor);
+            OFX_LAUNCH_CHECK(ctx);
+        }
+        return OFX_OK;
+    }
     auto gauss = [&](const T *ia, const T *ib, T *oa, T *ob, T *ta, T *tb, int nx, int ny, double sg) -> int {
         GaussTaps taps;
         if (ofx_gauss_taps(sg, &taps) != OFX_OK)
@@ -658,7 +736,6 @@ int op_build_pyramid_group(ofx_ctx *ctx, int G, const void *const *dA, const voi
     };
     // scratch: first half = the A images of the group, second half = the B images
     OFX_TRY(gauss(lvA[0], lvB[0], lvA[0], lvB[0], tmpA, tmpA + (size_t) G * size, nxx, nyy, sigma));
-    const double zsigma = 0.6 * sqrt(1.0 / (zfactor * zfactor) - 1.0);          // ZOOM_SIGMA_ZERO, zoom.cpp:15,60
     for (int s = 1; s < nscales; s++) {
         const int nx = nxs[s - 1], ny = nys[s - 1];
         const size_t st = (size_t) nx * ny;

@@ -718,7 +718,13 @@ static int sor_pick_spw(const ofx_ctx *ctx, int G)
 // (k_*_window_lds), 1 (default) by measurement: the LDS window for a lone solve -- a latency chain, where one memory latency
 // per launch instead of one per step counts -- and the global kernels for lockstep groups of 4 pairs and more, which are
 // bound by resident waves (28 per CU at 64 VGPRs and no LDS against a few LDS-limited workgroups).
-static bool sor_use_lds(const ofx_ctx *ctx, int G) { return ctx->sor_lds == 2 || (ctx->sor_lds == 1 && G < 4); }
+// Measured (profiles/r03_e_sor_window_kernels_lds_vs_global.txt, 16 P1 pairs of cfg 3 / cfg 4): Horn-Schunck lone solves
+// 572 -> 537 ms with 8 steps per launch (16: 617), lockstep groups of 16 81 -> 147 ms per pair; Brox lone solves 255 -> 297 ms.
+// A step is bound by the ~200 dependent instructions of a lone wave, not by the round trip the window removes.
+static bool sor_use_lds(const ofx_ctx *ctx, int G, bool brox = false)
+{
+    return ctx->sor_lds == 2 || (ctx->sor_lds == 1 && G < 4 && !brox);
+}
 static int sor_window_threads(int n_items)
 {
     const int t = ofx_cdiv(n_items, 64) * 64;
@@ -866,7 +872,7 @@ static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L, const HsParams &P, i
                 return OFX_OK;
             };
             OFX_TRY(sor_window_loop(ctx, G, nx * ny, ny, P.TOL, P.maxiter, 2 * ny + nx - 2, HS_PLANE_C, batch, window, take,
-                                    niter, error, 1, &L.sweep_hint, sor_use_lds(ctx, G) ? 16 : 0));
+                                    niter, error, 1, &L.sweep_hint, 0));
             OFX_TRY((op_skew<typename Pix<T>::v2, false>(ctx, L.Us, L.U, nx, ny, HS_PLANE_C_SKEW, G)));
         } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
             // one launch per time step (option sor_exact = 2): the reference implementation of the exact schedule
@@ -1741,7 +1747,7 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
                     const int spw = sor_pick_spw(ctx, G);
                     const size_t lds_need = (size_t) sor_window_threads(w.R + 3) * w.K * (sizeof(double4) + sizeof(double)) +
                                             (size_t) (w.R + 3) * (w.K + 5) * (sizeof(double2) + sizeof(double));
-                    if (sor_use_lds(ctx, G) && (w.K == 4 || w.K == 8 || w.K == 16) && w.R + 3 <= 256 && lds_need <= 160 * 1024) {
+                    if (sor_use_lds(ctx, G, true) && (w.K == 4 || w.K == 8 || w.K == 16) && w.R + 3 <= 256 && lds_need <= 160 * 1024) {
                         const dim3 grid(blocks, sweeps, G), blk(sor_window_threads(w.R + 3));
 #define OFX_BROX_WINL(K_)                                                                                                      \
     do {                                                                                                                       \
@@ -1782,7 +1788,7 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
                     return OFX_OK;
                 };
                 OFX_TRY(sor_window_loop(ctx, G, n, ny, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, batch, window,
-                                        take, nsor, error, 1, &L.sweep_hint, sor_use_lds(ctx, G) ? 16 : 0));
+                                        take, nsor, error, 1, &L.sweep_hint, 0));
                 OFX_TRY((op_skew<typename Pix<T>::v2, false>(ctx, L.DUs, L.DU, nx, ny, BROX_PLANE_C_SKEW, G)));
             } else if (ctx->sor_exact && nx >= 3 && ny >= 3) {
                 const size_t ub = (size_t) n * sizeof(typename Pix<T>::v2);

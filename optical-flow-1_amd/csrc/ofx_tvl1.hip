@@ -81,7 +81,7 @@ OFX_DEV RowIn<T> tvl1_load_row(const typename Pix<T>::v2 *U, const typename Pix<
 // Stage "primal" at one pixel: thresholding TH (src/tvl1flow.cpp:117-143), divergence of p
 // (src/operators.cpp:35-78) and u = v + theta div p (:156-157).  l11/l21 = p11/p21 of the left pixel,
 // up12/up22 = p12/p22 of the pixel above.  Returns the new (u1,u2), rounded to the storage type.
-template <typename T>
+template <typename T, bool STRICT = true>
 OFX_DEV double2 tvl1_primal(double2 u, double2 a, double r, double2 p1, double2 p2, double l11, double l21, double up12,
                             double up22, bool lef, bool rig, bool top, bool bot, double l_t, double theta)
 {
@@ -94,7 +94,7 @@ OFX_DEV double2 tvl1_primal(double2 u, double2 a, double r, double2 p1, double2 
     const double grad = ix * ix + iy * iy;                  // :100-104
     const double rho = r + (ix * u.x + iy * u.y);           // :119-120
     const double ltg = l_t * grad;
-    const double fi = -rho / grad;
+    const double fi = STRICT ? -rho / grad : -rho * rcp_newton(grad);   // used only where grad >= TVL1_GRAD_IS_ZERO
     double d1, d2;
     if (rho < -ltg)                     { d1 = l_t * ix;  d2 = l_t * iy; }
     else if (rho > ltg)                 { d1 = -l_t * ix; d2 = -l_t * iy; }
@@ -185,10 +185,13 @@ OFX_DEV void tvl1_dual(double2 p1, double2 p2, double2 un, double r1, double r2,
         q2.y = (p2.y + taut * u2y) / ng2;
 #endif
     } else {
-        const double g1 = sqrt(u1x * u1x + u1y * u1y);
-        const double g2 = sqrt(u2x * u2x + u2y * u2y);
-        const double i1 = 1.0 / (1.0 + taut * g1);
-        const double i2 = 1.0 / (1.0 + taut * g2);
+        // no bit-exactness to keep here: the square root and the reciprocal are the bare rsq / rcp iterations of the compiler's
+        // own expansions (<= 1 ulp), without their range scaling and fix-ups -- the clamp keeps rsq finite at |grad u| = 0,
+        // where sqrt(2^-600) = 2^-300 vanishes in 1 + taut g; the denominators are >= 1
+        const double g1 = sqrt_unscaled(fmax(u1x * u1x + u1y * u1y, 0x1p-600));
+        const double g2 = sqrt_unscaled(fmax(u2x * u2x + u2y * u2y, 0x1p-600));
+        const double i1 = rcp_newton(1.0 + taut * g1);
+        const double i2 = rcp_newton(1.0 + taut * g2);
         q1.x = (p1.x + taut * u1x) * i1;
         q1.y = (p1.y + taut * u1y) * i1;
         q2.x = (p2.x + taut * u2x) * i2;
@@ -331,8 +334,8 @@ __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
         if (y < ny) {
             const double l11 = wave_shift_up(cur.p1.x);
             const double l21 = wave_shift_up(cur.p2.x);
-            un = tvl1_primal<T>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0, y == ny - 1,
-                                l_t, theta);
+            un = tvl1_primal<T, STRICT>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0, y == ny - 1,
+                                        l_t, theta);
             if (owner && y < yend) {
                 st_u = so;
                 acc += (un.x - cur.u.x) * (un.x - cur.u.x) + (un.y - cur.u.y) * (un.y - cur.u.y);   // :159-160
@@ -423,8 +426,8 @@ OFX_DEV void tvl1_iter2_march(const typename Pix<T>::v2 *__restrict__ Uin, const
         if (have1) {
             const double l11 = wave_shift_up(cur.p1.x);
             const double l21 = wave_shift_up(cur.p2.x);
-            uA0 = tvl1_primal<T>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0, y == ny - 1,
-                                 l_t, theta);
+            uA0 = tvl1_primal<T, STRICT>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0,
+                                         y == ny - 1, l_t, theta);
             if (owner && y >= y0 && y < yend) {
                 accA += (uA0.x - cur.u.x) * (uA0.x - cur.u.x) + (uA0.y - cur.u.y) * (uA0.y - cur.u.y);
                 sa1 = so;
@@ -445,8 +448,8 @@ OFX_DEV void tvl1_iter2_march(const typename Pix<T>::v2 *__restrict__ Uin, const
         if (y - 2 >= y0 && y - 2 <= yend && y - 2 <= ny - 1) {
             const double l11 = wave_shift_up(pA1a.x);
             const double l21 = wave_shift_up(pA1b.x);
-            uB0 = tvl1_primal<T>(uA2, a2, r2c, pA1a, pA1b, l11, l21, pA2a.y, pA2b.y, lef, rig, y - 2 == 0, y - 2 == ny - 1,
-                                 l_t, theta);
+            uB0 = tvl1_primal<T, STRICT>(uA2, a2, r2c, pA1a, pA1b, l11, l21, pA2a.y, pA2b.y, lef, rig, y - 2 == 0,
+                                         y - 2 == ny - 1, l_t, theta);
             if (owner && y - 2 < yend) {
                 st3 = so - 2 * row2;
                 accB += (uB0.x - uA2.x) * (uB0.x - uA2.x) + (uB0.y - uA2.y) * (uB0.y - uA2.y);
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(64 * TILE_RH) void k_tvl1_tile(
             __syncthreads();
             const double2 up = s_p[it & 1][w > 0 ? w - 1 : 0][lane];     // row 0 of the region: halo (or the image's top row)
             const double l11 = wave_shift_up(p1.x), l21 = wave_shift_up(p2.x);
-            const double2 un = tvl1_primal<T>(u, a, r, p1, p2, l11, l21, up.x, up.y, lef, rig, top, bot, l_t, theta);
+            const double2 un = tvl1_primal<T, STRICT>(u, a, r, p1, p2, l11, l21, up.x, up.y, lef, rig, top, bot, l_t, theta);
             if (owner) acc[it] = (un.x - u.x) * (un.x - u.x) + (un.y - u.y) * (un.y - u.y);   // :159-160
             s_u[it & 1][w][lane] = un;
             __syncthreads();

@@ -334,3 +334,35 @@ def test_tvl1occflow_cli_is_drop_in(orc, synth, tmp_path):
     write_pgm(tmp_path / "small.pgm", seq[0][:40, :40])
     r4 = subprocess.run([exe, names[0], names[1], str(tmp_path / "small.pgm"), names[1], str(tmp_path / "no.flo")], capture_output=True)
     assert r4.returncode == 0 and not (tmp_path / "no.flo").exists()
+
+
+def test_front_end_stats_json(orc, synth, tmp_path):
+    """OFX_STATS=path: the work record of the solve as JSON (per-scale sizes, iterations and error per warp -- what the
+    reference prints as text when verbose, src/tvl1flow.cpp:184-188 -- plus iteration-kernel milliseconds); OFX_TOLERANCE=1
+    switches the front-end to the f64 tolerance mode (AEPE bar, not byte identity)."""
+    import json
+    nx, ny = 160, 120
+    I0, I1 = synth.pair("P1", nx, ny)
+    write_pgm(tmp_path / "a.pgm", I0)
+    write_pgm(tmp_path / "b.pgm", I1)
+    env = dict(os.environ, OFX_STATS=str(tmp_path / "stats.json"))
+    r = subprocess.run([os.path.join(BIN, "tvl1flow"), str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"), str(tmp_path / "o.flo"),
+                        "0", "0.25", "0.15", "0.3", "4"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    d = json.load(open(tmp_path / "stats.json"))
+    uo, vo, it, err = orc.tvl1_multiscale(I0, I1, nscales=4)
+    assert d["program"] == "tvl1flow" and d["nscales"] == 4 and d["solves_per_scale"] == 5
+    assert [s["iterations"] for s in d["scales"]] == [list(map(int, row)) for row in it]
+    assert [(s["nx"], s["ny"]) for s in d["scales"]] == [(160, 120), (80, 60), (40, 30), (20, 15)]
+    assert np.allclose([s["error"] for s in d["scales"]], err, rtol=1e-10, atol=0)
+    assert d["work_pix_iters"] == sum(int(it[s].sum()) * d["scales"][s]["nx"] * d["scales"][s]["ny"] for s in range(4))
+    assert all(s["iteration_kernel_ms"] > 0 for s in d["scales"]) and d["total_ms"] > 0
+    want = np.stack([uo, vo], axis=-1).astype(np.float32)
+    assert np.array_equal(read_flo(tmp_path / "o.flo"), want)
+    env = dict(os.environ, OFX_TOLERANCE="1")
+    r = subprocess.run([os.path.join(BIN, "tvl1flow"), str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"), str(tmp_path / "t.flo"),
+                        "0", "0.25", "0.15", "0.3", "4"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    got = read_flo(tmp_path / "t.flo").astype(np.float64)
+    assert float(np.mean(np.hypot(got[..., 0] - uo, got[..., 1] - vo))) < 1e-4
+    assert not os.path.exists(tmp_path / "none.json")

@@ -161,6 +161,15 @@ def test_full_size_1080p_matches_oracle(gpu64, oracle_mod, synth):
     assert np.array_equal(gpu64.stats().iterations(), it_o)
     assert aepe(ug, vg, uo, vo) < 1e-4
     assert np.abs(ug - uo).max() < 1e-9 and np.abs(vg - vo).max() < 1e-9
+    # the tolerance mode (what bench.py's headline runs) at the size the metric is quoted on: north_star's bar
+    gpu64.set_option("relaxed_dual", 1)
+    try:
+        ut, vt = gpu64.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+        it_t = gpu64.stats().iterations().copy()
+    finally:
+        gpu64.set_option("relaxed_dual", 0)
+    assert aepe(ut, vt, uo, vo) < 1e-4 and aepe(ut, vt, uo, vo) < 1e-8      # stated tolerance; what it actually achieves
+    assert np.abs(it_t - np.asarray(it_o)).max() <= 4
 
 
 @pytest.mark.timeout(900)
