@@ -107,6 +107,17 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         recomputed alone), 2 = always.  Results are bit-identical in all three settings.
  *   "nt_stores"      fused TV-L1 kernel: 0 (default) non-temporal stores when a launch's working set exceeds the Infinity
  *                    Cache, 1 always, 2 never (A/B measurements)
+ *   "relaxed_dual"   0/1  TV-L1 in OFX_F64 storage: 1 = the tolerance mode -- double storage and arithmetic, but sqrt(x^2 + y^2)
+ *                         for libm's hypot and reciprocals for the IEEE quotients of the dual update (<= 1 ulp each); NOT
+ *                         bit-identical: AEPE vs the reference ~1e-12 px on the BASELINE configs (bar 1e-4), ~9-15 % faster.
+ *                         0 (default) = strict.  The front-ends read OFX_TOLERANCE=1 for it.
+ *   "tile", "tile_max_px"  TV-L1: levels of at most tile_max_px pixels x pairs (default 200 000) run K = 4 | 6 iterations per
+ *                         launch on 2-D tiles instead of the marching strips (0 = off, the default: measured no faster)
+ *   "sor_lds"        windowed exact SOR sweeps: 0 = one global round trip per time step, 2 = the launch window staged in LDS,
+ *                         1 (default) = by measurement (LDS for lone Horn-Schunck solves).  Results do not depend on it.
+ *   "gauss_fused"    1/0  pyramids of lockstep groups: row + column pass of the Gaussian in one launch (default 1)
+ *   "spin_us"        microseconds the host spins on a convergence poll's pinned record before it sleeps in
+ *                         hipEventSynchronize (default 150; 0 = never)
  *   "warp_lds"       1/0  TV-L1 warp with the bicubic taps staged through LDS (default 1)
  *   "lockstep"       pairs per lockstep group in ofx_tvl1_batch_dev (default 0 = ofx_tvl1_batch_group_size's
  *                         rule: as large as possible, evened out over the contexts; at most 16)
@@ -185,12 +196,15 @@ int ofx_tvl1_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *dI0, const 
                        void *const *d_flo, int nx, int ny, double tau, double lambda, double theta,
                        int nscales, double zfactor, int warps, double epsilon, ofx_stats *stats_out);
 
-/* Batch of independent pairs on ONE device (the unit of parallel work is the image pair).
+/* Batch of independent pairs on one OR SEVERAL devices (the unit of parallel work is the image pair).
  * The pairs are cut into lockstep groups of ofx_tvl1_batch_group_size() consecutive pairs;
  * group q is solved on context ctxs[q % n_ctx] with ofx_tvl1_group_dev, one host thread per context, so
- * n_ctx groups are in flight at a time (each context = its own HIP stream and workspace; all contexts
- * must live on the same device and have the same precision).  Arrays dI0/dI1/d_flo hold n_pairs device
- * pointers with the layout of ofx_tvl1_multiscale_dev.  work_pix_iters (optional, n_pairs doubles)
+ * n_ctx groups are in flight at a time (each context = its own HIP stream and workspace; same precision).
+ * The contexts may live on different GPUs: a group whose images or payload arrays are not device memory of
+ * its context's GPU -- another GPU's memory, pinned or pageable host memory -- is staged through the context's
+ * workspace (peer / host copies on the context's stream) and its payloads are copied back into the caller's
+ * arrays: a single-process multi-GPU batch with the results gathered where the caller wants them.
+ * Arrays dI0/dI1/d_flo hold n_pairs pointers with the layout of ofx_tvl1_multiscale_dev.  work_pix_iters (optional, n_pairs doubles)
  * receives sum n_iter*nx_s*ny_s per pair.  Returns after every pair has been fully solved (all
  * streams synchronised); the first failing group's status is returned. */
 int ofx_tvl1_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI0, const void *const *dI1,

@@ -342,9 +342,11 @@ class Ofx:
         return u1, u2
 
     def tvl1_multiscale(self, I0, I1, tau=0.25, lam=0.15, theta=0.3, nscales=5, zfactor=0.5, warps=5, epsilon=0.01,
-                        verbose=0):
+                        verbose=0, out=None):
+        """out = (u1, u2): the caller's own (ny, nx) float64 planes to fill -- a loop over frames reuses them; fresh arrays
+        cost their page faults inside the call (the download is their first touch)"""
         ny, nx = I0.shape
-        u1, u2 = np.zeros((ny, nx)), np.zeros((ny, nx))
+        u1, u2 = out if out is not None else (np.zeros((ny, nx)), np.zeros((ny, nx)))
         self._ck(self.L.ofx_tvl1_multiscale(self.h, _f64(I0), _f64(I1), u1, u2, nx, ny, tau, lam, theta, nscales,
                                             zfactor, warps, epsilon, verbose))
         return u1, u2

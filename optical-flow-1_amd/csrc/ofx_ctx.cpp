@@ -94,9 +94,10 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->ev_t0 = ctx->ev_t1 = nullptr;
     for (int i = 0; i < OFX_NPOLL; i++) ctx->ev_poll[i] = nullptr;
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipMalloc((void **) &ctx->d_err, sizeof(double) * OFX_TVL1_MAX_ITERATIONS * OFX_NSHARD) == hipSuccess;
+    static_assert(sizeof(OfxIterState) * OFX_MAX_GROUP <= OFX_STATE_BYTES, "state block too small");
+    ok = ok && hipMalloc((void **) &ctx->d_state, OFX_STATE_BYTES + sizeof(double) * OFX_TVL1_MAX_ITERATIONS * OFX_NSHARD) == hipSuccess;
+    if (ok) ctx->d_err = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_state) + OFX_STATE_BYTES);
     ctx->d_err_cap = OFX_TVL1_MAX_ITERATIONS;
-    ok = ok && hipMalloc((void **) &ctx->d_state, sizeof(OfxIterState) * OFX_MAX_GROUP) == hipSuccess;
     ok = ok && hipHostMalloc((void **) &ctx->h_state, sizeof(OfxIterState) * OFX_NPOLL * OFX_MAX_GROUP, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < OFX_NPOLL; i++)
         ok = hipEventCreateWithFlags(&ctx->ev_poll[i], hipEventDisableTiming) == hipSuccess;
@@ -116,8 +117,7 @@ extern "C" void ofx_ctx_destroy(ofx_ctx *ctx)
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->slabs) (void) hipFree(s.base);
-    if (ctx->d_err) (void) hipFree(ctx->d_err);
-    if (ctx->d_state) (void) hipFree(ctx->d_state);
+    if (ctx->d_state) (void) hipFree(ctx->d_state);            // d_err lives in the same allocation
     if (ctx->h_state) (void) hipHostFree(ctx->h_state);
     for (int i = 0; i < OFX_NPOLL; i++)
         if (ctx->ev_poll[i]) (void) hipEventDestroy(ctx->ev_poll[i]);

@@ -27,6 +27,8 @@ struct OfxIterState {
                      // can spin on it instead of sleeping in hipEventSynchronize (0 = not published yet)
 };
 
+#define OFX_STATE_BYTES 512    // >= sizeof(OfxIterState) * OFX_MAX_GROUP, keeps the error slots 512-byte aligned
+
 struct OfxSlab {
     char  *base;
     size_t bytes;
@@ -44,9 +46,10 @@ struct ofx_ctx {
     size_t call_bytes;      // bytes handed out during this call (to coalesce next time)
 
     // convergence machinery
-    double       *d_err;    // [d_err_cap][OFX_NSHARD] per-iteration squared-update sums
+    // one allocation, [state: OFX_STATE_BYTES][error slots], so that a loop clears both with ONE memset (ofx_loop_clear)
+    double       *d_err;    // [d_err_cap][OFX_NSHARD] per-iteration squared-update sums (= d_state + OFX_STATE_BYTES)
     int           d_err_cap;
-    OfxIterState *d_state;  // device copy [OFX_MAX_GROUP]
+    OfxIterState *d_state;  // device copy [OFX_MAX_GROUP], start of the allocation
     OfxIterState *h_state;  // pinned ring [OFX_NPOLL][OFX_MAX_GROUP]
     hipEvent_t    ev_poll[OFX_NPOLL];
     hipEvent_t    ev_t0, ev_t1;

@@ -59,6 +59,7 @@ struct LoopSpec {
 };
 
 int ofx_loop_reserve(ofx_ctx *ctx, int max_iter);                      // err slots for max_iter sweeps
+int ofx_loop_clear(ofx_ctx *ctx, size_t slots);                        // zero the loop state + the first `slots` error slots
 // G problems in lockstep: problem g owns err slots [g * slots_per_problem, ...) and state entry g.
 // seq: number the records carry when they are complete (never 0); ofx_loop_wait_poll(slot, G, seq) waits for them
 int ofx_loop_finalize_group(ofx_ctx *ctx, const LoopSpec &L, int G, int slots_per_problem, int start, int launched,
@@ -105,8 +106,7 @@ static int ofx_run_loop_group_impl(ofx_ctx *ctx, const LoopSpec &L, int G, Launc
     OFX_TRY(ofx_loop_reserve(ctx, G * per));
     LoopSpec S = L;
     if (S.fixed) S.thr = -1.0;          // error >= 0 always passes `error > -1`
-    OFX_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(double) * (size_t) G * per * OFX_NSHARD, ctx->stream));
-    OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(OfxIterState) * G, ctx->stream));
+    OFX_TRY(ofx_loop_clear(ctx, (size_t) G * per));
     if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
 
     // head / tail count the polls issued / consumed.  A context that has the device to itself keeps two

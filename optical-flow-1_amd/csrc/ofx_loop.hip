@@ -72,11 +72,20 @@ int ofx_loop_reserve(ofx_ctx *ctx, int max_iter)
 {
     if (max_iter <= ctx->d_err_cap) return OFX_OK;
     OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_err) (void) hipFree(ctx->d_err);
+    if (ctx->d_state) (void) hipFree(ctx->d_state);
+    ctx->d_state = nullptr;
     ctx->d_err = nullptr;
     ctx->d_err_cap = 0;
-    OFX_HIP(ctx, hipMalloc((void **) &ctx->d_err, sizeof(double) * (size_t) max_iter * OFX_NSHARD));
+    OFX_HIP(ctx, hipMalloc((void **) &ctx->d_state, OFX_STATE_BYTES + sizeof(double) * (size_t) max_iter * OFX_NSHARD));
+    ctx->d_err = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_state) + OFX_STATE_BYTES);
     ctx->d_err_cap = max_iter;
+    return OFX_OK;
+}
+
+// zero the loop state and the first `slots` error slots: one memset (the two arrays share an allocation)
+int ofx_loop_clear(ofx_ctx *ctx, size_t slots)
+{
+    OFX_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, OFX_STATE_BYTES + sizeof(double) * slots * OFX_NSHARD, ctx->stream));
     return OFX_OK;
 }
 

@@ -1234,9 +1234,22 @@ int occ_single_scale_dev(ofx_ctx *ctx, int G, const double *I_1, const double *I
 }
 
 // G triples (host planes) on one context
+int occ_group_impl(ofx_ctx *ctx, int G, const double *const *I_1, const double *const *I0, const double *const *I1,
+                   const double *const *filtI0, double *const *u1, double *const *u2, double *const *chi, int nxx, int nyy,
+                   const OccParams &P, int nscales, double zfactor, ofx_stats *stats);
+// An error return must not leave kernels or copies into the caller's planes in flight (the next call resets the arena they
+// work in): drain the stream first, as ofx_run_loop_group does for the iteration loops.
 int occ_group(ofx_ctx *ctx, int G, const double *const *I_1, const double *const *I0, const double *const *I1,
               const double *const *filtI0, double *const *u1, double *const *u2, double *const *chi, int nxx, int nyy,
               const OccParams &P, int nscales, double zfactor, ofx_stats *stats)
+{
+    const int s = occ_group_impl(ctx, G, I_1, I0, I1, filtI0, u1, u2, chi, nxx, nyy, P, nscales, zfactor, stats);
+    if (s != OFX_OK) (void) hipStreamSynchronize(ctx->stream);
+    return s;
+}
+int occ_group_impl(ofx_ctx *ctx, int G, const double *const *I_1, const double *const *I0, const double *const *I1,
+                   const double *const *filtI0, double *const *u1, double *const *u2, double *const *chi, int nxx, int nyy,
+                   const OccParams &P, int nscales, double zfactor, ofx_stats *stats)
 {
     const double t0 = ofx_now_ms();
     std::vector<int> nxs, nys;
@@ -1351,14 +1364,19 @@ extern "C" int ofx_tvl1occ_batch(ofx_ctx *const *ctxs, int n_ctx, int n_triples,
         OFX_ENTER(ctx);
         OFX_TRY(occ_check_args(ctx, nxx, nyy, lambda, theta, nscales, zfactor, warps));
     }
-    // group size: option "lockstep" of ctxs[0], else as many as fit (~ 60 row-major + 10 hyperplane-major planes per triple)
+    // group size: option "lockstep" of ctxs[0], else as many as fit.  Per triple: 7 planes per pyramid level (occ_group: 4 images,
+    // u1, u2, chi) + OccWork's 28 full-size row-major and 10 hyperplane-major planes + 2 of Gaussian / zoom scratch
     int G = ctxs[0]->lockstep > 0 ? ctxs[0]->lockstep : OCC_MAX_GROUP;
     if (G > OCC_MAX_GROUP) G = OCC_MAX_GROUP;
     {
         size_t free_b = 0, total_b = 0;
         if (hipSetDevice(ctxs[0]->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return OFX_ERR_HIP;
         const double budget = (ctxs[0]->mem_budget > 0 ? ctxs[0]->mem_budget : 0.5 * (double) free_b) / n_ctx;
-        const double per = 8.0 * (60.0 * nxx * nyy + 10.0 * (double) rof_skew_elems(nxx, nyy));
+        std::vector<int> nxs, nys;
+        OFX_TRY(op_pyramid_sizes(ctxs[0], nxx, nyy, nscales, zfactor, nxs, nys));
+        double level_px = 0.0;
+        for (int s = 0; s < nscales; s++) level_px += (double) nxs[s] * nys[s];
+        const double per = 8.0 * (7.0 * level_px + 30.0 * nxx * nyy + 10.0 * (double) rof_skew_elems(nxx, nyy)) * 1.05;
         const int fit = (int) (budget / per);
         if (fit < 1) return ofx_fail(ctxs[0], OFX_ERR_NOMEM, "tvl1occ batch: %.1f GB per triple, %.1f GB per context available", per / 1e9, budget / 1e9);
         if (G > fit) G = fit;
