@@ -339,38 +339,6 @@ OFX_DEV int sor_border_block(int i, int ny, int R)
     return r / R;
 }
 
-// Interior rows in the windowed kernels (round 3).  A row thread 1 <= r <= ny - 2 at local step q updates pixel (r, q - 2 r),
-// which lies ON hyperplane q of the skewed layout: its element index is q ny + r, its eight neighbours sit at constant
-// offsets from it ((i + di, j + dj) -> (2 di + dj) ny + di), nothing is clamped and the corner quirk cannot apply.  The generic
-// path computes the plane item, four clamps and nine 64-bit addresses per update (~200 dependent instructions per step, and a
-// step of a one- or two-wave workgroup is bound by exactly that chain); here the same operands come from ONE 32-bit
-// base offset.  Same values, same arithmetic (hs_point_finish): bit-identical.  Waves that hold only interior rows never
-// enter the generic path.
-template <typename T> struct UFastPut {
-    typename Pix<T>::v2 *U, *snap;
-    unsigned p;
-    OFX_DEV void put(int, int, double2 v) const { stn2(U + p, v); stn2(snap + p, v); }
-};
-template <typename T>
-OFX_DEV double hs_point_interior(typename Pix<T>::v2 *U, typename Pix<T>::v2 *snap, const typename Pix<T>::v2 *__restrict__ A,
-                                 const T *__restrict__ Dif, unsigned p, unsigned ny, double alpha2)
-{
-    HsOps o;
-    o.p1 = ldu2<OFX_SOR_COH != 0>(U + (p - 3 * ny - 1));     // (i - 1, j - 1)
-    o.p2 = ldu2<OFX_SOR_COH != 0>(U + (p - ny - 1));         // (i - 1, j + 1)
-    o.p3 = ldu2<OFX_SOR_COH != 0>(U + (p + ny + 1));         // (i + 1, j - 1)
-    o.p4 = ldu2<OFX_SOR_COH != 0>(U + (p + 3 * ny + 1));     // (i + 1, j + 1)
-    o.p5 = ldu2<OFX_SOR_COH != 0>(U + (p - 2 * ny - 1));     // (i - 1, j)
-    o.p6 = ldu2<OFX_SOR_COH != 0>(U + (p - ny));             // (i, j - 1)
-    o.p7 = ldu2<OFX_SOR_COH != 0>(U + (p + 2 * ny + 1));     // (i + 1, j)
-    o.p8 = ldu2<OFX_SOR_COH != 0>(U + (p + ny));             // (i, j + 1)
-    o.c = ldu2<OFX_SOR_COH != 0>(U + p);
-    o.a = ldw2(A + p);
-    o.dif = ldw(Dif + p);
-    const UFastPut<T> acc = {U, snap, p};
-    return hs_point_finish<T>(acc, o, 0, 0, alpha2);
-}
-
 // SPW consecutive sweeps of one row block share a workgroup: their updates are independent (lag_s steps apart), so their
 // loads are issued together and ONE store drain + barrier per step serves all of them -- the per-step latency, not
 // arithmetic or bandwidth, is what bounds a lockstep group (profiles/r02_f_sor_counters.txt).
@@ -397,7 +365,6 @@ __global__ __launch_bounds__(MAXT) void k_hs_window(typename Pix<T>::v2 *Ug, typ
     const T *__restrict__ Dif = Difg + g * grp.npix;
     double *__restrict__ err = errg + (size_t) g * grp.err_stride;
     const int r = sor_window_item(w, b, threadIdx.x, ny);
-    const bool fast_ok = grp.npix < (1u << 27);                  // 32-bit element offsets (x 16 bytes) in the interior path
     double e[SPW];
 #pragma unroll
     for (int u = 0; u < SPW; u++) e[u] = 0.0;
@@ -424,8 +391,6 @@ __global__ __launch_bounds__(MAXT) void k_hs_window(typename Pix<T>::v2 *Ug, typ
                 // one sweep per workgroup: load and update in one go (the compiler interleaves them in 66 VGPRs = 7 waves
                 // per SIMD; holding every operand first would take 106)
                 if (SPW > 1) e[u] += hs_point_finish<T>(acc, ops[u], pi[u], pj[u], alpha2);
-                else if (fast_ok && r >= 1 && r <= ny - 2)
-                    e[u] += hs_point_interior<T>(U, mysnap, A, Dif, (unsigned) (q_first[u] + k) * (unsigned) ny + (unsigned) r, (unsigned) ny, alpha2);
                 else e[u] += hs_point_acc<T>(acc, A, Dif, pi[u], pj[u], nx, ny, alpha2);
             }
             const int q = q_first[u] + k;
@@ -1409,29 +1374,6 @@ OFX_DEV double brox_point_acc(const Acc &acc, const typename Pix<T>::v4 *__restr
     return brox_point_finish<T>(acc, o, i, j, alpha);
 }
 
-// interior rows of the windowed kernels (see hs_point_interior): pixel (r, q - r) is element q ny + r of the skewed layout
-// (c = 1), its four neighbours and their psi_s at +- ny and +- (ny + 1)
-template <typename T>
-OFX_DEV double brox_point_interior(typename Pix<T>::v2 *DU, typename Pix<T>::v2 *snap, const typename Pix<T>::v4 *__restrict__ CO,
-                                   const T *__restrict__ Dm, const T *__restrict__ Psis, unsigned p, unsigned ny, double alpha)
-{
-    BroxOps o;
-    const double c = ldw(Psis + p);
-    o.s.p1 = 0.5 * (ldw(Psis + (p + ny + 1)) + c);          // (i + 1, j)
-    o.s.p2 = 0.5 * (ldw(Psis + (p - ny - 1)) + c);          // (i - 1, j)
-    o.s.p3 = 0.5 * (ldw(Psis + (p + ny)) + c);              // (i, j + 1)
-    o.s.p4 = 0.5 * (ldw(Psis + (p - ny)) + c);              // (i, j - 1)
-    o.c = ldu2<OFX_SOR_COH != 0>(DU + p);
-    o.dn = ldu2<OFX_SOR_COH != 0>(DU + (p + ny + 1));
-    o.up = ldu2<OFX_SOR_COH != 0>(DU + (p - ny - 1));
-    o.rt = ldu2<OFX_SOR_COH != 0>(DU + (p + ny));
-    o.lf = ldu2<OFX_SOR_COH != 0>(DU + (p - ny));
-    o.co = ldw4(CO + p);
-    o.D = ldw(Dm + p);
-    const UFastPut<T> acc = {DU, snap, p};
-    return brox_point_finish<T>(acc, o, 0, 0, alpha);
-}
-
 template <typename T, bool COH = false, bool SNAP = false>
 OFX_DEV double brox_point(typename Pix<T>::v2 *DU, const typename Pix<T>::v4 *__restrict__ CO,
                           const T *__restrict__ Dm, const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha,
@@ -1532,7 +1474,6 @@ __global__ __launch_bounds__(MAXT) void k_brox_window(typename Pix<T>::v2 *DUg, 
     const T *__restrict__ Psis = Psisg + g * grp.npix;
     double *__restrict__ err = errg + (size_t) g * grp.err_stride;
     const int r = sor_window_item(w, b, threadIdx.x, ny);
-    const bool fast_ok = grp.npix < (1u << 27);
     double e[SPW];
 #pragma unroll
     for (int u = 0; u < SPW; u++) e[u] = 0.0;
@@ -1557,8 +1498,6 @@ __global__ __launch_bounds__(MAXT) void k_brox_window(typename Pix<T>::v2 *DUg, 
             if (have[u]) {
                 const UGlobal<T, OFX_SOR_COH != 0, true, LaySkew> acc = {DU, mysnap, LaySkew{ny, BROX_PLANE_C_SKEW}};
                 if (SPW > 1) e[u] += brox_point_finish<T>(acc, ops[u], pi[u], pj[u], alpha);
-                else if (fast_ok && r >= 1 && r <= ny - 2)
-                    e[u] += brox_point_interior<T>(DU, mysnap, CO, Dm, Psis, (unsigned) (q_first[u] + k) * (unsigned) ny + (unsigned) r, (unsigned) ny, alpha);
                 else e[u] += brox_point_acc<T>(acc, CO, Dm, Psis, pi[u], pj[u], nx, ny, alpha);
             }
             const int q = q_first[u] + k;

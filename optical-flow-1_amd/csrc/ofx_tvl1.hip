@@ -910,7 +910,8 @@ static int tvl1_pick_rows2(const ofx_ctx *ctx, int nx, int ny, int G)
         static const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 20, 24};
         for (int r : cand) {
             const long waves = strips_pad * ofx_cdiv(ny, r);
-            const long cost = ((waves + 1023) / 1024) * (r + 5);
+            const long slots = ctx->rows_slots > 0 ? ctx->rows_slots : 1024;
+            const long cost = ((waves + slots - 1) / slots) * (r + 5);
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
         }
         return best;

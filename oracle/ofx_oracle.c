@@ -1101,6 +1101,297 @@ int orc_brox_spatial(const double *I1, const double *I2, double *u, double *v, i
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* robust_expo_methods for ONE channel (nz = 1): src/robust_expo_methods.cpp:34-567,
+ * src/robust_expo_smoothness.cpp:26-187, src/robust_expo_generic_tensor.cpp:18-168.  The method is Brox's with an
+ * image-driven weight `expo` in the smoothness term; what differs from brox_single_scale above, line by line:
+ *   - psi1..4 are the half-sums with the RIGHT / LEFT / DOWN / UP neighbour (generic_tensor.cpp:18-90) and every sum over
+ *     them runs in that order (divergence :97-168, div_d methods.cpp:266, the SOR point :138-148);
+ *   - psi_smooth weighs the flow gradient with expo (smoothness.cpp:26-44); psi_data / psi_gradient add the motion terms
+ *     before subtracting I1 (methods.cpp:52-56, :92-96) and accumulate onto 0;
+ *   - the constant parts of the scheme are per-channel sums accumulated onto 0 and multiplied by psi afterwards
+ *     (methods.cpp:283-322): -psid * (dif * I2wx), not (-psid * dif) * I2wx;
+ *   - the multiscale driver presmooths with gaussian(I, nx, ny, nzz, GAUSSIAN_SIGMA) (:497-498), i.e. sigma = the number of
+ *     channels (1.0) and boundary condition (int) 0.8 = 0 = DIRICHLET, and truncates alpha * nzz to an int (:529).
+ * For nz > 1 the reference's pyramid reads beyond its scratch copy (zoom.cpp:96-118); only nz = 1 is restated. */
+#define REXPO_EPSILON 0.001        /* src/robust_expo_smoothness.h:16 */
+#define REXPO_MAXITER 300          /* src/robust_expo_methods.cpp:24 */
+#define REXPO_SOR_W   1.9          /* :25 */
+#define REXPO_XI      0.05         /* src/robust_expo_smoothness.cpp:17-19 */
+#define REXPO_TAU     0.94
+#define REXPO_BETA    0.001
+
+/* src/operators.cpp:506-624 with boundary_condition = BOUNDARY_CONDITION_DIRICHLET: samples outside the image are 0 and
+ * there is no size check (the padded line always has room) */
+void orc_gaussian_dirichlet(double *I, int nx, int ny, double sigma)
+{
+    double *B;
+    const int size = gauss_taps(sigma, &B);
+    double *line = dalloc((size_t) (nx > ny ? nx : ny));
+    for (int k = 0; k < ny; k++) {
+        double *row = I + (size_t) k * nx;
+        for (int x = 0; x < nx; x++) {
+            double sum = B[0] * row[x];
+            for (int j = 1; j < size; j++)
+                sum += B[j] * ((x - j >= 0 ? row[x - j] : 0.0) + (x + j < nx ? row[x + j] : 0.0));
+            line[x] = sum;
+        }
+        memcpy(row, line, (size_t) nx * sizeof(double));
+    }
+    for (int k = 0; k < nx; k++) {
+        for (int y = 0; y < ny; y++) {
+            double sum = B[0] * I[(size_t) y * nx + k];
+            for (int j = 1; j < size; j++)
+                sum += B[j] * ((y - j >= 0 ? I[(size_t) (y - j) * nx + k] : 0.0) + (y + j < ny ? I[(size_t) (y + j) * nx + k] : 0.0));
+            line[y] = sum;
+        }
+        for (int y = 0; y < ny; y++) I[(size_t) y * nx + k] = line[y];
+    }
+    free(line);
+    free(B);
+}
+
+static int rexpo_cmp(const void *a, const void *b)
+{
+    const double x = *(const double *) a, y = *(const double *) b;
+    return (x > y) - (x < y);
+}
+
+/* src/robust_expo_smoothness.cpp:128-187 (nz = 1): expo = exp(-lambda |grad I1|) (+ BETA for method 2); method 3 picks lambda
+ * per pixel, bounded by the value at the TAU quantile of the sorted gradients */
+void orc_rexpo_exponential(const double *Ix, const double *Iy, int n, double alpha, double lambda, int method, double *expo)
+{
+    double *mg = dalloc((size_t) n);
+    for (int i = 0; i < n; i++) mg[i] = sqrt(Ix[i] * Ix[i] + Iy[i] * Iy[i]);                       /* max_gradients, one channel */
+    if (method == 1 || method == 2) {
+        const double beta = method == 2 ? REXPO_BETA : 0;
+        for (int i = 0; i < n; i++) expo[i] = exp(-lambda * mg[i]) + beta;
+    } else if (method == 3) {
+        double *lp = dalloc((size_t) n), *ord = dalloc((size_t) n);
+        for (int i = 0; i < n; i++) lp[i] = (-log(REXPO_XI) + log(alpha)) / mg[i];
+        memcpy(ord, mg, (size_t) n * sizeof(double));
+        qsort(ord, (size_t) n, sizeof(double), rexpo_cmp);
+        const double c = -log(REXPO_XI) + log(alpha);
+        int pos_ref = (int) (REXPO_TAU * n);
+        double lambda_omega;
+        while ((pos_ref < n) && (c / 2 > ord[pos_ref - 1])) pos_ref++;
+        if (pos_ref == n) lambda_omega = 0;
+        else lambda_omega = (c / ord[pos_ref - 1]);
+        for (int i = 0; i < n; i++) {
+            double lambda_pi = lambda_omega;
+            if (lambda_omega > lp[i]) lambda_pi = lp[i];
+            expo[i] = exp(-lambda_pi * mg[i]);
+        }
+        free(lp); free(ord);
+    }
+    free(mg);
+}
+
+/* generic_tensor.cpp:97-168: existing terms in the order right, left, down, up */
+static inline double rexpo_div_at(const double *f, const double *pr, const double *pl, const double *pd, const double *pu,
+                                  int i, int j, int nx, int ny)
+{
+    const int k = i * nx + j;
+    double acc = 0;
+    int have = 0;
+    if (j < nx - 1) { acc = pr[k] * (f[k + 1] - f[k]); have = 1; }
+    if (j > 0)      { const double t = pl[k] * (f[k - 1] - f[k]);  acc = have ? acc + t : t; have = 1; }
+    if (i < ny - 1) { const double t = pd[k] * (f[k + nx] - f[k]); acc = have ? acc + t : t; have = 1; }
+    if (i > 0)      { const double t = pu[k] * (f[k - nx] - f[k]); acc = have ? acc + t : t; have = 1; }
+    return acc;
+}
+
+/* methods.cpp:111-154; psi1..4 = right, left, down, up */
+static inline double rexpo_sor_point(const double *Au, const double *Av, const double *Du, const double *Dv, const double *D,
+                                     double *du, double *dv, double alpha, const double *psi1, const double *psi2,
+                                     const double *psi3, const double *psi4, int i, int i0, int i1, int j, int nx, int j0, int j1)
+{
+    const double w = REXPO_SOR_W;
+    const int k = i * nx + j;
+    const double div_du = psi1[k] * du[k + j1] + psi2[k] * du[k - j0] + psi3[k] * du[k + i1] + psi4[k] * du[k - i0];
+    const double div_dv = psi1[k] * dv[k + j1] + psi2[k] * dv[k - j0] + psi3[k] * dv[k + i1] + psi4[k] * dv[k - i0];
+    const double duk = du[k], dvk = dv[k];
+    du[k] = (1. - w) * du[k] + w * (Au[k] - D[k] * dv[k] + alpha * div_du) / Du[k];
+    dv[k] = (1. - w) * dv[k] + w * (Av[k] - D[k] * du[k] + alpha * div_dv) / Dv[k];
+    return (du[k] - duk) * (du[k] - duk) + (dv[k] - dvk) * (dv[k] - dvk);
+}
+
+/* methods.cpp:161-455, one channel, one thread (the reference's interior loop is a racy omp parallel for like Brox's) */
+static void rexpo_single_scale(const double *I1, const double *I2, double *u, double *v, int nx, int ny, int method,
+                               double alpha, double gamma, double lambda, double TOL, int inner_iter, int outer_iter,
+                               int verbose, int *iters)
+{
+    const int size = nx * ny;
+    const size_t n = (size_t) size;
+    enum { NARR = 35 };
+    double *a[NARR];
+    for (int q = 0; q < NARR; q++) a[q] = dalloc(n);
+    double *du = a[0], *dv = a[1], *ux = a[2], *uy = a[3], *vx = a[4], *vy = a[5];
+    double *I1x = a[6], *I1y = a[7], *I2x = a[8], *I2y = a[9], *I2w = a[10], *I2wx = a[11], *I2wy = a[12];
+    double *I2xx = a[13], *I2yy = a[14], *I2xy = a[15], *I2wxx = a[16], *I2wyy = a[17], *I2wxy = a[18];
+    double *div_u = a[19], *div_v = a[20], *div_d = a[21];
+    double *Au = a[22], *Av = a[23], *Du = a[24], *Dv = a[25], *D = a[26];
+    double *psid = a[27], *psig = a[28], *psis = a[29], *psi1 = a[30], *psi2 = a[31], *psi3 = a[32], *psi4 = a[33], *expo = a[34];
+    int solve = 0;
+
+    orc_centered_gradient(I1, I1x, I1y, nx, ny);               /* :221-222 */
+    orc_centered_gradient(I2, I2x, I2y, nx, ny);
+    orc_dxx(I2, I2xx, nx, ny);                                 /* :225-227 */
+    orc_dyy(I2, I2yy, nx, ny);
+    orc_dxy(I2, I2xy, nx, ny);
+    orc_rexpo_exponential(I1x, I1y, size, alpha, lambda, method, expo);     /* :231 */
+
+    for (int no = 0; no < outer_iter; no++) {                  /* :234 */
+        orc_bicubic_warp(I2,   u, v, I2w,   nx, ny, 1);        /* :236-241 (bicubic_interpolation_warp_color, nz = 1) */
+        orc_bicubic_warp(I2x,  u, v, I2wx,  nx, ny, 1);
+        orc_bicubic_warp(I2y,  u, v, I2wy,  nx, ny, 1);
+        orc_bicubic_warp(I2xx, u, v, I2wxx, nx, ny, 1);
+        orc_bicubic_warp(I2xy, u, v, I2wxy, nx, ny, 1);
+        orc_bicubic_warp(I2yy, u, v, I2wyy, nx, ny, 1);
+        orc_centered_gradient(u, ux, uy, nx, ny);              /* :244-245 */
+        orc_centered_gradient(v, vx, vy, nx, ny);
+        for (int i = 0; i < size; i++) {                       /* robust_expo_psi_smooth, smoothness.cpp:36-43 */
+            const double gu = expo[i] * ux[i] * ux[i] + expo[i] * uy[i] * uy[i];
+            const double gv = expo[i] * vx[i] * vx[i] + expo[i] * vy[i] * vy[i];
+            const double normFlow = gu + gv;
+            psis[i] = expo[i] / sqrt(normFlow + REXPO_EPSILON * REXPO_EPSILON);
+        }
+        for (int i = 0; i < ny; i++)                           /* robust_expo_psi_divergence */
+            for (int j = 0; j < nx; j++) {
+                const int k = i * nx + j;
+                psi1[k] = (j < nx - 1) ? 0.5 * (psis[k + 1] + psis[k]) : 0;
+                psi2[k] = (j > 0)      ? 0.5 * (psis[k - 1] + psis[k]) : 0;
+                psi3[k] = (i < ny - 1) ? 0.5 * (psis[k + nx] + psis[k]) : 0;
+                psi4[k] = (i > 0)      ? 0.5 * (psis[k - nx] + psis[k]) : 0;
+            }
+        for (int i = 0; i < ny; i++)                           /* robust_expo_divergence of u and of v, :257-258 */
+            for (int j = 0; j < nx; j++) {
+                div_u[i * nx + j] = rexpo_div_at(u, psi1, psi2, psi3, psi4, i, j, nx, ny);
+                div_v[i * nx + j] = rexpo_div_at(v, psi1, psi2, psi3, psi4, i, j, nx, ny);
+            }
+        for (int i = 0; i < size; i++) {                       /* :261-267 */
+            div_d[i] = alpha * (psi1[i] + psi2[i] + psi3[i] + psi4[i]);
+            du[i] = dv[i] = 0;
+        }
+        for (int ni = 0; ni < inner_iter; ni++) {              /* :270 */
+            for (int i = 0; i < size; i++) {                   /* psi_data :48-60, one channel */
+                double dI2 = 0;
+                const double dI = I2w[i] + I2wx[i] * du[i] + I2wy[i] * dv[i] - I1[i];
+                dI2 += dI * dI;
+                psid[i] = (1. / sqrt(dI2 + REXPO_EPSILON * REXPO_EPSILON));
+            }
+            for (int i = 0; i < size; i++) {                   /* psi_gradient :85-102 */
+                double dI2 = 0;
+                const double dIx = I2wx[i] + I2wxx[i] * du[i] + I2wxy[i] * dv[i] - I1x[i];
+                const double dIy = I2wy[i] + I2wxy[i] * du[i] + I2wyy[i] * dv[i] - I1y[i];
+                dI2 += dIx * dIx + dIy * dIy;
+                psig[i] = (1. / sqrt(dI2 + REXPO_EPSILON * REXPO_EPSILON));
+            }
+            for (int i = 0; i < size; i++) {                   /* :279-322 */
+                double BNu = 0, BNv = 0, BDu = 0, BDv = 0, GNu = 0, GNv = 0, GDu = 0, GDv = 0, DI_Gradient = 0, DI_Data = 0;
+                const double dif = I2w[i] - I1[i];
+                BNu += dif * I2wx[i];
+                BNv += dif * I2wy[i];
+                BDu += I2wx[i] * I2wx[i];
+                BDv += I2wy[i] * I2wy[i];
+                DI_Data += (I2wy[i] * I2wx[i]);
+                const double dx = (I2wx[i] - I1x[i]);
+                const double dy = (I2wy[i] - I1y[i]);
+                GNu += (dx * I2wxx[i] + dy * I2wxy[i]);
+                GNv += (dx * I2wxy[i] + dy * I2wyy[i]);
+                GDu += (I2wxx[i] * I2wxx[i] + I2wxy[i] * I2wxy[i]);
+                GDv += (I2wyy[i] * I2wyy[i] + I2wxy[i] * I2wxy[i]);
+                DI_Gradient += (I2wxx[i] + I2wyy[i]) * I2wxy[i];
+                const double g = gamma * psig[i];
+                BNu = -psid[i] * BNu;
+                BNv = -psid[i] * BNv;
+                BDu = psid[i] * BDu;
+                BDv = psid[i] * BDv;
+                GNu = -g * GNu;
+                GNv = -g * GNv;
+                GDu = g * GDu;
+                GDv = g * GDv;
+                Au[i] = BNu + GNu + alpha * div_u[i];
+                Av[i] = BNv + GNv + alpha * div_v[i];
+                Du[i] = BDu + GDu + div_d[i];
+                Dv[i] = BDv + GDv + div_d[i];
+                D[i] = psid[i] * DI_Data + g * DI_Gradient;
+            }
+            double error = 1000;
+            int nsor = 0;
+            while (error > TOL && nsor < REXPO_MAXITER) {      /* :325-412, the sweep order of Brox */
+                error = 0;
+                nsor++;
+                for (int i = 1; i < ny - 1; i++)
+                    for (int j = 1; j < nx - 1; j++)
+                        error += rexpo_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, i, nx, nx, j, nx, 1, 1);
+                for (int j = 1; j < nx - 1; j++) {
+                    error += rexpo_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, 0, 0, nx, j, nx, 1, 1);
+                    error += rexpo_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, ny - 1, nx, 0, j, nx, 1, 1);
+                }
+                for (int i = 1; i < ny - 1; i++) {
+                    error += rexpo_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, i, nx, nx, 0, nx, 0, 1);
+                    error += rexpo_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, i, nx, nx, nx - 1, nx, 1, 0);
+                }
+                error += rexpo_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, 0, 0, nx, 0, nx, 0, 1);
+                error += rexpo_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, 0, 0, nx, nx - 1, nx, 1, 0);
+                error += rexpo_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, ny - 1, nx, 0, 0, nx, 0, 1);
+                error += rexpo_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, ny - 1, nx, 0, nx - 1, nx, 1, 0);
+                error = sqrt(error / size);                    /* :411 (size = pixels x channels) */
+            }
+            if (verbose) printf("Iterations: %d Error: %g\n", nsor, error);
+            if (iters) iters[solve] = nsor;
+            solve++;
+        }
+        for (int i = 0; i < size; i++) { u[i] += du[i]; v[i] += dv[i]; }   /* :419-422 */
+    }
+    for (int q = 0; q < NARR; q++) free(a[q]);
+}
+
+/* methods.cpp:463-567 with nzz = 1.  `iters` is laid out [scale][outer*inner].  Returns 1 where zoom_out's Gaussian throws. */
+int orc_robust_expo(const double *I1, const double *I2, double *u, double *v, int nxx, int nyy, int method, double alpha,
+                    double gamma, double lambda, int nscales, double nu, double TOL, int inner_iter, int outer_iter, int verbose,
+                    int *iters)
+{
+    const int nzz = 1;
+    pyramid P;
+    P.nscales = nscales;
+    P.nx = (int *) malloc(sizeof(int) * nscales);
+    P.ny = (int *) malloc(sizeof(int) * nscales);
+    P.A = (double **) calloc(nscales, sizeof(double *));
+    P.B = (double **) calloc(nscales, sizeof(double *));
+    P.u = (double **) calloc(nscales, sizeof(double *));
+    P.v = (double **) calloc(nscales, sizeof(double *));
+    P.nx[0] = nxx; P.ny[0] = nyy;
+    P.A[0] = dalloc((size_t) nxx * nyy);
+    P.B[0] = dalloc((size_t) nxx * nyy);
+    P.u[0] = u; P.v[0] = v;
+    int rc = 0;
+    orc_image_normalization_2_color(I1, I2, P.A[0], P.B[0], nxx * nyy * nzz, nzz);     /* :494 */
+    orc_gaussian_dirichlet(P.A[0], nxx, nyy, (double) nzz);                              /* :497-498: sigma = nzz, bc = (int) 0.8 */
+    orc_gaussian_dirichlet(P.B[0], nxx, nyy, (double) nzz);
+    for (int s = 1; s < nscales && !rc; s++) {
+        orc_zoom_size(P.nx[s - 1], P.ny[s - 1], &P.nx[s], &P.ny[s], nu);
+        const size_t n = (size_t) P.nx[s] * P.ny[s];
+        P.A[s] = dalloc(n); P.B[s] = dalloc(n); P.u[s] = dalloc(n); P.v[s] = dalloc(n);
+        rc |= orc_zoom_out(P.A[s - 1], P.A[s], P.nx[s - 1], P.ny[s - 1], nu);           /* zoom_out_color, nz = 1 */
+        rc |= orc_zoom_out(P.B[s - 1], P.B[s], P.nx[s - 1], P.ny[s - 1], nu);
+    }
+    if (!rc) {
+        const int c = nscales - 1;
+        for (int i = 0; i < P.nx[c] * P.ny[c]; i++) P.u[c][i] = P.v[c][i] = 0.0;
+    }
+    const int alpha_adapted_for_nchannels = (int) (alpha * nzz);                         /* :529: an int */
+    for (int s = nscales - 1; s >= 0 && !rc; s--) {
+        if (verbose) printf("Scale: %d\n", s);
+        rexpo_single_scale(P.A[s], P.B[s], P.u[s], P.v[s], P.nx[s], P.ny[s], method, alpha_adapted_for_nchannels, gamma, lambda,
+                           TOL, inner_iter, outer_iter, verbose, iters ? iters + s * inner_iter * outer_iter : NULL);
+        if (s) pyramid_upsample(&P, s, nu);
+    }
+    pyramid_free(&P);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Brox temporal: src/brox_optic_flow_temporal.cpp + src/brox_temporal_mask.cpp.
  * A sequence of `frames` images gives nz = frames - 1 flow fields coupled through a temporal smoothness term.
  * Arrays are frame-major: element k = f * nx * ny + i * nx + j. */

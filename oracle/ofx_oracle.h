@@ -80,6 +80,13 @@ int  orc_brox_spatial(const double *I1, const double *I2, double *u, double *v, 
                       double alpha, double gamma, int nscales, double nu, double TOL,
                       int inner_iter, int outer_iter, int verbose, int *iters);
 
+/* robust_expo_methods.cpp + robust_expo_smoothness.cpp + robust_expo_generic_tensor.cpp, one channel */
+void orc_gaussian_dirichlet(double *I, int nx, int ny, double sigma);
+void orc_rexpo_exponential(const double *Ix, const double *Iy, int n, double alpha, double lambda, int method, double *expo);
+int  orc_robust_expo(const double *I1, const double *I2, double *u, double *v, int nxx, int nyy, int method, double alpha,
+                     double gamma, double lambda, int nscales, double nu, double TOL, int inner_iter, int outer_iter, int verbose,
+                     int *iters);
+
 /* brox_optic_flow_temporal.cpp + brox_temporal_mask.cpp (+ operators.cpp centered_gradient3, utils.cpp
  * image_normalization_1) */
 void orc_centered_gradient3(const double *in, double *dx, double *dy, double *dz, int nx, int ny, int nz);
