@@ -271,6 +271,17 @@ int ofx_brox_batch_dev(ofx_ctx *const *ctxs, int n_ctx, const void *const *dI1, 
                        void *const *d_flo, int n_pairs, int nxx, int nyy, double alpha, double gamma, int nscales,
                        double nu, double TOL, int inner_iter, int outer_iter, double *work_pix_iters);
 
+/* ---- robust_expo_methods (replace src/robust_expo_methods.h:21-38) -----------------------------------*/
+/* Brox's scheme with an image-driven weight in the smoothness term: method_type 1 = exp(-lambda |grad I1|), 2 = the same
+ * + 0.001, 3 = lambda chosen per pixel from alpha and the gradient distribution.  The reference's argument order.  nzz must
+ * be 1 (OFX_ERR_ARG otherwise): for colour images the reference's pyramid reads beyond its scratch copy (zoom.cpp:96-118).
+ * Kept quirks of the source: the presmoothing is gaussian(I, nx, ny, nzz, 0.8), i.e. sigma = nzz = 1 with the DIRICHLET
+ * boundary (robust_expo_methods.cpp:497-498), and alpha * nzz is truncated to an int (:529).  SOR sweeps run in the
+ * reference's order (windowed exact schedule, option sor_exact = 1); bit-identical to the reference on one thread. */
+int ofx_robust_expo(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nxx, int nyy, int nzz,
+                    int method_type, double alpha, double gamma, double lambda, int nscales, double nu, double TOL,
+                    int inner_iter, int outer_iter, int verbose);
+
 /* ---- Brox temporal (replace src/brox_optic_flow.h:41-55) ---------------------------*/
 /* I: `frames` images of nx*ny, frame-major; u, v: frames - 1 flow fields (u[f] takes frame f to frame f + 1).
  * frames <= 2 is an error ("The method needs more than two frames", brox_optic_flow_temporal.cpp:537-541: the

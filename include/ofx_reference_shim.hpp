@@ -24,6 +24,7 @@
 #include "brox_optic_flow.h"
 #include "horn_schunck.h"
 #include "operators.h"
+#include "robust_expo_methods.h"
 #include "tvl1flow.h"
 #include "tvl1occflow.h"
 #include "tvl1occflow_solvers.h"
@@ -95,6 +96,14 @@ void brox_optic_flow_spatial(const ofpix_t *I1, const ofpix_t *I2, ofpix_t *u, o
 {
     ofx_shim::check(ofx_brox_spatial(ofx_shim::ctx(), I1, I2, u, v, nxx, nyy, alpha, gamma, nscales, nu, TOL, inner_iter, outer_iter,
                                      verbose));
+}
+// ---- src/robust_expo_methods.h:21-38 (one channel; nzz != 1 -> std::runtime_error with the library's message) -----------
+void robust_expo_methods(const ofpix_t *I1, const ofpix_t *I2, ofpix_t *u, ofpix_t *v, const int nxx, const int nyy, const int nzz,
+                         const int method_type, const double alpha, const double gamma, const double lambda, const int nscales,
+                         const double nu, const double TOL, const int inner_iter, const int outer_iter, const bool verbose)
+{
+    ofx_shim::check(ofx_robust_expo(ofx_shim::ctx(), I1, I2, u, v, nxx, nyy, nzz, method_type, alpha, gamma, lambda, nscales, nu,
+                                    TOL, inner_iter, outer_iter, verbose));
 }
 void brox_optic_flow_temporal(const ofpix_t *I, ofpix_t *u, ofpix_t *v, const int nxx, const int nyy, const int frames,
                               const double alpha, const double gamma, const int nscales, const double nu, const double TOL,

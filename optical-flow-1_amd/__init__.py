@@ -93,6 +93,7 @@ def lib():
         "ofx_gaussian": (_i, [_vp, _dp, _i, _i, _d]),
         "ofx_bicubic_at": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _i]),
         "ofx_hypot": (_i, [_vp, _dp, _dp, _dp, _i]),
+        "ofx_robust_expo": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _d, _d, _d, _i, _d, _d, _i, _i, _i]),
         "ofx_bicubic_warp": (_i, [_vp, _dp, _dp, _dp, _dp, _i, _i, _i]),
         "ofx_zoom_size": (None, [_i, _i, C.POINTER(_i), C.POINTER(_i), _d]),
         "ofx_zoom_out": (_i, [_vp, _dp, _dp, _i, _i, _d]),
@@ -302,6 +303,14 @@ class Ofx:
         out = np.empty(uu.shape)
         self._ck(self.L.ofx_bicubic_at(self.h, _f64(I), uu, vv, out, uu.size, nx, ny, int(border_out)))
         return out
+
+    def robust_expo(self, I1, I2, method=1, alpha=50.0, gamma=10.0, lam=1.0, nscales=5, nu=0.5, TOL=1e-4, inner=1, outer=15,
+                    verbose=0, nz=1):
+        ny, nx = I1.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        self._ck(self.L.ofx_robust_expo(self.h, _f64(I1), _f64(I2), u, v, nx, ny, nz, method, alpha, gamma, lam, nscales, nu, TOL,
+                                        inner, outer, verbose))
+        return u, v
 
     def hypot(self, x, y):
         x, y = _f64(np.atleast_1d(x)).ravel(), _f64(np.atleast_1d(y)).ravel()

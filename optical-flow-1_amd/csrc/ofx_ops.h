@@ -10,6 +10,7 @@
 
 struct GaussTaps {
     int    size;                       // kernel radius + 1  == (int)(5 sigma) + 1
+    int    dirichlet;                  // 1: samples outside the image are 0 (BOUNDARY_CONDITION_DIRICHLET); 0: reflecting (default)
     double B[OFX_GAUSS_MAX_TAPS];
 };
 
@@ -30,7 +31,7 @@ template <typename T> int op_normalize2(ofx_ctx *ctx, const T *I1, const T *I2, 
                                         double *d_scratch /* >= 2*2048+2 doubles */);
 
 // gaussian (src/operators.cpp:506-624): I updated in place, tmp is an nx*ny scratch image
-template <typename T> int op_gaussian(ofx_ctx *ctx, T *I, T *tmp, int nx, int ny, double sigma);
+template <typename T> int op_gaussian(ofx_ctx *ctx, T *I, T *tmp, int nx, int ny, double sigma, int dirichlet = 0);
 
 // generic bicubic resampling out(i1,j1) = bicubic(in, j1/fx, i1/fy, border_out=false)
 // (zoom_out: fx=fy=factor, src/zoom.cpp:67-75; zoom_in: per-axis factors, src/zoom.cpp:142-154)

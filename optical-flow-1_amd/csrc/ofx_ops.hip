@@ -222,6 +222,7 @@ int ofx_gauss_taps(double sigma, GaussTaps *t)
     const int size = (int) (5 * sigma) + 1;                 // DEFAULT_GAUSSIAN_WINDOW_SIZE, operators.h:120
     if (size < 1 || size > OFX_GAUSS_MAX_TAPS) return OFX_ERR_ARG;
     t->size = size;
+    t->dirichlet = 0;
     for (int i = 0; i < size; i++)
         t->B[i] = 1 / (sigma * sqrt(2.0 * 3.1415926)) * exp(-i * i / den);   // :527 (pi truncated)
     double norm = 0;
@@ -251,6 +252,19 @@ OFX_DEV void gauss_pass_px(const T *__restrict__ in, T *__restrict__ out, int nx
     if (j >= nx || i >= ny) return;
     const size_t p = (size_t) i * nx + j;
     double sum = taps.B[0] * ldw(in + p);
+    if (taps.dirichlet) {                                    // BOUNDARY_CONDITION_DIRICHLET (:551-555, :591-595): 0 outside the image
+        if (ALONG_X) {
+            const T *row = in + (size_t) i * nx;
+            for (int k = 1; k < taps.size; k++)
+                sum += taps.B[k] * ((j - k >= 0 ? ldw(row + j - k) : 0.0) + (j + k < nx ? ldw(row + j + k) : 0.0));
+        } else {
+            for (int k = 1; k < taps.size; k++)
+                sum += taps.B[k] * ((i - k >= 0 ? ldw(in + (size_t) (i - k) * nx + j) : 0.0) +
+                                    (i + k < ny ? ldw(in + (size_t) (i + k) * nx + j) : 0.0));
+        }
+        stn(out + p, sum);
+        return;
+    }
     if (ALONG_X) {
         const T *row = in + (size_t) i * nx;
         for (int k = 1; k < taps.size; k++)
@@ -318,14 +332,15 @@ __global__ __launch_bounds__(256) void k_gauss_xy_g(OfxPlanes2<const T> in_p, Of
     }
 }
 
-template <typename T> int op_gaussian(ofx_ctx *ctx, T *I, T *tmp, int nx, int ny, double sigma)
+template <typename T> int op_gaussian(ofx_ctx *ctx, T *I, T *tmp, int nx, int ny, double sigma, int dirichlet)
 {
     GaussTaps taps;
     if (ofx_gauss_taps(sigma, &taps) != OFX_OK)
         return ofx_fail(ctx, OFX_ERR_ARG, "gaussian: sigma %g needs more than %d taps", sigma, OFX_GAUSS_MAX_TAPS);
+    taps.dirichlet = dirichlet != 0;
     // reference: throws when size > xdim (:520-522); reads out of bounds when size == xdim or
-    // size >= ydim -- all three are reported as OFX_ERR_SIGMA here.
-    if (taps.size >= nx || taps.size >= ny)
+    // size >= ydim -- all three are reported as OFX_ERR_SIGMA here.  (Dirichlet: no check, the padded line always has room.)
+    if (!dirichlet && (taps.size >= nx || taps.size >= ny))
         return ofx_fail(ctx, OFX_ERR_SIGMA, "GaussianSmooth: sigma too large (radius %d, image %dx%d)",
                         taps.size, nx, ny);
     hipLaunchKernelGGL((k_gauss_pass<T, true>), grid2d(nx, ny), block2d(), 0, ctx->stream, (const T *) I, tmp,
@@ -810,7 +825,7 @@ template <typename T> int op_minmax(ofx_ctx *ctx, const T *x, int size, double *
     template int op_to_flo<T>(ofx_ctx *, const Pix<T>::v2 *, float2 *, size_t);                                       \
     template int op_fill2<T>(ofx_ctx *, Pix<T>::v2 *, size_t);                                                        \
     template int op_normalize2<T>(ofx_ctx *, const T *, const T *, T *, T *, int, double *);                          \
-    template int op_gaussian<T>(ofx_ctx *, T *, T *, int, int, double);                                               \
+    template int op_gaussian<T>(ofx_ctx *, T *, T *, int, int, double, int);                                          \
     template int op_resample<T>(ofx_ctx *, const T *, T *, int, int, int, int, double, double);                       \
     template int op_zoom_in_flow<T>(ofx_ctx *, const Pix<T>::v2 *, Pix<T>::v2 *, int, int, int, int, double);         \
     template int op_zoom_out<T>(ofx_ctx *, const T *, T *, T *, T *, int, int, double);                               \

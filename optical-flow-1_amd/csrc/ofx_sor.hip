@@ -21,6 +21,8 @@
 #include "ofx_device.h"
 #include "ofx_loop.h"
 
+#include <algorithm>
+
 #include <atomic>
 #include <cmath>
 #include <thread>
@@ -1198,20 +1200,31 @@ __global__ void k_brox_warp(const typename Pix<T>::v4 *__restrict__ PA, const ty
 }
 
 // psi_smooth of the centred flow gradient, :254-258 + :99-122
+// Expo != nullptr: robust_expo_psi_smooth (src/robust_expo_smoothness.cpp:26-44), the flow gradient weighed by expo
 template <typename T>
-__global__ void k_brox_psis(const typename Pix<T>::v2 *__restrict__ U, T *__restrict__ Psis, int nx, int ny)
+__global__ void k_brox_psis(const typename Pix<T>::v2 *__restrict__ U, T *__restrict__ Psis, int nx, int ny,
+                            const T *__restrict__ Expo = nullptr)
 {
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= ny) return;
     const size_t go = (size_t) blockIdx.z * nx * ny;             // pair of a lockstep group
     U += go; Psis += go;
+    if (Expo) Expo += go;
     const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
     const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
     const double2 r = ldw2(U + (size_t) i * nx + jr), l = ldw2(U + (size_t) i * nx + jl);
     const double2 d = ldw2(U + (size_t) id * nx + j), t = ldw2(U + (size_t) iu * nx + j);
     const double ux = 0.5 * (r.x - l.x), uy = 0.5 * (d.x - t.x);
     const double vx = 0.5 * (r.y - l.y), vy = 0.5 * (d.y - t.y);
+    if (Expo) {
+        const double e = ldw(Expo + (size_t) i * nx + j);
+        const double du = e * ux * ux + e * uy * uy;
+        const double dv = e * vx * vx + e * vy * vy;
+        const double normFlow = du + dv;
+        stn(Psis + (size_t) i * nx + j, e / sqrt(normFlow + BROX_EPSILON * BROX_EPSILON));       // ROBUST_EXPO_EPSILON = 0.001 too
+        return;
+    }
     const double du = ux * ux + uy * uy;
     const double dv = vx * vx + vy * vy;
     const double d2 = du + dv;
@@ -1239,7 +1252,7 @@ template <typename T> OFX_DEV Psi4 brox_psi4(const T *Psis, int i, int j, int nx
 template <typename T>
 __global__ void k_brox_div(const typename Pix<T>::v2 *__restrict__ U, const T *__restrict__ Psis,
                            typename Pix<T>::v2 *__restrict__ DV, T *__restrict__ Dd, typename Pix<T>::v2 *__restrict__ DU,
-                           int nx, int ny, double alpha)
+                           int nx, int ny, double alpha, int rx = 0)
 {
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
@@ -1249,6 +1262,32 @@ __global__ void k_brox_div(const typename Pix<T>::v2 *__restrict__ U, const T *_
     const size_t k = (size_t) i * nx + j;
     const Psi4 s = brox_psi4(Psis, i, j, nx, ny);
     const double2 c = ldw2(U + k);
+    if (rx) {
+        // robust_expo_divergence / div_d (src/robust_expo_generic_tensor.cpp:97-168, robust_expo_methods.cpp:266): the same
+        // terms in the order right, left, down, up
+        double du = 0.0, dv = 0.0;
+        bool have = false;
+        if (j < nx - 1) { const double2 q = ldw2(U + k + 1); du = s.p3 * (q.x - c.x); dv = s.p3 * (q.y - c.y); have = true; }
+        if (j > 0) {
+            const double2 q = ldw2(U + k - 1);
+            const double a = s.p4 * (q.x - c.x), b = s.p4 * (q.y - c.y);
+            du = have ? du + a : a; dv = have ? dv + b : b; have = true;
+        }
+        if (i < ny - 1) {
+            const double2 q = ldw2(U + k + nx);
+            const double a = s.p1 * (q.x - c.x), b = s.p1 * (q.y - c.y);
+            du = have ? du + a : a; dv = have ? dv + b : b; have = true;
+        }
+        if (i > 0) {
+            const double2 q = ldw2(U + k - nx);
+            const double a = s.p2 * (q.x - c.x), b = s.p2 * (q.y - c.y);
+            du = have ? du + a : a; dv = have ? dv + b : b; have = true;
+        }
+        stn2(DV + k, make_double2(du, dv));
+        stn(Dd + k, alpha * (s.p3 + s.p4 + s.p1 + s.p2));
+        stn2(DU + k, make_double2(0.0, 0.0));
+        return;
+    }
     // terms that exist, accumulated in the order down, up, right, left; missing terms are left out
     double du = 0.0, dv = 0.0;
     bool have = false;
@@ -1279,7 +1318,7 @@ __global__ void k_brox_coeff(const T *__restrict__ I1, const typename Pix<T>::v2
                              const typename Pix<T>::v4 *__restrict__ WA, const typename Pix<T>::v2 *__restrict__ WB,
                              const typename Pix<T>::v2 *__restrict__ DU, const typename Pix<T>::v2 *__restrict__ DV,
                              const T *__restrict__ Dd, typename Pix<T>::v4 *__restrict__ CO, T *__restrict__ Dm, int n,
-                             double alpha, double gamma)
+                             double alpha, double gamma, int rx = 0)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t) n) return;
@@ -1290,6 +1329,30 @@ __global__ void k_brox_coeff(const T *__restrict__ I1, const typename Pix<T>::v2
     const double2 d = ldw2(DU + i);
     const double I2w = wa.x, I2wx = wa.y, I2wy = wa.z, I2wxx = wa.w, I2wxy = wb.x, I2wyy = wb.y;
     const double eps2 = BROX_EPSILON * BROX_EPSILON;
+    if (rx) {
+        // robust_expo_methods.cpp:48-60, :85-102, :279-322 for one channel: the motion terms are added before I1 is subtracted,
+        // every per-channel sum is accumulated onto 0, and psi multiplies the finished sums
+        const double dI = I2w + I2wx * d.x + I2wy * d.y - i1;
+        const double psid = rnd_to<T>(1. / sqrt((0.0 + dI * dI) + eps2));
+        const double dIx = I2wx + I2wxx * d.x + I2wxy * d.y - g1.x;
+        const double dIy = I2wy + I2wxy * d.x + I2wyy * d.y - g1.y;
+        const double psig = rnd_to<T>(1. / sqrt((0.0 + (dIx * dIx + dIy * dIy)) + eps2));
+        const double dif = I2w - i1;
+        double BNu = 0.0 + dif * I2wx, BNv = 0.0 + dif * I2wy, BDu = 0.0 + I2wx * I2wx, BDv = 0.0 + I2wy * I2wy;
+        const double DI_Data = 0.0 + (I2wy * I2wx);
+        const double dx = (I2wx - g1.x), dy = (I2wy - g1.y);
+        double GNu = 0.0 + (dx * I2wxx + dy * I2wxy), GNv = 0.0 + (dx * I2wxy + dy * I2wyy);
+        double GDu = 0.0 + (I2wxx * I2wxx + I2wxy * I2wxy), GDv = 0.0 + (I2wyy * I2wyy + I2wxy * I2wxy);
+        const double DI_Gradient = 0.0 + (I2wxx + I2wyy) * I2wxy;
+        const double g = gamma * psig;
+        BNu = -psid * BNu; BNv = -psid * BNv; BDu = psid * BDu; BDv = psid * BDv;
+        GNu = -g * GNu; GNv = -g * GNv; GDu = g * GDu; GDv = g * GDv;
+        const double2 dvv = ldw2(DV + i);
+        const double dd = ldw(Dd + i);
+        stn4(CO + i, make_double4(BNu + GNu + alpha * dvv.x, BNv + GNv + alpha * dvv.y, BDu + GDu + dd, BDv + GDv + dd));
+        stn(Dm + i, psid * DI_Data + g * DI_Gradient);
+        return;
+    }
     const double dI = I2w - i1 + I2wx * d.x + I2wy * d.y;                              // psi_data :51
     const double psid = rnd_to<T>(1. / sqrt(dI * dI + eps2));
     const double dIx = I2wx - g1.x + I2wxx * d.x + I2wxy * d.y;                        // psi_gradient :86-87
@@ -1351,27 +1414,30 @@ OFX_DEV BroxOps brox_point_load(const Acc &acc, const typename Pix<T>::v4 *__res
     acc.coef4(CO, Dm, i, j, o.co, o.D);
     return o;
 }
-template <typename T, class Acc>
+// RX: robust_expo_methods.cpp:138-148 -- the same taps summed right, left, down, up
+template <typename T, class Acc, bool RX = false>
 OFX_DEV double brox_point_finish(const Acc &acc, const BroxOps &o, int i, int j, double alpha)
 {
     const Psi4 s = o.s;
     const double4 co = o.co;
     const double D = o.D;
     const double w = BROX_SOR_W;
-    const double div_du = s.p1 * o.dn.x + s.p2 * o.up.x + s.p3 * o.rt.x + s.p4 * o.lf.x;      // :153-154
-    const double div_dv = s.p1 * o.dn.y + s.p2 * o.up.y + s.p3 * o.rt.y + s.p4 * o.lf.y;      // :155-156
+    const double div_du = RX ? s.p3 * o.rt.x + s.p4 * o.lf.x + s.p1 * o.dn.x + s.p2 * o.up.x
+                             : s.p1 * o.dn.x + s.p2 * o.up.x + s.p3 * o.rt.x + s.p4 * o.lf.x;      // :153-154
+    const double div_dv = RX ? s.p3 * o.rt.y + s.p4 * o.lf.y + s.p1 * o.dn.y + s.p2 * o.up.y
+                             : s.p1 * o.dn.y + s.p2 * o.up.y + s.p3 * o.rt.y + s.p4 * o.lf.y;      // :155-156
     const double duk = o.c.x, dvk = o.c.y;
     const double dun = rnd_to<T>((1. - w) * duk + w * (co.x - D * dvk + alpha * div_du) / co.z);   // :162
     const double dvn = rnd_to<T>((1. - w) * dvk + w * (co.y - D * dun + alpha * div_dv) / co.w);   // :163
     acc.put(i, j, make_double2(dun, dvn));
     return (dun - duk) * (dun - duk) + (dvn - dvk) * (dvn - dvk);                     // :166
 }
-template <typename T, class Acc>
+template <typename T, class Acc, bool RX = false>
 OFX_DEV double brox_point_acc(const Acc &acc, const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
                               const T *__restrict__ Psis, int i, int j, int nx, int ny, double alpha)
 {
     const BroxOps o = brox_point_load<T>(acc, CO, Dm, Psis, i, j, nx, ny);
-    return brox_point_finish<T>(acc, o, i, j, alpha);
+    return brox_point_finish<T, Acc, RX>(acc, o, i, j, alpha);
 }
 
 template <typename T, bool COH = false, bool SNAP = false>
@@ -1450,7 +1516,7 @@ __global__ __launch_bounds__(64) void k_brox_plane(typename Pix<T>::v2 *__restri
 }
 
 // windowed exact mode (see k_hs_window): K steps per launch, one workgroup per (SPW sweeps, row block)
-template <typename T, int SPW, int MAXT>
+template <typename T, int SPW, int MAXT, bool RX = false>
 __global__ __launch_bounds__(MAXT) void k_brox_window(typename Pix<T>::v2 *DUg, typename Pix<T>::v2 *snap,
                                                       const typename Pix<T>::v4 *__restrict__ COg, const T *__restrict__ Dmg,
                                                       const T *__restrict__ Psisg, double *__restrict__ errg, SorWin w,
@@ -1497,15 +1563,19 @@ __global__ __launch_bounds__(MAXT) void k_brox_window(typename Pix<T>::v2 *DUg, 
             typename Pix<T>::v2 *mysnap = snap + g * grp.snap_stride + (size_t) (s0 + u) * grp.npix;
             if (have[u]) {
                 const UGlobal<T, OFX_SOR_COH != 0, true, LaySkew> acc = {DU, mysnap, LaySkew{ny, BROX_PLANE_C_SKEW}};
-                if (SPW > 1) e[u] += brox_point_finish<T>(acc, ops[u], pi[u], pj[u], alpha);
-                else e[u] += brox_point_acc<T>(acc, CO, Dm, Psis, pi[u], pj[u], nx, ny, alpha);
+                using AccT = UGlobal<T, OFX_SOR_COH != 0, true, LaySkew>;
+                if (SPW > 1) e[u] += brox_point_finish<T, AccT, RX>(acc, ops[u], pi[u], pj[u], alpha);
+                else e[u] += brox_point_acc<T, AccT, RX>(acc, CO, Dm, Psis, pi[u], pj[u], nx, ny, alpha);
             }
             const int q = q_first[u] + k;
             if (live[u] && r == ny + 2 && q >= 0 && q <= qmax) {
                 int i, j;
                 for (int corner = 0; corner < 4; corner++)
-                    if (brox_plane_item(r, q, nx, ny, corner, i, j) && sor_border_block(i, ny, w.R) == b)
-                        e[u] += brox_point_skew<T, OFX_SOR_COH != 0, true>(DU, CO, Dm, Psis, i, j, nx, ny, alpha, mysnap);
+                    if (brox_plane_item(r, q, nx, ny, corner, i, j) && sor_border_block(i, ny, w.R) == b) {
+                        using AccT = UGlobal<T, OFX_SOR_COH != 0, true, LaySkew>;
+                        const AccT cacc = {DU, mysnap, LaySkew{ny, BROX_PLANE_C_SKEW}};
+                        e[u] += brox_point_acc<T, AccT, RX>(cacc, CO, Dm, Psis, i, j, nx, ny, alpha);
+                    }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1652,6 +1722,7 @@ template <typename T> struct BroxLevel {
     v2 *DUs, *Snap;
     v4 *COs;
     T  *Dms, *Psiss;
+    T  *Expo = nullptr;   // robust_expo: the smoothness weight of the level (allocated when needed)
     int snap_planes;
     int sweep_hint;
     size_t n() const { return (size_t) nx * ny; }
@@ -1689,9 +1760,55 @@ template <typename T> static int brox_level_alloc(ofx_ctx *ctx, BroxLevel<T> &L,
 struct BroxParams {
     double alpha, gamma, TOL;
     int inner_iter, outer_iter, verbose;
+    // robust_expo_methods: Brox's scheme with the image-driven smoothness weight `expo` and that source's own
+    // summation orders (the kernels' rx / RX variants); 0 = Brox
+    int robust = 0, method = 1;
+    double lambda = 0.0;
 };
 
 // src/brox_optic_flow_spatial.cpp:179-444 on device data for the G pairs of a lockstep group; stats[g] = record of pair g
+// robust_expo_exponential_calculation (src/robust_expo_smoothness.cpp:128-187, one channel): expo = exp(-lambda |grad I1|)
+// (+ 0.001 for method 2), method 3 with a per-pixel lambda bounded by the value at the 0.94 quantile of the sorted gradient
+// magnitudes.  Evaluated on the HOST once per level: the reference calls libm's exp and log, whose last bit the device's
+// math library does not promise to share, and method 3 sorts the level (std::sort there, here).  The gradient comes from the
+// level's (I1x, I1y) pairs the prepare kernel has just written.
+template <typename T> static int rexpo_level_expo(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams &P)
+{
+    const size_t n = L.n();
+    if (!L.Expo) OFX_TRY(ofx_alloc(ctx, n, &L.Expo));
+    std::vector<typename Pix<T>::v2> g1(n);
+    std::vector<T> expo(n);
+    OFX_HIP(ctx, hipMemcpyAsync(g1.data(), L.G1, n * sizeof(typename Pix<T>::v2), hipMemcpyDeviceToHost, ctx->stream));
+    OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<double> mg(n);
+    for (size_t i = 0; i < n; i++) {
+        const double ix = (double) g1[i].x, iy = (double) g1[i].y;
+        mg[i] = sqrt(ix * ix + iy * iy);
+    }
+    if (P.method == 1 || P.method == 2) {
+        const double beta = P.method == 2 ? 0.001 : 0.0;
+        for (size_t i = 0; i < n; i++) expo[i] = (T) (exp(-P.lambda * mg[i]) + beta);
+    } else {
+        std::vector<double> ord(mg);
+        std::sort(ord.begin(), ord.end());
+        const double c = -log(0.05) + log(P.alpha);
+        long pos_ref = (long) (int) (0.94 * (double) (int) n);
+        double lambda_omega;
+        while (pos_ref < (long) n && c / 2 > ord[pos_ref - 1]) pos_ref++;
+        if (pos_ref == (long) n) lambda_omega = 0;
+        else lambda_omega = c / ord[pos_ref - 1];
+        for (size_t i = 0; i < n; i++) {
+            const double lp = (-log(0.05) + log(P.alpha)) / mg[i];
+            double lambda_pi = lambda_omega;
+            if (lambda_omega > lp) lambda_pi = lp;
+            expo[i] = (T) exp(-lambda_pi * mg[i]);
+        }
+    }
+    OFX_HIP(ctx, hipMemcpyAsync(L.Expo, expo.data(), n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    OFX_HIP(ctx, hipStreamSynchronize(ctx->stream));               // `expo` is a local
+    return OFX_OK;
+}
+
 template <typename T>
 static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams &P, int scale, ofx_stats *stats)
 {
@@ -1705,16 +1822,20 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
     if (G > 1 && !windowed)
         return ofx_fail(ctx, OFX_ERR_ARG, "brox: lockstep groups need sor_exact = 1 and levels of at least 3x3 (%dx%d)", nx, ny);
     int solve = 0;
+    const int rx = P.robust;
+    if (rx && (!windowed || G != 1))
+        return ofx_fail(ctx, OFX_ERR_ARG, "robust_expo: needs sor_exact = 1 and levels of at least 3x3 (%dx%d)", nx, ny);
     hipLaunchKernelGGL(k_brox_prepare<T>, g, b, 0, ctx->stream, (const T *) L.I1, (const T *) L.I2, L.G1, L.PA, L.PB, nx, ny);
     OFX_LAUNCH_CHECK(ctx);
+    if (rx) OFX_TRY(rexpo_level_expo<T>(ctx, L, P));                                              // robust_expo_methods.cpp:231
     for (int no = 0; no < P.outer_iter; no++) {                                                   // :244
         hipLaunchKernelGGL(k_brox_warp<T>, g, b, 0, ctx->stream, L.PA, L.PB, L.U, L.WA, L.WB, nx, ny);
-        hipLaunchKernelGGL(k_brox_psis<T>, g, b, 0, ctx->stream, L.U, L.Psis, nx, ny);
-        hipLaunchKernelGGL(k_brox_div<T>, g, b, 0, ctx->stream, L.U, (const T *) L.Psis, L.DV, L.Dd, L.DU, nx, ny, P.alpha);
+        hipLaunchKernelGGL(k_brox_psis<T>, g, b, 0, ctx->stream, L.U, L.Psis, nx, ny, (const T *) (rx ? L.Expo : nullptr));
+        hipLaunchKernelGGL(k_brox_div<T>, g, b, 0, ctx->stream, L.U, (const T *) L.Psis, L.DV, L.Dd, L.DU, nx, ny, P.alpha, rx);
         OFX_LAUNCH_CHECK(ctx);
         for (int ni = 0; ni < P.inner_iter; ni++) {                                               // :277
             hipLaunchKernelGGL(k_brox_coeff<T>, g1, b1, 0, ctx->stream, (const T *) L.I1, L.G1, L.WA, L.WB, L.DU, L.DV,
-                               (const T *) L.Dd, L.CO, L.Dm, (int) (npix * G), P.alpha, P.gamma);
+                               (const T *) L.Dd, L.CO, L.Dm, (int) (npix * G), P.alpha, P.gamma, rx);
             OFX_LAUNCH_CHECK(ctx);
             int nsor[OFX_MAX_GROUP] = {0};
             double error[OFX_MAX_GROUP];
@@ -1742,6 +1863,13 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
                 const size_t snap_stride = ps * L.snap_planes;
                 auto window = [&](const SorWin &w, int blocks, int sweeps, unsigned runmask, int err_stride) -> int {
                     const SorGrp grp = {runmask, err_stride, ps, snap_stride};
+                    if (rx) {                                    // robust_expo: the global window kernel with its summation order
+                        hipLaunchKernelGGL((k_brox_window<T, 1, 1024, true>), dim3(blocks, sweeps, G), dim3(sor_window_threads(w.R + 3)),
+                                           0, ctx->stream, L.DUs, L.Snap, L.COs, (const T *) L.Dms, (const T *) L.Psiss, ctx->d_err, w,
+                                           grp, sweeps, nx, ny, P.alpha);
+                        OFX_LAUNCH_CHECK(ctx);
+                        return OFX_OK;
+                    }
                     const int spw = sor_pick_spw(ctx, G);
                     const size_t lds_need = (size_t) sor_window_threads(w.R + 3) * w.K * (sizeof(double4) + sizeof(double)) +
                                             (size_t) (w.R + 3) * (w.K + 5) * (sizeof(double2) + sizeof(double));
@@ -1825,7 +1953,11 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
                 };
                 OFX_TRY(ofx_run_loop(ctx, LS, launch, [](int) { return OFX_OK; }, &nsor[0], &error[0], ctx->profile ? &ms : nullptr));
             }
-            if (P.verbose && G == 1) { printf("Iterations: %d\n", nsor[0]); fflush(stdout); }     // :392-394
+            if (P.verbose && G == 1) {                                                            // :392-394 / robust :414-416
+                if (rx) printf("Iterations: %d Error: %g\n", nsor[0], error[0]);
+                else printf("Iterations: %d\n", nsor[0]);
+                fflush(stdout);
+            }
             for (int q = 0; q < G; q++) {
                 ofx_stats &S = stats[q];
                 if (scale < OFX_MAX_SCALES) {
@@ -1865,6 +1997,18 @@ static int brox_spatial_dev(ofx_ctx *ctx, int G, const T *const *dI1, const T *c
         OFX_TRY(ofx_alloc(ctx, (size_t) G * op_pyramid_scratch_doubles(), &scr));
         std::vector<T *> lA(nscales), lB(nscales);
         for (int s = 0; s < nscales; s++) { lA[s] = lv[s].I1; lB[s] = lv[s].I2; }
+        if (P.robust) {
+            // robust_expo_methods.cpp:494-525 for one channel: image_normalization_2_color == image_normalization_2, then
+            // gaussian(I, nx, ny, nzz, GAUSSIAN_SIGMA) -- i.e. sigma = the number of channels = 1 and boundary condition
+            // (int) 0.8 = BOUNDARY_CONDITION_DIRICHLET --, then zoom_out_color == zoom_out
+            OFX_TRY(op_normalize2<T>(ctx, dI1[0], dI2[0], lA[0], lB[0], nx * ny, scr));
+            OFX_TRY(op_gaussian<T>(ctx, lA[0], tmpA, nx, ny, 1.0, 1));
+            OFX_TRY(op_gaussian<T>(ctx, lB[0], tmpA, nx, ny, 1.0, 1));
+            for (int s = 1; s < nscales; s++) {
+                OFX_TRY(op_zoom_out<T>(ctx, lA[s - 1], lA[s], tmpA, tmpB, nxs[s - 1], nys[s - 1], nu));
+                OFX_TRY(op_zoom_out<T>(ctx, lB[s - 1], lB[s], tmpA, tmpB, nxs[s - 1], nys[s - 1], nu));
+            }
+        } else
         OFX_TRY(op_build_pyramid_group<T>(ctx, G, (const void *const *) dI1, (const void *const *) dI2, nscales, nu,
                                           BROX_SIGMA, nxs.data(), nys.data(), lA.data(), lB.data(), tmpA, tmpB, scr));
     }
@@ -1915,6 +2059,30 @@ extern "C" int ofx_brox_spatial(ofx_ctx *ctx, const double *I1, const double *I2
     if (inner_iter < 0 || outer_iter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "brox: negative iteration count");
     const double t0 = ofx_now_ms();
     const BroxParams P = {alpha, gamma, TOL, inner_iter, outer_iter, verbose};
+    int s = ctx->precision == OFX_F64 ? brox_spatial_host<double>(ctx, I1, I2, u, v, nxx, nyy, P, nscales, nu)
+                                      : brox_spatial_host<float>(ctx, I1, I2, u, v, nxx, nyy, P, nscales, nu);
+    ctx->stats.total_ms = ofx_now_ms() - t0;
+    return s;
+}
+
+// robust_expo_methods (src/robust_expo_methods.h:21-38), one channel
+extern "C" int ofx_robust_expo(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v, int nxx, int nyy, int nzz,
+                               int method_type, double alpha, double gamma, double lambda, int nscales, double nu, double TOL,
+                               int inner_iter, int outer_iter, int verbose)
+{
+    OFX_ENTER(ctx);
+    if (!I1 || !I2 || !u || !v) return ofx_fail(ctx, OFX_ERR_ARG, "robust_expo: NULL pointer");
+    if (nzz != 1)
+        return ofx_fail(ctx, OFX_ERR_ARG, "robust_expo: nzz=%d (one channel only: for colour the reference's pyramid reads beyond its "
+                                          "scratch copy, zoom.cpp:96-118)", nzz);
+    if (method_type < 1 || method_type > 3) return ofx_fail(ctx, OFX_ERR_ARG, "robust_expo: method_type=%d (1, 2 or 3)", method_type);
+    if (inner_iter < 0 || outer_iter < 0) return ofx_fail(ctx, OFX_ERR_ARG, "robust_expo: negative iteration count");
+    if (ctx->sor_exact != 1) return ofx_fail(ctx, OFX_ERR_ARG, "robust_expo: needs the default option sor_exact = 1");
+    const double t0 = ofx_now_ms();
+    BroxParams P = {(double) (int) (alpha * nzz), gamma, TOL, inner_iter, outer_iter, verbose};     // :529: alpha * nzz as an int
+    P.robust = 1;
+    P.method = method_type;
+    P.lambda = lambda;
     int s = ctx->precision == OFX_F64 ? brox_spatial_host<double>(ctx, I1, I2, u, v, nxx, nyy, P, nscales, nu)
                                       : brox_spatial_host<float>(ctx, I1, I2, u, v, nxx, nyy, P, nscales, nu);
     ctx->stats.total_ms = ofx_now_ms() - t0;

@@ -344,6 +344,30 @@ class Oracle(_Lib):
             raise ValueError("GaussianSmooth: sigma too large")
         return u, v, np.array(list(iters)).reshape(nscales, inner * outer)
 
+    def robust_expo(self, I1, I2, method=1, alpha=50.0, gamma=10.0, lam=1.0, nscales=5, nu=0.5, TOL=1e-4, inner=1, outer=15,
+                    verbose=0):
+        """robust_expo_methods, one channel -> (u, v, sweep counts [scale][outer * inner])"""
+        ny, nx = I1.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        iters = (C.c_int * (inner * outer * nscales))()
+        rc = self._fn("robust_expo", C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                      C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _ip)(
+            _f64(I1), _f64(I2), u, v, nx, ny, method, alpha, gamma, lam, nscales, nu, TOL, inner, outer, verbose, iters)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return u, v, np.array(list(iters)).reshape(nscales, inner * outer)
+
+    def gaussian_dirichlet(self, I, sigma):
+        out = _f64(I).copy()
+        self._fn("gaussian_dirichlet", None, _dp, C.c_int, C.c_int, C.c_double)(out, I.shape[1], I.shape[0], sigma)
+        return out
+
+    def rexpo_exponential(self, Ix, Iy, alpha, lam, method):
+        expo = np.empty(Ix.shape)
+        self._fn("rexpo_exponential", None, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp)(
+            _f64(Ix), _f64(Iy), Ix.size, alpha, lam, method, expo)
+        return expo
+
     def brox_temporal(self, I, alpha=18.0, gamma=7.0, nscales=10, nu=0.75, TOL=1e-4, inner=1, outer=15, verbose=0):
         """I: (frames, ny, nx).  Returns u, v of shape (frames - 1, ny, nx) and the sweep counts [scale][solve]."""
         frames, ny, nx = I.shape
@@ -458,6 +482,29 @@ class Ref(_Lib):
         if rc:
             raise ValueError("GaussianSmooth: sigma too large")
         return u, v
+
+    def robust_expo(self, I1, I2, method=1, alpha=50.0, gamma=10.0, lam=1.0, nscales=5, nu=0.5, TOL=1e-4, inner=1, outer=15,
+                    verbose=0):
+        """the reference's robust_expo_methods with nzz = 1 -> (u, v)"""
+        ny, nx = I1.shape
+        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        rc = self._fn("robust_expo", C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                      C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int)(
+            _f64(I1), _f64(I2), u, v, nx, ny, 1, method, alpha, gamma, lam, nscales, nu, TOL, inner, outer, verbose)
+        if rc:
+            raise ValueError("GaussianSmooth: sigma too large")
+        return u, v
+
+    def gaussian_bc(self, I, sigma, bc):
+        out = _f64(I).copy()
+        self._fn("gaussian_bc", None, _dp, C.c_int, C.c_int, C.c_double, C.c_int)(out, I.shape[1], I.shape[0], sigma, bc)
+        return out
+
+    def rexpo_exponential(self, Ix, Iy, alpha, lam, method):
+        expo = np.empty(Ix.shape)
+        self._fn("rexpo_exponential", None, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _dp)(
+            _f64(Ix), _f64(Iy), Ix.size, Ix.size, 1, alpha, lam, method, expo)
+        return expo
 
     def brox_temporal(self, I, alpha=18.0, gamma=7.0, nscales=10, nu=0.75, TOL=1e-4, inner=1, outer=15, verbose=0):
         frames, ny, nx = I.shape

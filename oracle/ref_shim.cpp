@@ -24,6 +24,8 @@
 #include "tvl1occflow_solvers.h"
 #include "tvl1occflow_tv_rof_box.h"
 #include "tvl1occflow.h"
+#include "robust_expo_methods.h"
+#include "robust_expo_smoothness.h"
 
 #include <cstdlib>
 #include <new>
@@ -154,6 +156,23 @@ int ref_brox_spatial(const double *I1, const double *I2, double *u, double *v, i
     } catch (const std::runtime_error &) { return 1; }
     return 0;
 }
+
+// robust_expo_methods (robust_expo_methods.h:21-38), one channel; the multiscale entry.  The reference reports its sweep counts
+// only on stdout (verbose), so they are not returned here.
+int ref_robust_expo(const double *I1, const double *I2, double *u, double *v, int nx, int ny, int nz, int method_type,
+                    double alpha, double gamma, double lambda, int nscales, double nu, double TOL, int inner_iter,
+                    int outer_iter, int verbose)
+{
+    try {
+        robust_expo_methods(I1, I2, u, v, nx, ny, nz, method_type, alpha, gamma, lambda, nscales, nu, TOL, inner_iter,
+                            outer_iter, verbose != 0);
+    } catch (const std::runtime_error &) { return 1; }
+    return 0;
+}
+void ref_rexpo_exponential(const double *Ix, const double *Iy, int size_flow, int size, int nz, double alpha, double lambda,
+                           int method_type, double *expo)
+{ robust_expo_exponential_calculation(Ix, Iy, size_flow, size, nz, alpha, lambda, method_type, expo); }
+void ref_gaussian_bc(double *I, int nx, int ny, double sigma, int bc) { gaussian(I, nx, ny, sigma, bc); }
 
 int ref_brox_temporal(const double *I, double *u, double *v, int nx, int ny, int frames, double alpha,
                       double gamma, int nscales, double nu, double TOL, int inner_iter, int outer_iter, int verbose)

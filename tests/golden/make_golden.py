@@ -33,6 +33,10 @@ SOLVER_CASES = {
     "tvl1_p1_96x64_z07": ("tvl1", "P1", 96, 64, dict(nscales=3, zfactor=0.7, **TVL1)),
     "hs_p1_96x64": ("hs", "P1", 96, 64, dict(alpha=20.0, nscales=3, zfactor=0.5, warps=4, TOL=1e-4, maxiter=150)),
     "brox_p1_96x64": ("brox", "P1", 96, 64, dict(alpha=50.0, gamma=10.0, nscales=3, nu=0.5, TOL=1e-4, inner=1, outer=4)),
+    # robust_expo_methods, one channel: decreasing function with a fixed lambda, with the beta offset, automatic lambda
+    "rexpo_m1_p1_96x64": ("rexpo", "P1", 96, 64, dict(method=1, alpha=50.0, gamma=10.0, lam=0.1, nscales=3, nu=0.5, TOL=1e-4, inner=1, outer=4)),
+    "rexpo_m2_p0_80x60": ("rexpo", "P0", 80, 60, dict(method=2, alpha=18.7, gamma=5.0, lam=0.05, nscales=2, nu=0.5, TOL=1e-4, inner=2, outer=3)),
+    "rexpo_m3_p1_72x56": ("rexpo", "P1", 72, 56, dict(method=3, alpha=30.0, gamma=10.0, lam=1.0, nscales=2, nu=0.5, TOL=1e-4, inner=1, outer=3)),
     # temporal Brox: "pair" is the number of frames of synth.sequence
     "broxt_seq4_64x48": ("broxt", 4, 64, 48, dict(alpha=18.0, gamma=7.0, nscales=2, nu=0.75, TOL=1e-4, inner=1, outer=3)),
     "broxt_seq3_48x40": ("broxt", 3, 48, 40, dict(alpha=30.0, gamma=0.0, nscales=2, nu=0.5, TOL=1e-4, inner=2, outer=2)),
@@ -48,9 +52,9 @@ def run_verbose(case):
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", case], capture_output=True, text=True,
                          check=True)
     kind = SOLVER_CASES[case][0]
-    text = out.stderr if kind not in ("brox", "broxt") else out.stdout
+    text = out.stderr if kind not in ("brox", "broxt", "rexpo") else out.stdout
     pat = {"tvl1": r"Iterations: (\d+),", "hs": r"Iterations (\d+) \(", "brox": r"Iterations: (\d+)",
-           "broxt": r"Iterations: (\d+)", "occ": r"Iterations: (\d+),"}[kind]
+           "broxt": r"Iterations: (\d+)", "occ": r"Iterations: (\d+),", "rexpo": r"Iterations: (\d+)"}[kind]
     iters = [int(x) for x in re.findall(pat, text)]
     data = np.load(os.path.join(HERE, "_child.npz"))
     u, v = data["u"], data["v"]
@@ -73,7 +77,7 @@ def child(case):
         u, v = ref.brox_temporal(synth.sequence(nx, ny, pair), verbose=1, **kw)
     else:
         I0, I1 = synth.pair(pair, nx, ny)
-        fn = {"tvl1": ref.tvl1_multiscale, "hs": ref.hs_pyramidal, "brox": ref.brox_spatial}[kind]
+        fn = {"tvl1": ref.tvl1_multiscale, "hs": ref.hs_pyramidal, "brox": ref.brox_spatial, "rexpo": ref.robust_expo}[kind]
         u, v = fn(I0, I1, verbose=1, **kw)
     sys.stdout.flush()
     np.savez(os.path.join(HERE, "_child.npz"), u=u, v=v)

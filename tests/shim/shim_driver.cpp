@@ -75,6 +75,9 @@ int main(int argc, char **argv)
             image_normalization_4(I0, I1, I2, I1, a.data(), b.data(), c.data(), u.data(), n);
             put(fo, a); put(fo, b); put(fo, c); put(fo, u);
         }
+        // robust_expo_methods through its own header (src/robust_expo_methods.h), one channel
+        robust_expo_methods(I0, I1, u.data(), v.data(), nx, ny, 1, 2, 18.7, 5.0, 0.05, 2, 0.5, 1e-4, 1, 3, false);
+        put(fo, u); put(fo, v);
         // the reference's failure mode: an exception with its own text
         try {
             std::vector<ofpix_t> tiny(9, 1.0);

@@ -66,4 +66,6 @@ def test_reference_prototypes_through_the_shim(orc, synth, tmp_path):
     assert np.array_equal(take(S), orc.median_filtering(seq[0], 3))
     for want in orc.image_normalization_4(seq[0], seq[1], seq[2], seq[1]):
         assert np.array_equal(take(S), want)
+    uo, vo, _ = orc.robust_expo(I0, I1, method=2, alpha=18.7, gamma=5.0, lam=0.05, nscales=2, nu=0.5, TOL=1e-4, inner=1, outer=3)
+    assert np.abs(take(S) - uo).max() < 1e-11 and np.abs(take(S) - vo).max() < 1e-11
     assert pos[0] == out.size

@@ -455,3 +455,39 @@ def test_sor_groups_need_the_exact_mode(ofx_mod, gpu64, synth):
         gpu64.set_option("sor_exact", 1)
     with pytest.raises(ofx_mod.OfxError):
         gpu64.brox_group_dev([], [], [], 64, 48)
+
+
+# ---- robust_expo_methods, one channel ------------------------------------------------------------------------
+@pytest.mark.parametrize("pair,nx,ny,ns,kw", [
+    ("P1", 64, 48, 2, dict(method=1, alpha=50.0, gamma=10.0, lam=0.1, outer=4)),
+    ("P0", 96, 64, 3, dict(method=2, alpha=18.7, gamma=5.0, lam=0.05, outer=3, inner=2)),
+    ("P1", 80, 60, 2, dict(method=3, alpha=30.0, gamma=10.0, lam=1.0, outer=3)),
+    ("P1", 33, 21, 1, dict(method=1, alpha=7.9, gamma=0.0, lam=0.3, outer=5)),
+    ("P1", 320, 240, 4, dict(method=1, alpha=50.0, gamma=10.0, lam=0.1, outer=5))])
+def test_robust_expo_exact(gpu64, orc, synth, pair, nx, ny, ns, kw):
+    """ofx_robust_expo against the oracle (== the compiled reference, tests/test_oracle_vs_ref.py): the three decreasing
+    functions, alpha truncated to an int, the Dirichlet presmoothing with sigma = 1, the right-left-down-up sums: sweep
+    tables equal, flows to < 1e-11 (the order of the stopping sum is the only difference)"""
+    I1, I2 = synth.pair(pair, nx, ny)
+    uo, vo, it = orc.robust_expo(I1, I2, nscales=ns, **kw)
+    ug, vg = gpu64.robust_expo(I1, I2, nscales=ns, **kw)
+    got = gpu64.stats().iterations()[:ns, :it.shape[1]]
+    assert np.array_equal(got, it)
+    assert np.abs(ug - uo).max() < 1e-11 and np.abs(vg - vo).max() < 1e-11
+
+
+def test_robust_expo_golden_and_errors(gpu64, ofx_mod, synth):
+    import json, os
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cases = json.load(open(os.path.join(root, "cases.json")))
+    for name in sorted(c for c in cases if cases[c]["kind"] == "rexpo"):
+        c, g = cases[name], np.load(os.path.join(root, name + ".npz"))
+        I1, I2 = synth.pair(c["pair"], c["nx"], c["ny"])
+        u, v = gpu64.robust_expo(I1, I2, **c["params"])
+        ns = c["params"]["nscales"]
+        assert list(gpu64.stats().iterations()[:ns, :len(g["iters"]) // ns][::-1].ravel()) == list(g["iters"]), name
+        assert np.abs(u - g["u"]).max() < 1e-11 and np.abs(v - g["v"]).max() < 1e-11, name
+    z = np.zeros((32, 32))
+    for bad in (dict(nz=3), dict(method=0), dict(method=4), dict(inner=-1)):
+        with pytest.raises(ofx_mod.OfxError):
+            gpu64.robust_expo(z, z, **bad)

@@ -64,7 +64,7 @@ def test_solvers(orc, synth, case):
         out = orc.brox_temporal(synth.sequence(c["nx"], c["ny"], c["pair"]), **c["params"])
     else:
         I0, I1 = synth.pair(c["pair"], c["nx"], c["ny"])
-        fn = {"tvl1": orc.tvl1_multiscale, "hs": orc.hs_pyramidal, "brox": orc.brox_spatial}[c["kind"]]
+        fn = {"tvl1": orc.tvl1_multiscale, "hs": orc.hs_pyramidal, "brox": orc.brox_spatial, "rexpo": orc.robust_expo}[c["kind"]]
         out = fn(I0, I1, **c["params"])
     u, v, iters = out[0], out[1], out[2]
     assert np.array_equal(u, g["u"]) and np.array_equal(v, g["v"])

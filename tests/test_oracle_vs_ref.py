@@ -216,3 +216,24 @@ def test_tvl1occ_multiscale(orc, ref):
         ur2, vr2, cr2 = ref.tvl1occ_multiscale(seq[2], seq[1], seq[0], **kw)
         uo2, vo2, co2, _ = orc.tvl1occ_multiscale(seq[2], seq[1], seq[0], **kw)
         assert np.array_equal(ur2, uo2) and np.array_equal(cr2, co2)
+
+
+def test_robust_expo(orc, ref, synth):
+    """robust_expo_methods restated for one channel == the compiled reference, bit for bit: the Gaussian with
+    the Dirichlet boundary its driver really asks for (gaussian(I, nx, ny, nzz, GAUSSIAN_SIGMA): sigma = channels, bc = (int) 0.8),
+    the three decreasing functions, and the whole multiscale solve for every method type"""
+    rng = np.random.default_rng(3)
+    img = rng.random((20, 31)) * 255
+    for a in (img, img[:3, :4], img[:1, :9]):
+        assert np.array_equal(orc.gaussian_dirichlet(a, 1.0), ref.gaussian_bc(a, 1.0, 0))
+    Ix, Iy = orc.centered_gradient(img)
+    for m in (1, 2, 3):
+        assert np.array_equal(orc.rexpo_exponential(Ix, Iy, 50.0, 0.2, m), ref.rexpo_exponential(Ix, Iy, 50.0, 0.2, m))
+    for pair, nx, ny, ns, kw in (("P1", 64, 48, 2, dict(method=1, alpha=50.0, gamma=10.0, lam=0.1, outer=4)),
+                                 ("P0", 96, 64, 3, dict(method=2, alpha=18.7, gamma=5.0, lam=0.05, outer=3, inner=2)),
+                                 ("P1", 80, 60, 2, dict(method=3, alpha=30.0, gamma=10.0, lam=1.0, outer=3)),
+                                 ("P1", 33, 21, 1, dict(method=1, alpha=7.9, gamma=0.0, lam=0.3, outer=5))):
+        I1, I2 = synth.pair(pair, nx, ny)
+        uo, vo, _ = orc.robust_expo(I1, I2, nscales=ns, **kw)
+        ur, vr = ref.robust_expo(I1, I2, nscales=ns, **kw)
+        assert np.array_equal(uo, ur) and np.array_equal(vo, vr), (pair, nx, ny, kw)
