@@ -202,3 +202,39 @@ def test_tvl1occ_random_lockstep_groups(ofx_mod, gpu64, orc, synth, seed):
     for t, (u, v, c) in zip(triples, got):
         uo, vo, co, _ = orc.tvl1occ_multiscale(t[0], t[1], t[2], filtI0=t[3] if len(t) > 3 else None, **kw)
         assert np.array_equal(u, uo) and np.array_equal(v, vo) and np.array_equal(c, co), (nx, ny, kw)
+
+
+# ---- round 3: the f64 tolerance mode and robust_expo_methods on random configurations -------------------------------------
+@pytest.mark.parametrize("c", cases(FUZZ_SEED + 5, max(6, FUZZ_N // 3)), ids=lambda c: "%dx%d-%s-ns%d-w%d-z%g-e%g" % (
+    c["nx"], c["ny"], c["pair"], c["kw"]["nscales"], c["kw"]["warps"], c["kw"]["zfactor"], c["kw"]["epsilon"]))
+def test_tolerance_mode_random_configurations(gpu64, orc, synth, c):
+    """option relaxed_dual = 1 on random sizes / parameters: north_star's bar (AEPE < 1e-4 px) against the oracle, iteration
+    counts within a few per loop (they are equal on every BASELINE config; tiny images sit closer to the threshold)"""
+    I0, I1 = synth.pair(c["pair"], c["nx"], c["ny"], c["k"])
+    uo, vo, it_o, _ = orc.tvl1_multiscale(I0, I1, **c["kw"])
+    gpu64.set_option("relaxed_dual", 1)
+    try:
+        ug, vg = gpu64.tvl1_multiscale(I0, I1, **c["kw"])
+        it_g = gpu64.stats().iterations().copy()
+    finally:
+        gpu64.set_option("relaxed_dual", 0)
+    assert float(np.mean(np.hypot(ug - uo, vg - vo))) < 1e-4
+    assert np.abs(it_g - np.asarray(it_o)).max() <= 4
+
+
+FUZZ_REXPO = int(os.environ.get("OFX_FUZZ_REXPO", "6"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_REXPO))
+def test_robust_expo_random_configurations(gpu64, orc, synth, seed):
+    rng = np.random.default_rng(FUZZ_SEED + 900 + seed)
+    nx, ny = int(rng.integers(20, 150)), int(rng.integers(20, 110))
+    ns = int(rng.integers(1, 3)) if min(nx, ny) >= 40 else 1
+    kw = dict(method=int(rng.integers(1, 4)), alpha=float(rng.choice([7.9, 18.7, 50.0, 33.3])), gamma=float(rng.choice([0.0, 5.0, 10.0])),
+              lam=float(rng.choice([0.05, 0.1, 1.0])), nscales=ns, nu=float(rng.choice([0.5, 0.75])), TOL=float(rng.choice([1e-4, 1e-3])),
+              inner=int(rng.integers(1, 3)), outer=int(rng.integers(1, 5)))
+    I1, I2 = synth.pair(str(rng.choice(["P0", "P1"])), nx, ny, int(rng.integers(0, 4)))
+    uo, vo, it = orc.robust_expo(I1, I2, **kw)
+    ug, vg = gpu64.robust_expo(I1, I2, **kw)
+    assert np.array_equal(gpu64.stats().iterations()[:ns, :it.shape[1]], it), kw
+    assert np.abs(ug - uo).max() < 1e-11 and np.abs(vg - vo).max() < 1e-11, kw
