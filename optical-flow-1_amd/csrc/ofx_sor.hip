@@ -341,6 +341,15 @@ OFX_DEV int sor_border_block(int i, int ny, int R)
     return r / R;
 }
 
+// Local steps at which row block b has any pixel to update (rows b R .. min(b R + R, ny) - 1 and the border pixels assigned to
+// it, sor_border_block): [c b R, c r_last + nx + 5] for the stencil skew c (2 Horn-Schunck, 1 Brox) -- half of the (sweep, block)
+// units of a launch lie outside it and leave at once (tools/check_sor_schedule.py unit_range, tests/test_host_logic.py).
+OFX_DEV bool sor_unit_idle(const SorWin &w, int b, int q_first, int K, int c, int nx, int ny)
+{
+    const int rf = b * w.R, rl = (rf + w.R < ny ? rf + w.R : ny) - 1;
+    return q_first > c * rl + nx + 5 || q_first + K - 1 < c * rf;
+}
+
 // SPW consecutive sweeps of one row block share a workgroup: their updates are independent (lag_s steps apart), so their
 // loads are issued together and ONE store drain + barrier per step serves all of them -- the per-step latency, not
 // arithmetic or bandwidth, is what bounds a lockstep group (profiles/r02_f_sor_counters.txt).
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(MAXT) void k_hs_window(typename Pix<T>::v2 *Ug, typ
 #pragma unroll
     for (int u = 0; u < SPW; u++) {
         q_first[u] = w.tau0 - w.lag_s * (s0 + u) - w.lag_b * b;
-        live[u] = (s0 + u < w.s_first + s_cnt) && !(q_first[u] > qmax || q_first[u] + w.K - 1 < 0);
+        live[u] = (s0 + u < w.s_first + s_cnt) && !sor_unit_idle(w, b, q_first[u], w.K, 2, nx, ny);
         any = any || live[u];
     }
     if (!any) return;                                            // none of these (sweep, block) units has a step in the window
@@ -461,7 +470,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(1, 2))) vo
     if (!((grp.runmask >> g) & 1u)) return;                      // this pair's solve has already stopped
     const int qmax = 2 * ny + nx - 2;
     const int q0 = w.tau0 - w.lag_s * s - w.lag_b * b;
-    if (q0 > qmax || q0 + KW - 1 < 0) return;                    // no step of this (sweep, block) in the window: uniform
+    if (sor_unit_idle(w, b, q0, KW, 2, nx, ny)) return;          // no step of this (sweep, block) in the window: uniform
     typename Pix<T>::v2 *U = Ug + g * grp.npix;
     const typename Pix<T>::v2 *__restrict__ A = Ag + g * grp.npix;
     const T *__restrict__ Dif = Difg + g * grp.npix;
@@ -719,7 +728,8 @@ static int sor_pick_spw(const ofx_ctx *ctx, int G)
 // per launch instead of one per step counts -- and the global kernels for lockstep groups of 4 pairs and more, which are
 // bound by resident waves (28 per CU at 64 VGPRs and no LDS against a few LDS-limited workgroups).
 // Measured (profiles/r03_e_sor_window_kernels_lds_vs_global.txt, 16 P1 pairs of cfg 3 / cfg 4): Horn-Schunck lone solves
-// 572 -> 537 ms with 8 steps per launch (16: 617), lockstep groups of 16 81 -> 147 ms per pair; Brox lone solves 255 -> 297 ms.
+// 572 -> 537 ms with 8 steps per launch (16: 617), lockstep groups of 16 81 -> 147 ms per pair (116 since idle units leave at
+// once, profiles/r03_n_hs_window_kernels_counters.txt: 800 resident waves against 2400); Brox lone solves 255 -> 297 ms.
 // A step is bound by the ~200 dependent instructions of a lone wave, not by the round trip the window removes.
 static bool sor_use_lds(const ofx_ctx *ctx, int G, bool brox = false)
 {
@@ -1530,7 +1540,7 @@ __global__ __launch_bounds__(MAXT) void k_brox_window(typename Pix<T>::v2 *DUg, 
 #pragma unroll
     for (int u = 0; u < SPW; u++) {
         q_first[u] = w.tau0 - w.lag_s * (s0 + u) - w.lag_b * b;
-        live[u] = (s0 + u < w.s_first + s_cnt) && !(q_first[u] > qmax || q_first[u] + w.K - 1 < 0);
+        live[u] = (s0 + u < w.s_first + s_cnt) && !sor_unit_idle(w, b, q_first[u], w.K, 1, nx, ny);
         any = any || live[u];
     }
     if (!any) return;
@@ -1632,7 +1642,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(1, 2))) vo
     if (!((grp.runmask >> g) & 1u)) return;
     const int qmax = ny + nx - 2;
     const int q0 = w.tau0 - w.lag_s * s - w.lag_b * b;
-    if (q0 > qmax || q0 + KW - 1 < 0) return;
+    if (sor_unit_idle(w, b, q0, KW, 1, nx, ny)) return;
     typename Pix<T>::v2 *DU = DUg + g * grp.npix;
     const typename Pix<T>::v4 *__restrict__ CO = COg + g * grp.npix;
     const T *__restrict__ Dm = Dmg + g * grp.npix;
@@ -2335,7 +2345,7 @@ __global__ __launch_bounds__(1024) void k_broxt_window(typename Pix<T>::v2 *DU, 
     const int f = (o < nz - 2) ? o + 1 : (o == nz - 2 ? 0 : nz - 1);
     const int qmax = ny + nx - 2;
     const int q_first = w.tau0 - w.lag_s * s - w.lag_f * o - w.lag_b * b;
-    if (q_first > qmax || q_first + w.K - 1 < 0) return;
+    if (sor_unit_idle(w, b, q_first, w.K, 1, nx, ny)) return;
     typename Pix<T>::v2 *mysnap = snap + (size_t) s * nz * nx * ny;
     const int r = sor_window_item(w, b, threadIdx.x, ny);
     double e = 0.0;

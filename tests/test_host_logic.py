@@ -177,6 +177,12 @@ def test_lds_windows_of_the_sor_kernels_cover_every_access():
     for solver in ("hs", "brox"):                          # the schedule itself with the larger windows
         for nx, ny, K, B in [(23, 30, 16, 3), (16, 9, 24, 2), (9, 12, 16, 1)]:
             assert mod.check(nx, ny, K, B, solver, 2) == 0
+    # sor_unit_idle: a (sweep, row block) unit leaves a launch at once when the launch's steps lie outside the steps at which
+    # the block has pixels -- no pixel's step may lie outside the range assumed for the block that executes it
+    for solver in ("hs", "brox"):
+        for nx, ny in [(23, 52), (40, 31), (17, 9), (9, 33), (5, 5), (3, 3), (2, 7), (7, 2), (4, 3), (100, 20)]:
+            for R in (2, 3, 5, 7, 16, 64):
+                assert mod.unit_range_violations(nx, ny, R, solver) == 0, (solver, nx, ny, R)
 
 
 def test_flo_reader_on_the_reference_own_flow_file(io):

@@ -25,9 +25,14 @@ for a in sys.argv[1:]:
         GRID = [tuple(int(x) for x in g.split("x")) for g in a.split("=")[1].split(",")]
 nowarm = "--no-warm" in sys.argv
 OPTS = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--opt=")]      # --opt=name=value for every context
+KW = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--kw=")]         # --kw=name=value overrides a solver parameter
 for name, (nx, ny), bpp, kw in CONFIGS:
     if only and name not in only:
         continue
+    for o in KW:
+        k_, v_ = o.split("=")
+        if k_ in kw:
+            kw[k_] = type(kw[k_])(float(v_))
     nmax = max(c * g for c, g in GRID)
     ins = [synth.pair_device("P0" if k == 0 else "P1", nx, ny, k, dev) for k in range(nmax)]
     flo = torch.empty((nmax, ny, nx, 2), dtype=torch.float32, device=dev)
@@ -48,7 +53,7 @@ for name, (nx, ny), bpp, kw in CONFIGS:
         dt = time.perf_counter() - t0
         mps = sum(work) / dt / 1e6
         print(json.dumps({"config": name, "size": "%dx%d" % (nx, ny), "contexts": nctx, "group": G, "pairs": n,
-                          "seconds": round(dt, 4), "ms_per_pair": round(dt / n * 1e3, 2), "mpix_sweeps_per_s": round(mps, 1),
+                          "seconds": round(dt, 4), "mpix_sweeps": round(sum(work) / 1e6, 1), "ms_per_pair": round(dt / n * 1e3, 2), "mpix_sweeps_per_s": round(mps, 1),
                           "algorithmic_gbs": round(mps * bpp / 1e3, 1), "frac_of_hbm_peak": round(mps * bpp / 8e6, 4)}), flush=True)
         if check and (nctx, G) == GRID[-1]:
             solo = ofx.Ofx(0, ofx.F64)

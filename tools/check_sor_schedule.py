@@ -82,11 +82,9 @@ def check(nx, ny, K, B, solver, m, verbose=False):
                     if verbose and bad<4: print("viol",solver,nx,ny,K,B,m,(i,j),(ii,jj),tx,ty,before)
     return bad
 
-def cover(nx, ny, K, R, solver):
-    """What the K steps of one launch of a (sweep, row block) workgroup touch, relative to the launch's first local step q0
-    and the block's first row b R: (hmin, hmax) = range of (skewed hyperplane c i + j) - q0 over all unknowns read or
-    written, (rmin, rmax) = range of row - b R, (cmin, cmax) = hyperplane range of the updated pixels themselves (their
-    coefficients).  k_hs_window_lds / k_brox_window_lds stage exactly these windows in LDS (HsWinLds / BroxWinLds)."""
+def _rules(nx, ny, R, solver):
+    """(skew c, pos(i, j), blk(i, j), stencil) as the window kernels have them (hs_plane_item / brox_plane_item,
+    sor_window_item, sor_border_block)."""
     if solver == "hs":
         cs = 2
         def pos(i, j):
@@ -120,6 +118,34 @@ def cover(nx, ny, K, R, solver):
         elif j == 0 or j == nx - 1: r = min(i + 1, ny - 1)
         else: r = i
         return r // R
+    return cs, pos, blk, nbrs
+
+
+def unit_range(nx, ny, R, b, solver):
+    """sor_unit_idle of ofx_sor.hip: the local steps [lo, hi] outside which row block b has no pixel to update."""
+    cs = 2 if solver == "hs" else 1
+    rf = b * R
+    rl = min(rf + R, ny) - 1
+    return cs * rf, cs * rl + nx + 5
+
+
+def unit_range_violations(nx, ny, R, solver):
+    """pixels whose step lies outside the range sor_unit_idle assumes for the block that executes them (must be 0)"""
+    cs, pos, blk, _ = _rules(nx, ny, R, solver)
+    bad = 0
+    for i in range(ny):
+        for j in range(nx):
+            lo, hi = unit_range(nx, ny, R, blk(i, j), solver)
+            bad += not (lo <= pos(i, j) <= hi)
+    return bad
+
+
+def cover(nx, ny, K, R, solver):
+    """What the K steps of one launch of a (sweep, row block) workgroup touch, relative to the launch's first local step q0
+    and the block's first row b R: (hmin, hmax) = range of (skewed hyperplane c i + j) - q0 over all unknowns read or
+    written, (rmin, rmax) = range of row - b R, (cmin, cmax) = hyperplane range of the updated pixels themselves (their
+    coefficients).  k_hs_window_lds / k_brox_window_lds stage exactly these windows in LDS (HsWinLds / BroxWinLds)."""
+    cs, pos, blk, nbrs = _rules(nx, ny, R, solver)
     big = 10 ** 9
     hmin = rmin = cmin = big
     hmax = rmax = cmax = -big
