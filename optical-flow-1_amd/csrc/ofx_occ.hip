@@ -503,6 +503,16 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
 #define ROF_THREADS (ROF_NT + 64)     // + one wave whose first two threads walk the image's first and last row
 #define ROF_K 24
 #define ROF_LAG (ROF_K + 8)
+// Iterations in flight.  One iteration of the solver is alfa -> sweep -> u, and alfa of the next iteration needs u.  But
+// u = lambda f + lambda div P at a cell only needs the dual values around that cell, which are final as soon as the sweep's
+// wavefront is four positions past it: the sweep of iteration s therefore follows ROF_LAGI positions behind the sweep of
+// iteration s - 1, and between the two wavefronts -- ROF_D positions ahead of sweep s -- an "alfa stage" (workgroups of the
+// same launches) computes alfa_s straight from the pairs sweep s - 1 has left behind (u_{s-1} at the cell, its east and
+// its south neighbour, never stored).  A call of n iterations is then one chain of qmax + ROF_LAGI (n - 1) steps instead of
+// n chains of qmax steps.  The conditions (every value an alfa stage or a sweep takes from another workgroup was stored by an
+// earlier launch and is overwritten by a later one) are enumerated by tools/check_rof_pipeline.py: D in [58, 60], LAGI >= 118.
+#define ROF_D (ROF_K + ROF_LAG + 2)
+#define ROF_LAGI 120
 #define ROF_RING (ROF_K + 7)         // positions q0 - 4 .. q1 + 2
 #define ROF_COEF (ROF_K + 3)         // positions q0 - 2 .. q1 + 1
 #define ROF_LDS_BYTES ((size_t) ROF_NT * (ROF_RING * sizeof(double2) + ROF_COEF * (sizeof(double2) + sizeof(double))))
@@ -674,26 +684,64 @@ OFX_DEV void rof_cell(const RofRing &r, int ci, int cj, double w, RofPre &pre, b
 // (independent) problems
 struct RofSet {
     RofArr a[2];
+    const double *LF[2];             // lambda f per cell and problem, hyperplane-major (alfa stage)
+    const double *LG;                // lambda g per cell, hyperplane-major (shared by the problems of a set)
+    double *ALw[2];                  // a[k].AL, writable (alfa stage)
     size_t stride;                   // lockstep groups: problem set g = blockIdx.z works on arrays offset by g * stride
     unsigned mask;                   // bit g: still iterating
+    int nc, B;                       // problems per set, row blocks: blockIdx.y = problem + nc * iteration, blockIdx.x = block (+ B: alfa stage)
 };
-__global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, double w)
+// u = lambda f + lambda (P_south - P_north + P_east - P_west) of one cell from the hyperplane-major pairs (k_rof_u's expression)
+OFX_DEV double rof_u_cell(const double2 *__restrict__ PP, const double *__restrict__ LF, int ci, int cj, int ny, double lambda)
+{
+    const size_t k = rof_sk(ci, cj, ny);
+    const double2 own = PP[k];
+    const double pn = ci > 0 ? PP[rof_sk(ci - 1, cj, ny)].x : 0.0, pw = cj > 0 ? PP[rof_sk(ci, cj - 1, ny)].y : 0.0;
+    return LF[k] + lambda * (own.x - pn + own.y - pw);
+}
+// alfa stage of one row block: alfa of the cells of its rows at positions [p0, p0 + ROF_K) (k_rof_alfa's expression on
+// u recomputed from the pairs).  Thread = row; no dependence between cells.
+OFX_DEV void rof_alfa_band(const RofArr &a, const double *__restrict__ LF, const double *__restrict__ LG, double *__restrict__ AL,
+                           int b, int p0, double lambda)
+{
+    const int t = (int) threadIdx.x, nx = a.nx, ny = a.ny;
+    const int ci = b * ROF_R + t;
+    if (t >= ROF_R || ci >= ny) return;
+#pragma unroll 4
+    for (int p = p0; p < p0 + ROF_K; p++) {
+        const int cj = p - 2 * ci;
+        if (cj < 0 || cj >= nx) continue;
+        const double u0 = rof_u_cell(a.PP, LF, ci, cj, ny, lambda);
+        const double ux = (cj < nx - 1) ? rof_u_cell(a.PP, LF, ci, cj + 1, ny, lambda) - u0 : 0.0;
+        const double uy = (ci < ny - 1) ? rof_u_cell(a.PP, LF, ci + 1, cj, ny, lambda) - u0 : 0.0;
+        const size_t k = rof_sk(ci, cj, ny);
+        AL[k] = sqrt(ux * ux + uy * uy) / LG[k];
+    }
+}
+__global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, double w, double lambda)
 {
     extern __shared__ double2 rof_lds[];
     double2 (*win)[ROF_NT] = reinterpret_cast<double2 (*)[ROF_NT]>(rof_lds);
     double2 (*cff)[ROF_NT] = reinterpret_cast<double2 (*)[ROF_NT]>(rof_lds + ROF_RING * ROF_NT);
     double (*cal)[ROF_NT] = reinterpret_cast<double (*)[ROF_NT]>(rof_lds + (ROF_RING + ROF_COEF) * ROF_NT);
     if (!((s.mask >> blockIdx.z) & 1u)) return;
-    RofArr a = blockIdx.y ? s.a[1] : s.a[0];                                // by value: a dynamic index would be re-read from the kernel arguments at every use
-    {
-        const size_t off = (size_t) blockIdx.z * s.stride;
-        a.PP += off; a.FF += off; a.AL += off;
-    }
+    const int it = (int) blockIdx.y / s.nc, prob = (int) blockIdx.y - it * s.nc;    // iteration in flight, problem of the set
+    const bool alfa_stage = (int) blockIdx.x >= s.B;
+    const int b = (int) blockIdx.x - (alfa_stage ? s.B : 0);
+    RofArr a = prob ? s.a[1] : s.a[0];                                      // by value: a dynamic index would be re-read from the kernel arguments at every use
+    const size_t off = (size_t) blockIdx.z * s.stride;
+    a.PP += off; a.FF += off; a.AL += off;
     const int nx = a.nx, ny = a.ny;
-    const int t = (int) threadIdx.x, row0 = (int) blockIdx.x * ROF_R - 2;
-    const int qmax = 2 * (ny - 1) + nx - 1;
-    const int q0 = T0 - ROF_LAG * (int) blockIdx.x, q1 = q0 + ROF_K - 1;
-    if (q0 > qmax || q1 < 0) return;                                        // uniform over the workgroup
+    const int t = (int) threadIdx.x, row0 = b * ROF_R - 2;
+    const int q0 = T0 - ROF_LAG * b - ROF_LAGI * it, q1 = q0 + ROF_K - 1;
+    // positions at which the block's own rows have cells: outside them the unit has nothing to do (uniform over the workgroup)
+    const int p_lo = 2 * b * ROF_R, p_hi = 2 * (min(b * ROF_R + ROF_R, ny) - 1) + nx - 1;
+    if (alfa_stage) {
+        if (it == 0 || q0 + ROF_D > p_hi || q1 + ROF_D < p_lo) return;      // alfa of iteration 0 comes from the seed (k_rof_alfa)
+        rof_alfa_band(a, (prob ? s.LF[1] : s.LF[0]) + off, s.LG + off, (prob ? s.ALw[1] : s.ALw[0]) + off, b, q0 + ROF_D, lambda);
+        return;
+    }
+    if (q0 > p_hi || q1 < p_lo) return;
     // Who walks which row.  Threads 0 .. 127 = LDS columns = rows row0 .. row0 + 127 (125 own rows between two halo rows above
     // and one below).  The image's first and last row consist of cells of another kind (3 x 3 systems) than the inner rows:
     // left in their column's wave they would make that wave -- and with it the whole launch, which waits for its slowest
@@ -785,13 +833,18 @@ __global__ void k_rof_skew(double *__restrict__ ps, double *__restrict__ pe, dou
     }
 }
 // edge differences of f (once per call), :137-164
-__global__ void k_rof_fdiff(const double *__restrict__ f, double2 *__restrict__ FF, int nx, int ny, OccGrp Grm, size_t sk_stride)
+// ... and the two products the alfa stage needs per cell, in the sweep's layout: lambda f (the first term of u) and lambda g
+// (the divisor of alfa); LG may be null (second problem of a set: same g)
+__global__ void k_rof_fdiff(const double *__restrict__ f, double2 *__restrict__ FF, int nx, int ny, OccGrp Grm, size_t sk_stride,
+                            const double *__restrict__ g, double *__restrict__ LF, double *__restrict__ LG, double lambda)
 {
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
     size_t o;
     if (j >= nx || i >= ny || !occ_grp(Grm, o)) return;
     const size_t c = o + (size_t) i * nx + j, k = blockIdx.z * sk_stride + rof_sk(i, j, ny);
     FF[k] = make_double2((i < ny - 1) ? f[c + nx] - f[c] : 0.0, (j < nx - 1) ? f[c + 1] - f[c] : 0.0);
+    LF[k] = lambda * f[c];
+    if (LG) LG[k] = lambda * g[c];
 }
 // alfa = hypot(forward gradient of u) / (lambda g) with the file-local hypot = sqrt(x x + y y), :15-20,173-187
 struct RofPt {
@@ -826,8 +879,11 @@ __global__ void k_rof_u(RofPt a, int nx, int ny, double lambda)
 // nc = 1 | 2 independent problems sharing g, lambda and the size (the two flow components of Solver_wrt_u), every launch
 // serving both -- and all G sets of them (lockstep groups: set s on planes offset by s * nx * ny / s * rof_skew_elems(),
 // sets whose bit of `mask` is clear are left alone).  Device arrays in place: u[k] (in: seed, out: result; row-major),
-// PP[k] = (Ps, Pe) pairs (in/out state, HYPERPLANE-MAJOR, rof_skew_elems() pairs per set); scratch = 3 nc G hyperplane-major
-// planes of doubles (the (Fs, Fe) pairs of every problem first, then the alfa planes).
+// PP[k] = (Ps, Pe) pairs (in/out state, HYPERPLANE-MAJOR, rof_skew_elems() pairs per set); scratch = ROF_SCRATCH_PLANES(nc) G
+// hyperplane-major planes of doubles (the (Fs, Fe) pairs of every problem first, then alfa, lambda f, and one plane lambda g).
+// All n_iter iterations are in flight together (see ROF_LAGI): the seed's alfa, one chain of windows, the final u.
+// Option "rof_pipe" = 0: one iteration at a time (alfa pass, windows, u pass per iteration), the round-2 schedule.
+#define ROF_SCRATCH_PLANES(nc) (4 * (nc) + 1)
 static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *const *f, double2 *const *PP, const double *g,
                        double lambda, double omega, int nx, int ny, int n_iter, double *scratch, int G = 1, unsigned mask = 1u)
 {
@@ -835,31 +891,52 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
     const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), nc * G), block(64, 4);
     RofSet set;
     RofPt pt;
+    double *LG = scratch + (size_t) (4 * nc) * n * G;
     for (int k = 0; k < 2; k++) {
         const int c = k < nc ? k : 0;
         double2 *FF = reinterpret_cast<double2 *>(scratch + (2 * c) * n * G);        // pairs first: 16-byte aligned whatever n
-        double *AL = scratch + (2 * nc + c) * n * G;
+        double *AL = scratch + (2 * nc + c) * n * G, *LF = scratch + (3 * nc + c) * n * G;
         if (k < nc) {
-            hipLaunchKernelGGL(k_rof_fdiff, dim3(grid.x, grid.y, G), block, 0, ctx->stream, f[c], FF, nx, ny, OccGrp{nrm, mask}, n);
+            hipLaunchKernelGGL(k_rof_fdiff, dim3(grid.x, grid.y, G), block, 0, ctx->stream, f[c], FF, nx, ny, OccGrp{nrm, mask}, n, g, LF,
+                               k == 0 ? LG : (double *) nullptr, lambda);
             OFX_LAUNCH_CHECK(ctx);
         }
         set.a[k] = RofArr{PP[c], FF, AL, nx, ny};
+        set.LF[k] = LF; set.ALw[k] = AL;
         pt.u[k] = u[c]; pt.f[k] = f[c]; pt.PP[k] = PP[c]; pt.AL[k] = AL; pt.uo[k] = u[c];
     }
-    set.stride = n; set.mask = mask;
-    pt.nc = nc; pt.rm_stride = nrm; pt.sk_stride = n; pt.mask = mask;
     const int B = ofx_cdiv(ny, ROF_R), qmax = 2 * (ny - 1) + nx - 1;
-    const long total = (long) qmax + 1 + (long) ROF_LAG * (B - 1);
+    set.LG = LG; set.stride = n; set.mask = mask; set.nc = nc; set.B = B;
+    pt.nc = nc; pt.rm_stride = nrm; pt.sk_stride = n; pt.mask = mask;
     static std::atomic<unsigned> lds_set(0);           // bit d: the attribute has been set on device d (per device, any thread)
     if (!(lds_set.load() & (1u << (ctx->device & 31)))) {
         OFX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_rof_window), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int) ROF_LDS_BYTES));
         lds_set.fetch_or(1u << (ctx->device & 31));
     }
+    if (n_iter < 1) return OFX_OK;
+    if (ctx->rof_pipe) {
+        const long total = (long) qmax + 1 + (long) ROF_LAG * (B - 1) + (long) ROF_LAGI * (n_iter - 1);
+        hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
+        for (long T0 = 0; T0 < total; T0 += ROF_K) {
+            // iterations with a window in this launch: T0 - LAGI it within [-K - D, qmax + LAG (B - 1)]
+            long it_lo = (T0 - qmax - (long) ROF_LAG * (B - 1) + ROF_LAGI - 1) / ROF_LAGI;
+            if (T0 - qmax - (long) ROF_LAG * (B - 1) < 0) it_lo = 0;
+            long it_hi = (T0 + ROF_K + ROF_D) / ROF_LAGI;
+            if (it_hi > n_iter - 1) it_hi = n_iter - 1;
+            (void) it_lo;                                  // the grid covers iterations 0 .. it_hi; units outside their range leave at once
+            hipLaunchKernelGGL(k_rof_window, dim3(2 * B, nc * (int) (it_hi + 1), G), dim3(ROF_THREADS), ROF_LDS_BYTES, ctx->stream, set,
+                               (int) T0, omega, lambda);
+        }
+        hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, pt, nx, ny, lambda);
+        OFX_LAUNCH_CHECK(ctx);
+        return OFX_OK;
+    }
+    const long total = (long) qmax + 1 + (long) ROF_LAG * (B - 1);
     for (int it = 0; it < n_iter; it++) {
         hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
         for (long T0 = 0; T0 < total; T0 += ROF_K)
-            hipLaunchKernelGGL(k_rof_window, dim3(B, nc, G), dim3(ROF_THREADS), ROF_LDS_BYTES, ctx->stream, set, (int) T0, omega);
+            hipLaunchKernelGGL(k_rof_window, dim3(B, nc, G), dim3(ROF_THREADS), ROF_LDS_BYTES, ctx->stream, set, (int) T0, omega, lambda);
         hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, pt, nx, ny, lambda);
         OFX_LAUNCH_CHECK(ctx);
     }
@@ -904,7 +981,7 @@ extern "C" int ofx_scalar_rof_box_cell_centered(ofx_ctx *ctx, double *u, const d
     OFX_TRY(d.in(g_function, &dg, n));
     OFX_TRY(ofx_alloc(ctx, 2 * n, &tmp));
     OFX_TRY(rof_state_in(ctx, initialP1, initialP2, &dpp, tmp, nx, ny));
-    OFX_TRY(ofx_alloc(ctx, 3 * rof_skew_elems(nx, ny), &scratch));
+    OFX_TRY(ofx_alloc(ctx, ROF_SCRATCH_PLANES(1) * rof_skew_elems(nx, ny), &scratch));
     const double *fs[1] = {df};
     OFX_TRY(rof_box_dev(ctx, 1, &du, fs, &dpp, dg, lambda, omega, nx, ny, nIter, scratch));
     OFX_TRY(d.out(du, u, n));
@@ -955,7 +1032,7 @@ extern "C" int ofx_solver_wrt_u(ofx_ctx *ctx, double *u1, double *u2, const doub
     hipLaunchKernelGGL(k_occ_u_init, dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4)), dim3(64, 4), 0, ctx->stream, (const double *) dv1,
                        (const double *) dv2, (const double *) dchi, f1, f2, du1, du2, nx, ny, theta, beta, OCC_ONE);
     OFX_LAUNCH_CHECK(ctx);
-    OFX_TRY(ofx_alloc(ctx, 6 * rof_skew_elems(nx, ny), &scratch));
+    OFX_TRY(ofx_alloc(ctx, ROF_SCRATCH_PLANES(2) * rof_skew_elems(nx, ny), &scratch));
     double *us[2] = {du1, du2};
     const double *fs[2] = {f1, f2};
     OFX_TRY(rof_box_dev(ctx, 2, us, fs, dpp, dg, theta, OCC_OMEGA, nx, ny, n_iter, scratch));
@@ -1145,7 +1222,7 @@ struct OccWork {
         for (auto p : planes) OFX_TRY(ofx_alloc(ctx, n * G, p));
         OFX_TRY(ofx_alloc(ctx, 4 * nskew * G, &state));      // dual planes of Solver_wrt_u, hyperplane-major
         OFX_TRY(ofx_alloc(ctx, 2 * n * G, &eta));            // dual variable of Solver_wrt_chi
-        OFX_TRY(ofx_alloc(ctx, 6 * nskew * G, &rof));
+        OFX_TRY(ofx_alloc(ctx, ROF_SCRATCH_PLANES(2) * nskew * G, &rof));
         return ofx_alloc(ctx, (size_t) (OCC_ERR_BLOCKS + 1) * G, &part);
     }
 };
@@ -1365,7 +1442,7 @@ extern "C" int ofx_tvl1occ_batch(ofx_ctx *const *ctxs, int n_ctx, int n_triples,
         OFX_TRY(occ_check_args(ctx, nxx, nyy, lambda, theta, nscales, zfactor, warps));
     }
     // group size: option "lockstep" of ctxs[0], else as many as fit.  Per triple: 7 planes per pyramid level (occ_group: 4 images,
-    // u1, u2, chi) + OccWork's 28 full-size row-major and 10 hyperplane-major planes + 2 of Gaussian / zoom scratch
+    // u1, u2, chi) + OccWork's 28 full-size row-major and 13 hyperplane-major planes + 2 of Gaussian / zoom scratch
     int G = ctxs[0]->lockstep > 0 ? ctxs[0]->lockstep : OCC_MAX_GROUP;
     if (G > OCC_MAX_GROUP) G = OCC_MAX_GROUP;
     {
@@ -1376,7 +1453,7 @@ extern "C" int ofx_tvl1occ_batch(ofx_ctx *const *ctxs, int n_ctx, int n_triples,
         OFX_TRY(op_pyramid_sizes(ctxs[0], nxx, nyy, nscales, zfactor, nxs, nys));
         double level_px = 0.0;
         for (int s = 0; s < nscales; s++) level_px += (double) nxs[s] * nys[s];
-        const double per = 8.0 * (7.0 * level_px + 30.0 * nxx * nyy + 10.0 * (double) rof_skew_elems(nxx, nyy)) * 1.05;
+        const double per = 8.0 * (7.0 * level_px + 30.0 * nxx * nyy + 13.0 * (double) rof_skew_elems(nxx, nyy)) * 1.05;
         const int fit = (int) (budget / per);
         if (fit < 1) return ofx_fail(ctxs[0], OFX_ERR_NOMEM, "tvl1occ batch: %.1f GB per triple, %.1f GB per context available", per / 1e9, budget / 1e9);
         if (G > fit) G = fit;

@@ -9,6 +9,18 @@ from test_oracle_vs_ref import _occ_inputs
 pytestmark = pytest.mark.gpu
 
 
+# The ROF box sweeps run with all iterations of a call in flight (option rof_pipe = 1, default: sweeps ROF_LAGI positions apart,
+# alfa of the next iteration computed between the wavefronts) or one iteration at a time (0): every test that reaches them runs
+# with both.
+@pytest.fixture(autouse=True, params=[1, 0], ids=["pipelined", "serial"])
+def rof_schedule(request, gpu64):
+    if request.param == 0 and not request.node.name.startswith(("test_rof", "test_tvl1occ_multiscale", "test_tvl1occ_lockstep")):
+        pytest.skip("does not reach the ROF sweeps: once is enough")
+    gpu64.set_option("rof_pipe", request.param)
+    yield request.param
+    gpu64.set_option("rof_pipe", 1)
+
+
 @pytest.mark.parametrize("ny,nx,nz", [(9, 13, 3), (40, 70, 3), (17, 8, 2), (6, 6, 1), (130, 97, 4)])
 def test_colour_warp_and_normalisation_bitexact(gpu64, orc, ny, nx, nz):
     rng = np.random.default_rng(nx * ny + nz)

@@ -185,6 +185,22 @@ def test_lds_windows_of_the_sor_kernels_cover_every_access():
                 assert mod.unit_range_violations(nx, ny, R, solver) == 0, (solver, nx, ny, R)
 
 
+def test_rof_iteration_pipeline_schedule():
+    """k_rof_window keeps all iterations of a Scalar_ROF_BoxCellCentered call in flight: sweep s follows ROF_LAGI = 120 positions
+    behind sweep s - 1, the alfa stage of s runs ROF_D = 58 positions ahead of it (ofx_occ.hip).  tools/check_rof_pipeline.py
+    enumerates, per cell, what each stage takes from another workgroup: stored by an earlier launch, overwritten by a later one."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_rof_pipeline", os.path.join(ROOT, "tools", "check_rof_pipeline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src = open(os.path.join(ROOT, "optical-flow-1_amd", "csrc", "ofx_occ.hip")).read()
+    assert "#define ROF_K 24" in src and "#define ROF_LAG (ROF_K + 8)" in src and "#define ROF_LAGI 120" in src
+    assert "#define ROF_D (ROF_K + ROF_LAG + 2)" in src and "#define ROF_NT 128" in src and "#define ROF_R (ROF_NT - 3)" in src
+    for nx, ny, R in [(40, 30, 125), (17, 260, 125), (9, 9, 125), (2, 2, 125), (33, 20, 7), (5, 40, 3)]:
+        assert mod.violations(nx, ny, R, 24, 32, 120, 58) == 0, (nx, ny, R)
+    assert mod.violations(33, 20, 7, 24, 32, 112, 58) > 0 and mod.violations(33, 20, 7, 24, 32, 120, 50) > 0    # the checker does bite
+
+
 def test_flo_reader_on_the_reference_own_flow_file(io):
     """tests/golden/ipol_tvl1flow_3_uv.flo is the one data file the reference ships (3rdparty/tvl1flow_3/uv.flo,
     a 256x256 flow written by the IPOL original's iio; its input images were removed upstream, so it pins the

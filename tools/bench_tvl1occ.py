@@ -22,8 +22,11 @@ ap.add_argument("--cpu", default="ref")
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--warps", type=int, default=2)
 ap.add_argument("--batch", default="", help="contexts:triples, e.g. 4:8 -- also time a batch of independent triples")
+ap.add_argument("--opt", action="append", default=[], help="name=value for every context (e.g. rof_pipe=0)")
 a = ap.parse_args()
 ctx = ofx.Ofx(0, ofx.F64)
+for o in a.opt:
+    ctx.set_option(o.split("=")[0], float(o.split("=")[1]))
 for size in a.size or ["320x240"]:
     nx, ny = (int(v) for v in size.split("x"))
     zf = 0.5
@@ -36,7 +39,7 @@ for size in a.size or ["320x240"]:
     gpu_s = time.perf_counter() - t
     st = ctx.stats()
     iters = [[st.iters[s][w] for w in range(a.warps)] for s in range(ns)]
-    rec = {"size": size, "nscales": ns, "warps": a.warps, "gpu_s": round(gpu_s, 4), "outer_iterations": iters,
+    rec = {"size": size, "options": a.opt, "nscales": ns, "warps": a.warps, "gpu_s": round(gpu_s, 4), "outer_iterations": iters,
            "occluded_frac": round(float(c.mean()), 4)}
     if a.cpu != "none":
         import oracle
@@ -54,6 +57,9 @@ for size in a.size or ["320x240"]:
     if a.batch:
         n_ctx, n_tr = (int(v) for v in a.batch.split(":"))
         ctxs = [ofx.Ofx(0, ofx.F64) for _ in range(n_ctx)]
+        for c_ in ctxs:
+            for o in a.opt:
+                c_.set_option(o.split("=")[0], float(o.split("=")[1]))
         triples = [tuple(synth.sequence(nx, ny, 3, k + 1)) for k in range(n_tr)]
         ofx.tvl1occ_batch(ctxs, triples[:n_ctx], **dict(kw, nscales=1, warps=1))                # warm every context
         t = time.perf_counter()
