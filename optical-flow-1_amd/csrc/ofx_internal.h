@@ -71,6 +71,7 @@ struct ofx_ctx {
     int gauss_fused;    // pyramids of lockstep groups: row + column pass of the Gaussian in one launch through LDS (1 default)
     int warp_lds;       // 1 (default): TV-L1 warp with the taps staged through LDS; 0: gathered from global memory
     int chunk;
+    int chi_fuse;       // Solver_wrt_chi: 1 = CHI_N iterations per launch on LDS tiles (default), 0 = two launches per iteration
     int rof_pipe;       // ROF box sweeps (ofx_occ.hip): 1 = all iterations of a call in flight (default), 0 = one at a time
     int rows_slots;     // strip-height model of the fused kernel when contexts share the device: waves per "round" (0 = 1024)
     int spin_us;        // convergence polls: microseconds the host spins on the pinned record before it falls back to

@@ -434,6 +434,153 @@ __global__ void k_occ_chi(OccChi a, int nx, int ny, double lambda, double theta,
     a.chi[p] = c;
 }
 
+// Several iterations per launch.  One iteration moves information by one pixel (eta reads chi of the right / lower
+// neighbour, chi reads g eta of the left / upper one), so a workgroup that holds a CHI_T x CHI_T tile of (chi, g eta1, g eta2) in
+// LDS can run n <= CHI_N iterations on its own: whatever enters from beyond the tile edge is wrong by then only within
+// CHI_N pixels of the edge, and the (CHI_T - 2 CHI_N)^2 pixels in the middle are exactly what n global iterations give
+// (same expressions, same order; pixels outside the image are never read -- the one-sided differences at the image border
+// do not look there).  The state goes from one set of planes to another (tiles overlap), the per-pixel constants -- g, the
+// two branches of F and G, beta div u -- are computed once per launch and stay in registers.  100 iterations = 20 launches
+// instead of 200; a small level is a chain of launch latencies, so that is most of its time.
+#define CHI_T 32
+#define CHI_N 5
+#define CHI_IN (CHI_T - 2 * CHI_N)
+struct OccChiState {
+    const double *chi, *eta1, *eta2;     // in
+    double *chi_o, *eta1_o, *eta2_o;     // out
+};
+__global__ __launch_bounds__(256) void k_occ_chi_fused(OccChi a, OccChiState st, int nx, int ny, int n_it, double lambda, double theta,
+                                                       double alpha, double beta, double tau_chi, double tau_eta, OccGrp grp)
+{
+    __shared__ double s_chi[CHI_T][CHI_T + 1], s_g1[CHI_T][CHI_T + 1], s_g2[CHI_T][CHI_T + 1];
+    size_t o;
+    if (!occ_grp(grp, o)) return;
+    const int tx = threadIdx.x, ty = threadIdx.y;                       // 32 x 8: four rows per thread
+    const int j = (int) blockIdx.x * CHI_IN - CHI_N + tx;
+    const int i0 = (int) blockIdx.y * CHI_IN - CHI_N + ty;
+    constexpr int M = CHI_T / 8;
+    double g[M], F0[M], G0[M], F1[M], G1[M], bd[M], c[M], e1[M], e2[M];
+    bool in[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int i = i0 + 8 * m, ly = ty + 8 * m;
+        in[m] = j >= 0 && j < nx && i >= 0 && i < ny;
+        g[m] = F0[m] = G0[m] = F1[m] = G1[m] = bd[m] = c[m] = e1[m] = e2[m] = 0.0;
+        if (in[m]) {
+            const size_t p = o + (size_t) i * nx + j;
+            g[m] = a.g[p];
+            const double u1 = a.u1[p], u2 = a.u2[p];
+            const double f1 = a.Vf1[p], f2 = a.Vf2[p], b1 = a.Vb1[p], b2 = a.Vb2[p];
+            const double rho1 = a.rho1_c[p] + (a.I1wx[p] * f1 + a.I1wy[p] * f2);
+            const double abs_rho1 = (rho1 < 0.) ? -rho1 : rho1;
+            const double rho3 = a.rho3_c[p] - (a.I_1wx[p] * b1 + a.I_1wy[p] * b2);
+            const double abs_rho3 = (rho3 < 0.) ? -rho3 : rho3;
+            F0[m] = -lambda * abs_rho1;
+            G0[m] = -(0.5 / theta) * ((f1 - u1) * (f1 - u1) + (f2 - u2) * (f2 - u2));
+            F1[m] = lambda * abs_rho3;
+            G1[m] = (0.5 / theta) * ((b1 - u1) * (b1 - u1) + (b2 - u2) * (b2 - u2)) + alpha * theta * (b1 * b1 + b2 * b2);
+            bd[m] = beta * a.div_u[p];
+            c[m] = st.chi[p];
+            e1[m] = st.eta1[p];
+            e2[m] = st.eta2[p];
+        }
+        s_chi[ly][tx] = c[m];
+        s_g1[ly][tx] = g[m] * e1[m];
+        s_g2[ly][tx] = g[m] * e2[m];
+    }
+    __syncthreads();
+    const int txr = tx < CHI_T - 1 ? tx + 1 : tx, txl = tx > 0 ? tx - 1 : 0;        // beyond the tile: any value (see above)
+    for (int it = 0; it < n_it; it++) {
+#pragma unroll
+        for (int m = 0; m < M; m++) {                                    // eta += tau_eta g grad(chi), projected (k_occ_eta)
+            const int i = i0 + 8 * m, ly = ty + 8 * m, lyd = ly < CHI_T - 1 ? ly + 1 : ly;
+            if (in[m]) {
+                const double chix = (j < nx - 1) ? s_chi[ly][txr] - c[m] : 0.0;
+                const double chiy = (i < ny - 1) ? s_chi[lyd][tx] - c[m] : 0.0;
+                double a1 = e1[m] + tau_eta * g[m] * chix;
+                double a2 = e2[m] + tau_eta * g[m] * chiy;
+                const double norm2 = a1 * a1 + a2 * a2;
+                if (norm2 < OCC_IS_ZERO) {
+                    a1 = 0.0;
+                    a2 = 0.0;
+                } else {
+                    const double norm = sqrt(norm2);
+                    a1 = a1 / norm;
+                    a2 = a2 / norm;
+                }
+                e1[m] = a1;
+                e2[m] = a2;
+                s_g1[ly][tx] = g[m] * a1;
+                s_g2[ly][tx] = g[m] * a2;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M; m++) {                                    // chi += tau_chi (div(g eta) - F - G - beta div u), clamped (k_occ_chi)
+            const int i = i0 + 8 * m, ly = ty + 8 * m, lyu = ly > 0 ? ly - 1 : 0;
+            if (in[m]) {
+                const double ac = g[m] * e1[m], bc = g[m] * e2[m];
+                const double al = j > 0 ? s_g1[ly][txl] : 0.0, bu = i > 0 ? s_g2[lyu][tx] : 0.0;
+                const double div_eta = div_backward(ac, al, bc, bu, j == 0, j == nx - 1, i == 0, i == ny - 1);
+                double cc = c[m];
+                const double F = cc < 0.5 ? F0[m] : F1[m], G = cc < 0.5 ? G0[m] : G1[m];
+                cc = cc + tau_chi * (div_eta - F - G - bd[m]);
+                if (cc > 1.) cc = 1.;
+                else if (cc < 0.) cc = 0.;
+                c[m] = cc;
+                s_chi[ly][tx] = cc;
+            }
+        }
+        __syncthreads();
+    }
+    if (tx >= CHI_N && tx < CHI_T - CHI_N) {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const int i = i0 + 8 * m, ly = ty + 8 * m;
+            if (in[m] && ly >= CHI_N && ly < CHI_T - CHI_N) {
+                const size_t p = o + (size_t) i * nx + j;
+                st.chi_o[p] = c[m];
+                st.eta1_o[p] = e1[m];
+                st.eta2_o[p] = e2[m];
+            }
+        }
+    }
+}
+// n_iter iterations of the chi solver on G sets of planes: (chi, eta1, eta2) in place, alt = three scratch planes per set
+static int occ_chi_iterations(ofx_ctx *ctx, const OccChi &a, double *chi, double *eta1, double *eta2, double *alt, int nx, int ny,
+                              int n_iter, double lambda, double theta, double alpha, double beta, double tau_chi, double tau_eta,
+                              int G, const OccGrp &grp)
+{
+    const size_t n = (size_t) nx * ny * G;
+    if (!ctx->chi_fuse) {
+        const dim3 grid(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), G), block(64, 4);
+        for (int k = 0; k < n_iter; k++) {
+            hipLaunchKernelGGL(k_occ_eta, grid, block, 0, ctx->stream, (const double *) chi, a.g, eta1, eta2, nx, ny, tau_eta, grp);
+            hipLaunchKernelGGL(k_occ_chi, grid, block, 0, ctx->stream, a, nx, ny, lambda, theta, alpha, beta, tau_chi, grp);
+        }
+        OFX_LAUNCH_CHECK(ctx);
+        return OFX_OK;
+    }
+    double *cur[3] = {chi, eta1, eta2}, *nxt[3] = {alt, alt + n, alt + 2 * n};
+    const dim3 grid(ofx_cdiv(nx, CHI_IN), ofx_cdiv(ny, CHI_IN), G), block(CHI_T, 8);
+    int launches = 0;
+    for (int k = 0; k < n_iter; k += CHI_N, launches++) {
+        const OccChiState st = {cur[0], cur[1], cur[2], nxt[0], nxt[1], nxt[2]};
+        hipLaunchKernelGGL(k_occ_chi_fused, grid, block, 0, ctx->stream, a, st, nx, ny, n_iter - k < CHI_N ? n_iter - k : CHI_N, lambda,
+                           theta, alpha, beta, tau_chi, tau_eta, grp);
+        for (int q = 0; q < 3; q++) { double *t = cur[q]; cur[q] = nxt[q]; nxt[q] = t; }
+    }
+    OFX_LAUNCH_CHECK(ctx);
+    if (launches & 1) {                                   // the result sits in the scratch planes: bring it home (sets that are
+        for (int q = 0; q < 3; q++)                       // not iterating were not written there: copy set by set)
+            for (int gi = 0; gi < G; gi++)
+                if ((grp.mask >> gi) & 1u)
+                    OFX_HIP(ctx, hipMemcpyAsync(nxt[q] + (size_t) gi * nx * ny, cur[q] + (size_t) gi * nx * ny,
+                                                (size_t) nx * ny * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return OFX_OK;
+}
+
 extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *u2, double *chi, const double *I1wx,
                                   const double *I1wy, const double *I_1wx, const double *I_1wy, const double *rho1_c,
                                   const double *rho3_c, const double *Vfwd_1, const double *Vfwd_2, const double *Vbck_1,
@@ -455,12 +602,9 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
     OFX_LAUNCH_CHECK(ctx);
     const OccChi a = {di[0], di[1], di[2], di[3], di[4], di[5], di[6], di[7], di[8], di[9], di[10], di[11], di[12], di[14], di[15],
                       div_u, di[13]};
-    for (int it = 0; it < n_iter; it++) {
-        hipLaunchKernelGGL(k_occ_eta, grid, block, 0, ctx->stream, (const double *) di[13], (const double *) di[12], di[14], di[15],
-                           nx, ny, tau_eta, OCC_ONE);
-        hipLaunchKernelGGL(k_occ_chi, grid, block, 0, ctx->stream, a, nx, ny, lambda, theta, alpha, beta, tau_chi, OCC_ONE);
-    }
-    OFX_LAUNCH_CHECK(ctx);
+    double *alt;
+    OFX_TRY(ofx_alloc(ctx, 3 * n, &alt));
+    OFX_TRY(occ_chi_iterations(ctx, a, di[13], di[14], di[15], alt, nx, ny, n_iter, lambda, theta, alpha, beta, tau_chi, tau_eta, 1, OCC_ONE));
     OFX_TRY(d.out(di[13], chi, n));
     OFX_TRY(d.out(di[14], eta1, n));
     OFX_TRY(d.out(di[15], eta2, n));
@@ -510,9 +654,13 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
 // same launches) computes alfa_s straight from the pairs sweep s - 1 has left behind (u_{s-1} at the cell, its east and
 // its south neighbour, never stored).  A call of n iterations is then one chain of qmax + ROF_LAGI (n - 1) steps instead of
 // n chains of qmax steps.  The conditions (every value an alfa stage or a sweep takes from another workgroup was stored by an
-// earlier launch and is overwritten by a later one) are enumerated by tools/check_rof_pipeline.py: D in [58, 60], LAGI >= 118.
+// earlier launch and is overwritten by a later one) are enumerated by tools/check_rof_pipeline.py: D in [58, 60], LAGI >= 118;
+// an image of one row block (ny <= ROF_R: the coarse pyramid levels, where the pipeline's depth is most of the chain) has no
+// block lag to respect: D in [26, 28], LAGI >= 54.
 #define ROF_D (ROF_K + ROF_LAG + 2)
 #define ROF_LAGI 120
+#define ROF_D_1 (ROF_K + 2)
+#define ROF_LAGI_1 56
 #define ROF_RING (ROF_K + 7)         // positions q0 - 4 .. q1 + 2
 #define ROF_COEF (ROF_K + 3)         // positions q0 - 2 .. q1 + 1
 #define ROF_LDS_BYTES ((size_t) ROF_NT * (ROF_RING * sizeof(double2) + ROF_COEF * (sizeof(double2) + sizeof(double))))
@@ -690,6 +838,7 @@ struct RofSet {
     size_t stride;                   // lockstep groups: problem set g = blockIdx.z works on arrays offset by g * stride
     unsigned mask;                   // bit g: still iterating
     int nc, B;                       // problems per set, row blocks: blockIdx.y = problem + nc * iteration, blockIdx.x = block (+ B: alfa stage)
+    int lagi, d;                     // positions between the sweeps of consecutive iterations / alfa stage ahead of its sweep
 };
 // u = lambda f + lambda (P_south - P_north + P_east - P_west) of one cell from the hyperplane-major pairs (k_rof_u's expression)
 OFX_DEV double rof_u_cell(const double2 *__restrict__ PP, const double *__restrict__ LF, int ci, int cj, int ny, double lambda)
@@ -733,12 +882,12 @@ __global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, do
     a.PP += off; a.FF += off; a.AL += off;
     const int nx = a.nx, ny = a.ny;
     const int t = (int) threadIdx.x, row0 = b * ROF_R - 2;
-    const int q0 = T0 - ROF_LAG * b - ROF_LAGI * it, q1 = q0 + ROF_K - 1;
+    const int q0 = T0 - ROF_LAG * b - s.lagi * it, q1 = q0 + ROF_K - 1;
     // positions at which the block's own rows have cells: outside them the unit has nothing to do (uniform over the workgroup)
     const int p_lo = 2 * b * ROF_R, p_hi = 2 * (min(b * ROF_R + ROF_R, ny) - 1) + nx - 1;
     if (alfa_stage) {
-        if (it == 0 || q0 + ROF_D > p_hi || q1 + ROF_D < p_lo) return;      // alfa of iteration 0 comes from the seed (k_rof_alfa)
-        rof_alfa_band(a, (prob ? s.LF[1] : s.LF[0]) + off, s.LG + off, (prob ? s.ALw[1] : s.ALw[0]) + off, b, q0 + ROF_D, lambda);
+        if (it == 0 || q0 + s.d > p_hi || q1 + s.d < p_lo) return;          // alfa of iteration 0 comes from the seed (k_rof_alfa)
+        rof_alfa_band(a, (prob ? s.LF[1] : s.LF[0]) + off, s.LG + off, (prob ? s.ALw[1] : s.ALw[0]) + off, b, q0 + s.d, lambda);
         return;
     }
     if (q0 > p_hi || q1 < p_lo) return;
@@ -907,6 +1056,8 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
     }
     const int B = ofx_cdiv(ny, ROF_R), qmax = 2 * (ny - 1) + nx - 1;
     set.LG = LG; set.stride = n; set.mask = mask; set.nc = nc; set.B = B;
+    set.lagi = B > 1 ? ROF_LAGI : ROF_LAGI_1;
+    set.d = B > 1 ? ROF_D : ROF_D_1;
     pt.nc = nc; pt.rm_stride = nrm; pt.sk_stride = n; pt.mask = mask;
     static std::atomic<unsigned> lds_set(0);           // bit d: the attribute has been set on device d (per device, any thread)
     if (!(lds_set.load() & (1u << (ctx->device & 31)))) {
@@ -916,15 +1067,13 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
     }
     if (n_iter < 1) return OFX_OK;
     if (ctx->rof_pipe) {
-        const long total = (long) qmax + 1 + (long) ROF_LAG * (B - 1) + (long) ROF_LAGI * (n_iter - 1);
+        const long total = (long) qmax + 1 + (long) ROF_LAG * (B - 1) + (long) set.lagi * (n_iter - 1);
         hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
         for (long T0 = 0; T0 < total; T0 += ROF_K) {
-            // iterations with a window in this launch: T0 - LAGI it within [-K - D, qmax + LAG (B - 1)]
-            long it_lo = (T0 - qmax - (long) ROF_LAG * (B - 1) + ROF_LAGI - 1) / ROF_LAGI;
-            if (T0 - qmax - (long) ROF_LAG * (B - 1) < 0) it_lo = 0;
-            long it_hi = (T0 + ROF_K + ROF_D) / ROF_LAGI;
+            // the grid covers iterations 0 .. it_hi (the last one whose alfa stage has reached position 0); units outside
+            // their range of positions leave at once
+            long it_hi = (T0 + ROF_K + set.d) / set.lagi;
             if (it_hi > n_iter - 1) it_hi = n_iter - 1;
-            (void) it_lo;                                  // the grid covers iterations 0 .. it_hi; units outside their range leave at once
             hipLaunchKernelGGL(k_rof_window, dim3(2 * B, nc * (int) (it_hi + 1), G), dim3(ROF_THREADS), ROF_LDS_BYTES, ctx->stream, set,
                                (int) T0, omega, lambda);
         }
@@ -1214,7 +1363,7 @@ struct OccParams {
 // [G][rof_skew_elems()]
 struct OccWork {
     double *I1x, *I1y, *I_1x, *I_1y, *I1wx, *I1wy, *I_1wx, *I_1wy, *rho1_c, *rho3_c, *grad1, *grad3, *v1, *v2, *vf1, *vf2, *vb1,
-        *vb2, *g, *u1p, *u2p, *f1, *f2, *t1, *t2, *divu, *state, *eta, *rof, *part;
+        *vb2, *g, *u1p, *u2p, *f1, *f2, *t1, *t2, *divu, *state, *eta, *rof, *part, *chi_alt;
     int alloc(ofx_ctx *ctx, size_t n, size_t nskew, int G)
     {
         double **planes[] = {&I1x, &I1y, &I_1x, &I_1y, &I1wx, &I1wy, &I_1wx, &I_1wy, &rho1_c, &rho3_c, &grad1, &grad3, &v1,
@@ -1222,6 +1371,7 @@ struct OccWork {
         for (auto p : planes) OFX_TRY(ofx_alloc(ctx, n * G, p));
         OFX_TRY(ofx_alloc(ctx, 4 * nskew * G, &state));      // dual planes of Solver_wrt_u, hyperplane-major
         OFX_TRY(ofx_alloc(ctx, 2 * n * G, &eta));            // dual variable of Solver_wrt_chi
+        OFX_TRY(ofx_alloc(ctx, 3 * n * G, &chi_alt));        // second set of (chi, eta1, eta2) planes of the fused chi iterations
         OFX_TRY(ofx_alloc(ctx, ROF_SCRATCH_PLANES(2) * nskew * G, &rof));
         return ofx_alloc(ctx, (size_t) (OCC_ERR_BLOCKS + 1) * G, &part);
     }
@@ -1279,11 +1429,8 @@ int occ_single_scale_dev(ofx_ctx *ctx, int G, const double *I_1, const double *I
                                W.t2, nx, ny, n, active);
             hipLaunchKernelGGL(k_occ_copy2, g1, dim3(256), 0, st, (const double *) W.t1, (const double *) W.t2, u1, u2, (int) n, grp);
             hipLaunchKernelGGL(k_occ_divu, grid, block, 0, st, (const double *) u1, (const double *) u2, W.divu, nx, ny, grp);
-            for (int k = 0; k < OCC_MAX_ITERATIONS_CHI; k++) {
-                hipLaunchKernelGGL(k_occ_eta, grid, block, 0, st, (const double *) chi, (const double *) W.g, eta1, eta2, nx, ny,
-                                   OCC_TAU_ETA, grp);
-                hipLaunchKernelGGL(k_occ_chi, grid, block, 0, st, ac, nx, ny, P.lambda, P.theta, P.alpha, P.beta, OCC_TAU_CHI, grp);
-            }
+            OFX_TRY(occ_chi_iterations(ctx, ac, chi, eta1, eta2, W.chi_alt, nx, ny, OCC_MAX_ITERATIONS_CHI, P.lambda, P.theta, P.alpha,
+                                       P.beta, OCC_TAU_CHI, OCC_TAU_ETA, G, grp));
             hipLaunchKernelGGL(k_occ_err_partial, dim3(OCC_ERR_BLOCKS, 1, G), dim3(256), 0, st, (const double *) u1, (const double *) u2,
                                W.u1p, W.u2p, (int) n, W.part, grp);
             hipLaunchKernelGGL(k_occ_err_final, dim3(G), dim3(256), 0, st, (const double *) W.part, d_err);
@@ -1442,7 +1589,7 @@ extern "C" int ofx_tvl1occ_batch(ofx_ctx *const *ctxs, int n_ctx, int n_triples,
         OFX_TRY(occ_check_args(ctx, nxx, nyy, lambda, theta, nscales, zfactor, warps));
     }
     // group size: option "lockstep" of ctxs[0], else as many as fit.  Per triple: 7 planes per pyramid level (occ_group: 4 images,
-    // u1, u2, chi) + OccWork's 28 full-size row-major and 13 hyperplane-major planes + 2 of Gaussian / zoom scratch
+    // u1, u2, chi) + OccWork's 31 full-size row-major and 13 hyperplane-major planes + 2 of Gaussian / zoom scratch
     int G = ctxs[0]->lockstep > 0 ? ctxs[0]->lockstep : OCC_MAX_GROUP;
     if (G > OCC_MAX_GROUP) G = OCC_MAX_GROUP;
     {
@@ -1453,7 +1600,7 @@ extern "C" int ofx_tvl1occ_batch(ofx_ctx *const *ctxs, int n_ctx, int n_triples,
         OFX_TRY(op_pyramid_sizes(ctxs[0], nxx, nyy, nscales, zfactor, nxs, nys));
         double level_px = 0.0;
         for (int s = 0; s < nscales; s++) level_px += (double) nxs[s] * nys[s];
-        const double per = 8.0 * (7.0 * level_px + 30.0 * nxx * nyy + 13.0 * (double) rof_skew_elems(nxx, nyy)) * 1.05;
+        const double per = 8.0 * (7.0 * level_px + 33.0 * nxx * nyy + 13.0 * (double) rof_skew_elems(nxx, nyy)) * 1.05;
         const int fit = (int) (budget / per);
         if (fit < 1) return ofx_fail(ctxs[0], OFX_ERR_NOMEM, "tvl1occ batch: %.1f GB per triple, %.1f GB per context available", per / 1e9, budget / 1e9);
         if (G > fit) G = fit;

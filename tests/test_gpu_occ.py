@@ -9,16 +9,20 @@ from test_oracle_vs_ref import _occ_inputs
 pytestmark = pytest.mark.gpu
 
 
-# The ROF box sweeps run with all iterations of a call in flight (option rof_pipe = 1, default: sweeps ROF_LAGI positions apart,
-# alfa of the next iteration computed between the wavefronts) or one iteration at a time (0): every test that reaches them runs
-# with both.
+# Two schedules exist for the two iterative solvers inside the outer loop, both bit-identical by construction and both tested:
+# * ROF box sweeps: all iterations of a call in flight (option rof_pipe = 1, default: sweeps ROF_LAGI positions apart, alfa of
+#   the next iteration computed between the wavefronts) or one iteration at a time (0);
+# * Solver_wrt_chi: CHI_N iterations per launch on overlapping LDS tiles (chi_fuse = 1, default) or two launches per iteration (0).
 @pytest.fixture(autouse=True, params=[1, 0], ids=["pipelined", "serial"])
 def rof_schedule(request, gpu64):
-    if request.param == 0 and not request.node.name.startswith(("test_rof", "test_tvl1occ_multiscale", "test_tvl1occ_lockstep")):
-        pytest.skip("does not reach the ROF sweeps: once is enough")
+    if request.param == 0 and not request.node.name.startswith(("test_rof", "test_occlusion_solvers", "test_tvl1occ_multiscale",
+                                                                "test_tvl1occ_lockstep")):
+        pytest.skip("does not reach the iterative solvers: once is enough")
     gpu64.set_option("rof_pipe", request.param)
+    gpu64.set_option("chi_fuse", request.param)
     yield request.param
     gpu64.set_option("rof_pipe", 1)
+    gpu64.set_option("chi_fuse", 1)
 
 
 @pytest.mark.parametrize("ny,nx,nz", [(9, 13, 3), (40, 70, 3), (17, 8, 2), (6, 6, 1), (130, 97, 4)])

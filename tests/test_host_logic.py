@@ -196,8 +196,12 @@ def test_rof_iteration_pipeline_schedule():
     src = open(os.path.join(ROOT, "optical-flow-1_amd", "csrc", "ofx_occ.hip")).read()
     assert "#define ROF_K 24" in src and "#define ROF_LAG (ROF_K + 8)" in src and "#define ROF_LAGI 120" in src
     assert "#define ROF_D (ROF_K + ROF_LAG + 2)" in src and "#define ROF_NT 128" in src and "#define ROF_R (ROF_NT - 3)" in src
+    assert "#define ROF_D_1 (ROF_K + 2)" in src and "#define ROF_LAGI_1 56" in src
     for nx, ny, R in [(40, 30, 125), (17, 260, 125), (9, 9, 125), (2, 2, 125), (33, 20, 7), (5, 40, 3)]:
         assert mod.violations(nx, ny, R, 24, 32, 120, 58) == 0, (nx, ny, R)
+    for nx, ny in [(40, 30), (160, 120), (9, 9), (2, 2), (3, 125), (125, 3)]:            # one row block: the shorter lags
+        assert mod.violations(nx, ny, 125, 24, 32, 56, 26) == 0, (nx, ny)
+    assert mod.violations(17, 260, 125, 24, 32, 56, 26) > 0                              # ... which several blocks do not allow
     assert mod.violations(33, 20, 7, 24, 32, 112, 58) > 0 and mod.violations(33, 20, 7, 24, 32, 120, 50) > 0    # the checker does bite
 
 
