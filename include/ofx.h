@@ -115,6 +115,10 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         launch on 2-D tiles instead of the marching strips (0 = off, the default: measured no faster)
  *   "sor_lds"        windowed exact SOR sweeps: 0 = one global round trip per time step, 2 = the launch window staged in LDS,
  *                         1 (default) = by measurement (LDS for lone Horn-Schunck solves).  Results do not depend on it.
+ *   "rof_pipe"       1/0  TV-L1 with occlusions / Scalar_ROF_BoxCellCentered: all iterations of a call in flight, the sweep
+ *                         of iteration s 120 positions behind the sweep of s - 1 (default 1); 0 = one iteration at a time
+ *   "chi_fuse"       1/0  Solver_wrt_chi: 5 iterations per launch on overlapping LDS tiles (default 1); 0 = two launches per
+ *                         iteration.  Results do not depend on either.
  *   "gauss_fused"    1/0  pyramids of lockstep groups: row + column pass of the Gaussian in one launch (default 1)
  *   "spin_us"        microseconds the host spins on a convergence poll's pinned record before it sleeps in
  *                         hipEventSynchronize (default 150; 0 = never)

@@ -849,17 +849,15 @@ OFX_DEV double rof_u_cell(const double2 *__restrict__ PP, const double *__restri
     return LF[k] + lambda * (own.x - pn + own.y - pw);
 }
 // alfa stage of one row block: alfa of the cells of its rows at positions [p0, p0 + ROF_K) (k_rof_alfa's expression on
-// u recomputed from the pairs).  Thread = row; no dependence between cells.
+// u recomputed from the pairs).  No dependence between cells: consecutive threads take consecutive rows of one position.
 OFX_DEV void rof_alfa_band(const RofArr &a, const double *__restrict__ LF, const double *__restrict__ LG, double *__restrict__ AL,
                            int b, int p0, double lambda)
 {
-    const int t = (int) threadIdx.x, nx = a.nx, ny = a.ny;
-    const int ci = b * ROF_R + t;
-    if (t >= ROF_R || ci >= ny) return;
-#pragma unroll 4
-    for (int p = p0; p < p0 + ROF_K; p++) {
+    const int nx = a.nx, ny = a.ny;
+    for (int idx = (int) threadIdx.x; idx < ROF_R * ROF_K; idx += ROF_THREADS) {
+        const int ci = b * ROF_R + idx % ROF_R, p = p0 + idx / ROF_R;
         const int cj = p - 2 * ci;
-        if (cj < 0 || cj >= nx) continue;
+        if (ci >= ny || cj < 0 || cj >= nx) continue;
         const double u0 = rof_u_cell(a.PP, LF, ci, cj, ny, lambda);
         const double ux = (cj < nx - 1) ? rof_u_cell(a.PP, LF, ci, cj + 1, ny, lambda) - u0 : 0.0;
         const double uy = (ci < ny - 1) ? rof_u_cell(a.PP, LF, ci + 1, cj, ny, lambda) - u0 : 0.0;
@@ -885,6 +883,9 @@ __global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, do
     const int q0 = T0 - ROF_LAG * b - s.lagi * it, q1 = q0 + ROF_K - 1;
     // positions at which the block's own rows have cells: outside them the unit has nothing to do (uniform over the workgroup)
     const int p_lo = 2 * b * ROF_R, p_hi = 2 * (min(b * ROF_R + ROF_R, ny) - 1) + nx - 1;
+    // The alfa stage of (iteration, block) has workgroups of its own.  (Run as the head of the sweep's workgroup instead -- half
+    // the workgroups per launch, each of which fills a CU's LDS -- it changes nothing for lockstep groups, 5.4 ms per 640x480
+    // triple either way, and costs a lone solve 7 %: measured, dropped.)
     if (alfa_stage) {
         if (it == 0 || q0 + s.d > p_hi || q1 + s.d < p_lo) return;          // alfa of iteration 0 comes from the seed (k_rof_alfa)
         rof_alfa_band(a, (prob ? s.LF[1] : s.LF[0]) + off, s.LG + off, (prob ? s.ALw[1] : s.ALw[0]) + off, b, q0 + s.d, lambda);
@@ -1074,8 +1075,8 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
             // their range of positions leave at once
             long it_hi = (T0 + ROF_K + set.d) / set.lagi;
             if (it_hi > n_iter - 1) it_hi = n_iter - 1;
-            hipLaunchKernelGGL(k_rof_window, dim3(2 * B, nc * (int) (it_hi + 1), G), dim3(ROF_THREADS), ROF_LDS_BYTES, ctx->stream, set,
-                               (int) T0, omega, lambda);
+            hipLaunchKernelGGL(k_rof_window, dim3(2 * B, nc * (int) (it_hi + 1), G), dim3(ROF_THREADS), ROF_LDS_BYTES,
+                               ctx->stream, set, (int) T0, omega, lambda);
         }
         hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, pt, nx, ny, lambda);
         OFX_LAUNCH_CHECK(ctx);
