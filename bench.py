@@ -245,9 +245,10 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None, mode="str
     ctx.set_option("profile", 0)
     ctx.set_option("fixed_work", 0)
     us_iter = lv_ms[0] * 1e3 / max(lv_n[0], 1)            # per ITERATION (stats count iterations)
-    us_single = 2.0 * us_iter
+    F1 = max(int(st.fused[0]), 1)                         # iterations per launch of the kernel the library picked (2, or 3: k_tvl1_iter3)
+    us_single = F1 * us_iter
     fused = 15.0 * elem * nx * ny                         # bytes per pair and launch, compulsory for the fused kernel
-    G, us_launch, n_launch = 1, us_single, int(lv_n[0] // 2)
+    G, us_launch, n_launch, F = 1, us_single, int(lv_n[0] // F1), F1
     if group:
         G, solve_group = group
         ctx.set_option("profile", 1)
@@ -256,27 +257,48 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None, mode="str
         g_ms, g_n = 0.0, 0
         for _ in range(max(1, passes)):
             st_g = solve_group()
+            F = max(int(st_g[0].fused[0]), 1)
             g_ms += st_g[0].iter_ms[0]                   # the group's launches, recorded on every member
-            g_n += st_g[0].iter_launches[0] // 2
+            g_n += st_g[0].iter_launches[0] // F
         ctx.synchronize()
         ctx.set_option("profile", 0)
         ctx.set_option("fixed_work", 0)
         us_launch, n_launch = g_ms * 1e3 / max(g_n, 1), g_n
     ach = G * fused / (us_launch * 1e-6) / 1e9
-    equiv = 2.0 * ach
+    equiv = F * ach
     tname = "double" if precision == "f64" else "float"
-    roof = {"bound": "hbm",
-            "kernel": "k_tvl1_iter2<%s> @ %dx%d (2 fused iterations per launch, %d pair%s per launch)" % (tname, nx, ny, G, "" if G == 1 else "s"),
+    roof = {"bound": "hbm", "iterations_per_launch": F,
+            "kernel": "k_tvl1_iter%d<%s> @ %dx%d (%d fused iterations per launch, %d pair%s per launch)" % (F, tname, nx, ny, F, G, "" if G == 1 else "s"),
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": None, "avg_launch_us": round(us_launch, 3), "launches": n_launch, "pairs_per_launch": G,
             "fused_algorithmic_bytes_per_launch": G * fused,
-            "bytes_model": "15 storage elements/px per pair and LAUNCH (2 fused iterations): read U,P1,P2,A,R + write U,P1,P2",
-            "algorithmic_equivalent_bytes_per_launch": 2.0 * G * fused,
+            "bytes_model": "15 storage elements/px per pair and LAUNCH (%d fused iterations): read U,P1,P2,A,R + write U,P1,P2" % F,
+            "algorithmic_equivalent_bytes_per_launch": float(F) * G * fused,
             "algorithmic_equivalent_gbs": round(equiv, 1),
             "algorithmic_equivalent_frac": round(equiv / HBM_PEAK_GBS, 4),
-            "algorithmic_equivalent_note": "SURVEY 8(d): 15 elements/px per ITERATION x 2 iterations per launch; the rate an "
-                                           "unfused kernel would need -- may exceed the HBM peak, not a bandwidth",
-            "mpix_iters_per_s": round(2.0 * G * nx * ny / us_launch, 1), "arithmetic_mode": mode if precision == "f64" else "f32"}
+            "algorithmic_equivalent_note": "SURVEY 8(d): 15 elements/px per ITERATION x %d iterations per launch; the rate an "
+                                           "unfused kernel would need -- may exceed the HBM peak, not a bandwidth" % F,
+            "mpix_iters_per_s": round(float(F) * G * nx * ny / us_launch, 1), "arithmetic_mode": mode if precision == "f64" else "f32"}
+    if F == 3:
+        roof["note"] = ("three fused iterations move the compulsory streams once per THREE iterations: `frac` (compulsory bytes per launch / "
+                        "launch time / peak) is lower than the two-iteration kernel's although the iteration rate is ~30 % higher -- "
+                        "the launch is bound by FP64 issue, no longer by its streams (DESIGN 5.1d); `two_iterations_per_launch` is the "
+                        "same launch shape with option fuse3 = 0")
+    if group and F == 3:                                  # the same launch shape with two iterations per launch, for comparison
+        ctx.set_option("fuse3", 0)
+        ctx.set_option("profile", 1)
+        ctx.set_option("fixed_work", 1)
+        solve_group()
+        st2 = solve_group()
+        ctx.synchronize()
+        ctx.set_option("profile", 0)
+        ctx.set_option("fixed_work", 0)
+        ctx.set_option("fuse3", 2)
+        us2 = st2[0].iter_ms[0] * 1e3 / max(st2[0].iter_launches[0] // 2, 1)
+        a2 = G * fused / (us2 * 1e-6) / 1e9
+        roof["two_iterations_per_launch"] = {"kernel": "k_tvl1_iter2<%s>, option fuse3 = 0" % tname, "avg_launch_us": round(us2, 3),
+                                             "achieved": round(a2, 1), "frac": round(a2 / HBM_PEAK_GBS, 4),
+                                             "mpix_iters_per_s": round(2.0 * G * nx * ny / us2, 1)}
     if group:
         a1 = fused / (us_single * 1e-6) / 1e9
         roof["single_pair"] = {"avg_launch_us": round(us_single, 3), "achieved": round(a1, 1), "frac": round(a1 / HBM_PEAK_GBS, 4),
@@ -285,7 +307,8 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None, mode="str
     pmc = load_pmc()
     # round-3 counter passes on the group launches, per f64 mode (tools/pmc_round3.sh): preferred when they cover this launch
     try:
-        r3 = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_group_launches.json"))).get("%dx%d_group%d_%s" % (nx, ny, G, mode))
+        r3 = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_group_launches.json"))).get(
+            "%dx%d_group%d_%s%s" % (nx, ny, G, mode, "_iter3" if F == 3 else ""))
     except Exception:
         r3 = None
     if r3 and precision == "f64":
@@ -297,6 +320,8 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None, mode="str
         roof["valu_active"] = round(r3["valu_active_fraction"], 3)
         roof["limiter"] = ("strict kernel: co-limited by FP64 issue (VALU active 0.70) and memory (counter traffic 5.6-5.7 TB/s at the counter "
                            "pass's launch time)" if mode == "strict" else
+                           ("tolerance kernel, three iterations per launch: bound by FP64 issue (VALU active %.2f), streams at %.1f TB/s by "
+                            "the counters" % (r3["valu_active_fraction"], r3["counter_tb_per_s"])) if F == 3 else
                            "tolerance kernel: memory-bound -- counter traffic 6.0 (1080p) / 6.3 (4K) TB/s at the counter pass's launch time, "
                            "the rate the guide gives as achievable for HBM3E on this part; VALU active 0.45-0.48")
         levels = [{"size": "%dx%d" % (st.nx[s_], st.ny[s_]), "iter_us": round(lv_ms[s_] * 1e3 / max(lv_n[s_], 1), 2),

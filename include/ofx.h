@@ -75,6 +75,9 @@ typedef struct ofx_stats {
                                                          fused pair ...                                        */
     int    odd_stops_stored;                          /* ... of which the launch had stored its intermediate
                                                          state (option "store_a"): no recomputation needed     */
+    int    fused[OFX_MAX_SCALES];                     /* TV-L1: iterations per iteration launch at each level
+                                                         (1, 2, 3, or the tile kernel's 4 | 6); odd_stops then
+                                                         counts the loops that ended inside such a launch unit  */
 } ofx_stats;
 
 /* ---- context ---------------------------------------------------------------------------------*/
@@ -101,6 +104,9 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *   "sor_spw"        consecutive sweeps of a row block that share a workgroup in sor_exact = 1 (1, 2 or 4; default 0 = 1,
  *                         the fastest measured; results do not depend on it)
  *   "fuse2"          1/0  TV-L1: two iterations per kernel launch (default 1)
+ *   "fuse3", "fuse3_min_px"  TV-L1: three iterations per launch (k_tvl1_iter3): 0 never, 1 on every level of at least
+ *                         fuse3_min_px pixels x pairs, 2 (default) by measurement: not in strict mode, only for lockstep groups
+ *                         or contexts sharing the device, levels of >= 500 000 pixels x pairs.  Results do not depend on it.
  *   "store_a"        TV-L1, fused pairs: a loop that stops on the first iteration of a pair needs the state between the
  *                         two iterations; 1 (default) = a launch also stores it when the previous error is within 1.5x
  *                         of the threshold (the host then just switches buffers), 0 = never (the iteration is

@@ -39,7 +39,7 @@ class Stats(C.Structure):
                 ("iter_ms", C.c_double * MAX_SCALES),
                 ("iter_launches", C.c_longlong * MAX_SCALES),
                 ("work_pix_iters", C.c_double), ("total_ms", C.c_double),
-                ("odd_stops", C.c_int), ("odd_stops_stored", C.c_int)]
+                ("odd_stops", C.c_int), ("odd_stops_stored", C.c_int), ("fused", C.c_int * MAX_SCALES)]
 
     def iterations(self):
         return np.array([[self.iters[s][w] for w in range(min(self.nsolves, MAX_SOLVES))]

@@ -78,6 +78,9 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->rows_slots = 0;
     ctx->rof_pipe = 1;
     ctx->chi_fuse = 1;
+    ctx->fuse3 = 2;
+    ctx->fuse3_min_px = 0.0;
+    ctx->rows_per_wave3 = 0;
     ctx->fixed_work = 0;
     ctx->sor_exact = 1;
     ctx->sor_batch = 0;
@@ -224,6 +227,13 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "rows_slots")) { ctx->rows_slots = (int) value; return OFX_OK; }
     if (!strcmp(name, "rof_pipe")) { ctx->rof_pipe = value != 0; return OFX_OK; }
     if (!strcmp(name, "chi_fuse")) { ctx->chi_fuse = value != 0; return OFX_OK; }
+    if (!strcmp(name, "fuse3")) {
+        if (value != 0 && value != 1 && value != 2) return ofx_fail(ctx, OFX_ERR_ARG, "fuse3 must be 0, 1 or 2");
+        ctx->fuse3 = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "fuse3_min_px")) { ctx->fuse3_min_px = value; return OFX_OK; }
+    if (!strcmp(name, "rows_per_wave3")) { ctx->rows_per_wave3 = (int) value; return OFX_OK; }
     if (!strcmp(name, "spin_us")) {
         if (value < 0 || value > 1e6) return ofx_fail(ctx, OFX_ERR_ARG, "spin_us out of range");
         ctx->spin_us = (int) value;

@@ -71,6 +71,9 @@ struct ofx_ctx {
     int gauss_fused;    // pyramids of lockstep groups: row + column pass of the Gaussian in one launch through LDS (1 default)
     int warp_lds;       // 1 (default): TV-L1 warp with the taps staged through LDS; 0: gathered from global memory
     int chunk;
+    int fuse3;          // TV-L1: three iterations per launch (k_tvl1_iter3): 0 never, 1 levels of >= fuse3_min_px pixels x pairs, 2 auto (default)
+    double fuse3_min_px;
+    int rows_per_wave3; // strip height of k_tvl1_iter3 (0 = tvl1_pick_rows3)
     int chi_fuse;       // Solver_wrt_chi: 1 = CHI_N iterations per launch on LDS tiles (default), 0 = two launches per iteration
     int rof_pipe;       // ROF box sweeps (ofx_occ.hip): 1 = all iterations of a call in flight (default), 0 = one at a time
     int rows_slots;     // strip-height model of the fused kernel when contexts share the device: waves per "round" (0 = 1024)

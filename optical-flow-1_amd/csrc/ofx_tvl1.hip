@@ -553,6 +553,211 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
                                        y0, yend, ys, yl, lef, rig, owner, off, so, up12, up22, cur, l_t, theta, taut);
 }
 
+// ---- three iterations per launch ------------------------------------------------------------------------------------------
+// The two-iteration kernel in tolerance mode is bound by its memory streams (6.0 - 6.3 TB/s by the counters, VALU 45 % active,
+// profiles/r03_pmc_group_launches.json).  A third fused iteration moves the same streams once per THREE iterations: six-stage
+// pipeline per loaded row y,   S1 u_A(y)  S2 p_A(y-1)  S3 u_B(y-2)  S4 p_B(y-3)  S5 u_C(y-4)  S6 p_C(y-5),   three halo lanes each
+// side (58 output columns), rows y0-2 .. yend+2 loaded.  HBM elements per pixel and iteration: (9 (rows+5)/rows 64/58 + 6) / 3
+// = 6.0 at 24 rows against 8.4 for two.  CNT < 3 runs only the first CNT iterations (the redo of a loop that ended inside a unit
+// and the tail unit of an iteration limit that is no multiple of 3): same stages, results stored after stage 2 CNT.
+#define STRIP3_OUT 58
+// Measured and dropped (profiles/r03_q_ab_three_iterations_per_launch.txt): 2 waves per SIMD instead of 3 (same speed: the
+// launch is not bound by resident waves); the pipeline registers in row-indexed rings with a four-step loop body instead of
+// shifting ~50 doubles per step (v_mov_b64 119 -> 57 per step, 210 VGPRs: 1.5 % SLOWER -- VALU issue is not the bound either).
+#ifndef OFX_ITER3_WAVES
+#define OFX_ITER3_WAVES 3
+#endif
+template <typename T, bool NT, bool STRICT, int CNT>
+OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const typename Pix<T>::v2 *__restrict__ P1in,
+                              const typename Pix<T>::v2 *__restrict__ P2in, const typename Pix<T>::v2 *__restrict__ A,
+                              const T *__restrict__ R, typename Pix<T>::v2 *Uout, typename Pix<T>::v2 *P1out,
+                              typename Pix<T>::v2 *P2out, double *__restrict__ err, int slot0, int slot_step, int gw, int nx,
+                              int ny, int y0, int yend, int ys, int yl, bool lef, bool rig, bool owner, unsigned off, unsigned so,
+                              double up12, double up22, RowIn<T> cur, double l_t, double theta, double taut)
+{
+    const unsigned E2 = 2 * sizeof(T);
+    const unsigned row2 = (unsigned) nx * E2;
+    const double2 z2 = make_double2(0.0, 0.0);
+    const unsigned level_bytes = (unsigned) nx * (unsigned) ny * E2;
+    const ofx_rsrc rU = make_rsrc(Uout, level_bytes), rP1 = make_rsrc(P1out, level_bytes), rP2 = make_rsrc(P2out, level_bytes);
+    double accA = 0.0, accB = 0.0, accC = 0.0;
+    double2 uA0 = z2, uA1 = z2, uA2 = z2;                    // u_A of rows y, y-1, y-2
+    double2 a1 = z2, a2 = z2, a3 = z2, a4 = z2;              // (I1wx, I1wy) of rows y-1 .. y-4
+    double r1c = 0.0, r2c = 0.0, r3c = 0.0, r4c = 0.0;       // rho_c of rows y-1 .. y-4
+    double2 p0a = z2, p0b = z2;                              // p (iteration k-1) of row y-1
+    double2 pA1a = z2, pA1b = z2, pA2a = z2, pA2b = z2;      // p_A of rows y-2, y-3
+    double2 uB0 = z2, uB1 = z2, uB2 = z2;                    // u_B of rows y-2, y-3, y-4
+    double2 pB1a = z2, pB1b = z2, pB2a = z2, pB2b = z2;      // p_B of rows y-4, y-5
+    double2 uC0 = z2, uC1 = z2;                              // u_C of rows y-4, y-5
+    const int nyl = ny - 1;
+    const int yB0 = y0 > 0 ? y0 - 1 : 0;                     // first row of the B stages
+    const int ylc = (yend + CNT - 1 < yl) ? yend + CNT - 1 : yl;                    // last row of u_A
+    const int hiA = (yend + CNT - 2 < nyl) ? yend + CNT - 2 : nyl;                  // last row of p_A and u_B
+    const int hiB = (yend + CNT - 3 < nyl) ? yend + CNT - 3 : nyl;                  // last row of p_B
+    const int hiC = (yend < nyl) ? yend : nyl;                                      // last row of u_C
+    const int ylast = yend - 1 + (2 * CNT - 1);
+
+    auto step = [&](const int y) {
+        RowIn<T> nxt = cur;
+        if (y + 1 <= ylc) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + row2);
+        unsigned stu = OFX_OOB, stp = OFX_OOB;               // this step's stores: u (one row), p (the row above it)
+        double2 su = z2, sp1 = z2, sp2 = z2;
+
+        // S1: u_A(y)
+        if (y <= ylc) {
+            const double l11 = wave_shift_up(cur.p1.x);
+            const double l21 = wave_shift_up(cur.p2.x);
+            uA0 = tvl1_primal<T, STRICT>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0, y == nyl, l_t,
+                                         theta);
+            if (owner && y >= y0 && y < yend) {
+                accA += (uA0.x - cur.u.x) * (uA0.x - cur.u.x) + (uA0.y - cur.u.y) * (uA0.y - cur.u.y);
+                if (CNT == 1) { stu = so; su = uA0; }
+            }
+        }
+        // S2: p_A(y-1)
+        double2 pAna = z2, pAnb = z2;
+        if (y - 1 >= ys && y - 1 <= hiA) {
+            const double n1 = wave_shift_down(uA1.x);
+            const double n2 = wave_shift_down(uA1.y);
+            tvl1_dual<T, STRICT>(p0a, p0b, uA1, n1, n2, uA0, rig, y - 1 == nyl, taut, pAna, pAnb);
+            pAna.x = rnd_to<T>(pAna.x); pAna.y = rnd_to<T>(pAna.y);
+            pAnb.x = rnd_to<T>(pAnb.x); pAnb.y = rnd_to<T>(pAnb.y);
+            if (CNT == 1 && owner && y - 1 >= y0 && y - 1 < yend) { stp = so - row2; sp1 = pAna; sp2 = pAnb; }
+        }
+        double2 pBna = z2, pBnb = z2;
+        if (CNT >= 2) {
+            // S3: u_B(y-2)
+            if (y - 2 >= yB0 && y - 2 <= hiA) {
+                const double l11 = wave_shift_up(pA1a.x);
+                const double l21 = wave_shift_up(pA1b.x);
+                uB0 = tvl1_primal<T, STRICT>(uA2, a2, r2c, pA1a, pA1b, l11, l21, pA2a.y, pA2b.y, lef, rig, y - 2 == 0, y - 2 == nyl,
+                                             l_t, theta);
+                if (owner && y - 2 >= y0 && y - 2 < yend) {
+                    accB += (uB0.x - uA2.x) * (uB0.x - uA2.x) + (uB0.y - uA2.y) * (uB0.y - uA2.y);
+                    if (CNT == 2) { stu = so - 2 * row2; su = uB0; }
+                }
+            }
+            // S4: p_B(y-3)
+            if (y - 3 >= yB0 && y - 3 <= hiB) {
+                const double n1 = wave_shift_down(uB1.x);
+                const double n2 = wave_shift_down(uB1.y);
+                tvl1_dual<T, STRICT>(pA2a, pA2b, uB1, n1, n2, uB0, rig, y - 3 == nyl, taut, pBna, pBnb);
+                pBna.x = rnd_to<T>(pBna.x); pBna.y = rnd_to<T>(pBna.y);
+                pBnb.x = rnd_to<T>(pBnb.x); pBnb.y = rnd_to<T>(pBnb.y);
+                if (CNT == 2 && owner && y - 3 >= y0 && y - 3 < yend) { stp = so - 3 * row2; sp1 = pBna; sp2 = pBnb; }
+            }
+        }
+        if (CNT == 3) {
+            // S5: u_C(y-4)
+            if (y - 4 >= y0 && y - 4 <= hiC) {
+                const double l11 = wave_shift_up(pB1a.x);
+                const double l21 = wave_shift_up(pB1b.x);
+                uC0 = tvl1_primal<T, STRICT>(uB2, a4, r4c, pB1a, pB1b, l11, l21, pB2a.y, pB2b.y, lef, rig, y - 4 == 0, y - 4 == nyl,
+                                             l_t, theta);
+                if (owner && y - 4 < yend) {
+                    accC += (uC0.x - uB2.x) * (uC0.x - uB2.x) + (uC0.y - uB2.y) * (uC0.y - uB2.y);
+                    stu = so - 4 * row2; su = uC0;
+                }
+            }
+            // S6: p_C(y-5)
+            if (y - 5 >= y0 && y - 5 < yend) {
+                const double n1 = wave_shift_down(uC1.x);
+                const double n2 = wave_shift_down(uC1.y);
+                tvl1_dual<T, STRICT>(pB2a, pB2b, uC1, n1, n2, uC0, rig, y - 5 == nyl, taut, sp1, sp2);
+                if (owner) stp = so - 5 * row2;
+            }
+        }
+        // the stores of this step: always issued, lanes / steps with nothing to write are out of range
+        bst2<NT>(rU, stu, su, Uout);
+        bst2<NT>(rP1, stp, sp1, P1out);
+        bst2<NT>(rP2, stp, sp2, P2out);
+        // advance the pipeline by one row
+        uA2 = uA1; uA1 = uA0;
+        a4 = a3; a3 = a2; a2 = a1; a1 = cur.a;
+        r4c = r3c; r3c = r2c; r2c = r1c; r1c = cur.r;
+        p0a = cur.p1; p0b = cur.p2;
+        up12 = cur.p1.y; up22 = cur.p2.y;
+        pA2a = pA1a; pA2b = pA1b; pA1a = pAna; pA1b = pAnb;
+        uB2 = uB1; uB1 = uB0;
+        pB2a = pB1a; pB2b = pB1b; pB1a = pBna; pB1b = pBnb;
+        uC1 = uC0;
+        cur = nxt;
+        off += row2;
+        so += row2;
+    };
+    for (int y = ys; y <= ylast; y++) step(y);
+    loop_accumulate(err, slot0, accA, gw);
+    if (CNT >= 2) loop_accumulate(err, slot0 + slot_step, accB, gw);
+    if (CNT == 3) loop_accumulate(err, slot0 + 2 * slot_step, accC, gw);
+}
+
+// Launch unit j = iterations [3 j, 3 j + 3) (k0 = 3 j): same interface as k_tvl1_tile -- `check`: the stopping test on the three
+// error slots before k0; `nit`: iterations to run, 4 bits per pair (3 for a unit; 1 | 2 for a redo or a tail, whose errors all go
+// into slot0); pairs whose bit of runmask is clear are skipped.
+template <typename T, bool NT, bool STRICT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFX_ITER3_WAVES, OFX_ITER3_WAVES))) void k_tvl1_iter3(
+    Tri<typename Pix<T>::v2> Ut, Tri<typename Pix<T>::v2> P1t, Tri<typename Pix<T>::v2> P2t,
+    const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int k0, int check, int slot0,
+    int nx, int ny, int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2, unsigned incode,
+    unsigned runmask, unsigned long long nit, int err_stride)
+{
+    using v2 = typename Pix<T>::v2;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = blockIdx.y;
+    if (!((runmask >> g) & 1u)) return;
+    const int niter = (int) ((nit >> (4 * g)) & 15ull);
+    const size_t npix = (size_t) nx * ny;
+    const TriSel<v2> hu = pick3(Ut, incode, g, npix), h1 = pick3(P1t, incode, g, npix), h2 = pick3(P2t, incode, g, npix);
+    const v2 *__restrict__ Uin = hu.in, *__restrict__ P1in = h1.in, *__restrict__ P2in = h2.in;
+    const v2 *__restrict__ A = Ag + (size_t) g * npix;
+    const T *__restrict__ R = Rg + (size_t) g * npix;
+    double *__restrict__ err = errg + (size_t) g * err_stride;
+    double prev[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) prev[i] = (check && k0 - i > 0) ? loop_fetch_prev(err, k0 - i) : 0.0;
+
+    const int band = gw / strips_pad, strip = gw % strips_pad;
+    const int y0 = band * rows;
+    const bool idle = (strip >= strips_x) || (y0 >= ny);
+    const int yend = (y0 + rows < ny) ? y0 + rows : ny;     // rows [y0, yend) are written by this wave
+    const int ys = y0 > 2 ? y0 - 2 : 0;                      // first row loaded
+    const int yl = (yend + 2 < ny - 1) ? yend + 2 : ny - 1;  // last row loaded
+    const int c = strip * STRIP3_OUT - 3 + lane;            // lanes 0..2 / 61..63 are halo columns
+    const int cc = c < 0 ? 0 : (c > nx - 1 ? nx - 1 : c);
+    const bool lef = (c == 0), rig = (c == nx - 1);
+    const bool owner = (lane >= 3) && (lane <= STRIP3_OUT + 2) && (c < nx);
+    const unsigned E2 = 2 * sizeof(T);
+    const unsigned row2 = (unsigned) nx * E2;
+    const unsigned off = ((unsigned) ys * nx + cc) * E2;    // byte offset of (y, cc): loads
+    const unsigned so = ((unsigned) ys * nx + (c < 0 ? 0 : c)) * E2;   // ... of (y, c): stores (owner lanes only)
+    double up12 = 0.0, up22 = 0.0;                           // p12 / p22 (iteration k0-1) of row ys-1
+    RowIn<T> cur;
+    if (!idle) {
+        if (ys > 0) {
+            up12 = ldw2(at(P1in, off - row2)).y;
+            up22 = ldw2(at(P2in, off - row2)).y;
+        }
+        cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off);
+    }
+    if (check) {                                            // stopping test of src/tvl1flow.cpp:113 -- the same decision in every wave
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (k0 - i > 0 && !(loop_error_from_sum(wave_allreduce_sum(prev[i]), nx * ny, OFX_CRIT_MEAN) > eps2)) return;
+    }
+    if (idle) return;
+    const int step = check ? 1 : 0;                         // a redo's errors all go into its one scratch slot
+    if (niter >= 3)
+        tvl1_iter3_march<T, NT, STRICT, 3>(Uin, P1in, P2in, A, R, hu.out, h1.out, h2.out, err, slot0, step, gw, nx, ny, y0, yend, ys, yl,
+                                           lef, rig, owner, off, so, up12, up22, cur, l_t, theta, taut);
+    else if (niter == 2)
+        tvl1_iter3_march<T, NT, STRICT, 2>(Uin, P1in, P2in, A, R, hu.out, h1.out, h2.out, err, slot0, step, gw, nx, ny, y0, yend, ys, yl,
+                                           lef, rig, owner, off, so, up12, up22, cur, l_t, theta, taut);
+    else
+        tvl1_iter3_march<T, NT, STRICT, 1>(Uin, P1in, P2in, A, R, hu.out, h1.out, h2.out, err, slot0, step, gw, nx, ny, y0, yend, ys, yl,
+                                           lef, rig, owner, off, so, up12, up22, cur, l_t, theta, taut);
+}
+
 // ---- K iterations per launch on a 2-D tile: the small pyramid levels ---------------------------------------------------
 // On a level of a few thousand pixels a launch of the marching kernels is a latency chain: a strip of r rows takes r + 5
 // dependent marching steps of ~2.4 us while most of the chip idles (120x68: 6 us per iteration).  Here the rows are spread
@@ -634,7 +839,7 @@ __global__ __launch_bounds__(64 * TILE_RH) void k_tvl1_tile(
     }
 #pragma unroll
     for (int it = 0; it < K; it++)
-        if (it < niter) loop_accumulate(err, slot0 + it, acc[it], blockIdx.x * TILE_RH + w);
+        if (it < niter) loop_accumulate(err, slot0 + (check ? it : 0), acc[it], blockIdx.x * TILE_RH + w);   // a redo (check = 0): one scratch slot
 }
 
 // Warp + linearisation (src/tvl1flow.cpp:94-109): the three bicubic warps of I1, I1x, I1y share one
@@ -955,12 +1160,47 @@ struct Tvl1Params;
 template <typename T>
 static int tvl1_run_iterations_tile(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, LoopSpec S, int K, int *n_out,
                                     double *err_out, float *ms_out, int *alt_out);
+template <typename T>
+static int tvl1_run_iterations_tri(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, LoopSpec S, int *n_out, double *err_out,
+                                   float *ms_out, int *alt_out);
+
+// strip height of the three-iteration kernel: tvl1_pick_rows2's model with r + 7 marching steps per strip
+static int tvl1_pick_rows3(const ofx_ctx *ctx, int nx, int ny, int G)
+{
+    if (ctx->rows_per_wave3 > 0) return ctx->rows_per_wave3;
+    const long strips_pad = (long) ofx_cdiv(ofx_cdiv(nx, STRIP3_OUT), 4) * 4 * G;
+    const int rmax = 32;
+    int best = rmax;
+    long best_cost = -1;
+    if (ctx->concurrency > 1) {
+        static const int cand[] = {2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32};
+        for (int r : cand) {
+            const long waves = strips_pad * ofx_cdiv(ny, r);
+            const long slots = ctx->rows_slots > 0 ? ctx->rows_slots : 1024;
+            const long cost = ((waves + slots - 1) / slots) * (r + 7);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
+        }
+        return best;
+    }
+    const long slots = 1024L * OFX_ITER3_WAVES;
+    for (int k = 1; k <= 4; k++) {
+        for (int r = 1; r <= rmax; r++) {
+            if (strips_pad * ofx_cdiv(ny, r) > k * slots) continue;
+            const long cost = (long) k * (r + 7);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
+            break;
+        }
+    }
+    if (best < 4 && strips_pad * ofx_cdiv(ny, 4) >= 512) best = 4;
+    return best;
+}
 
 // The inner loop of one warp (src/tvl1flow.cpp:111-182) for all pairs of the group in lockstep.  On return
 // L.cur points at the halves holding the results; n_out[g] / err_out[g] are what the reference prints.
 template <typename T>
 static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, int *n_out, double *err_out,
-                               float *ms_out, int *alt_out = nullptr)     // alt_out[g]: 0 even stop, 1 odd + recomputed, 2 odd + stored
+                               float *ms_out, int *alt_out = nullptr,     // alt_out[g]: 0 stop at the end of a launch unit, 1 inside + recomputed, 2 inside + stored
+                               int *unit_out = nullptr)                   // iterations per launch unit of the kernel that ran
 {
     const int nx = L.nx, ny = L.ny, G = L.G;
     if ((long long) nx * ny >= (1LL << 27)) return ofx_fail(ctx, OFX_ERR_ARG, "tvl1: image larger than 2^27 pixels");
@@ -985,7 +1225,25 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
     S.pairs = pairs;
     // small levels: K iterations per launch on 2-D tiles (k_tvl1_tile) instead of the marching strips
     const int tileK = tvl1_pick_tile(ctx, nx, ny, G);
+    if (unit_out) *unit_out = tileK ? tileK : (pairs ? 2 : 1);
     if (tileK) return tvl1_run_iterations_tile<T>(ctx, L, P, S, tileK, n_out, err_out, ms_out, alt_out);
+    // Three iterations per launch (k_tvl1_iter3; option "fuse3": 0 never, 1 on every level of at least fuse3_min_px pixels x
+    // pairs, 2 = by measurement, the default).  Measured on one box, interleaved (profiles/r03_q_ab_three_iterations_per_launch.txt):
+    // the tolerance mode's job 55.8k -> 61.8k Mpix*warp-iters/s, fixed work 79.8k -> 103.7k; the strict mode, bound by FP64 issue
+    // and not by its streams, LOSES 14 % (more halo arithmetic), and a lone pair gains nothing (its launches are latency chains
+    // of r + 7 instead of r + 5 marching steps): so 2 = not strict, pairs in lockstep or contexts sharing the device, and a level
+    // of at least 500 000 pixels x pairs.
+    {
+        const bool strict_mode = sizeof(T) == sizeof(double) && !ctx->relaxed_dual;
+        const double px = (double) nx * ny * G;
+        const bool tri = ctx->fuse3 == 1 ? px >= ctx->fuse3_min_px
+                                         : (ctx->fuse3 == 2 && !strict_mode && (G >= 2 || ctx->concurrency > 1) &&
+                                            px >= (ctx->fuse3_min_px > 0 ? ctx->fuse3_min_px : 5e5));
+        if (pairs && tri) {
+            if (unit_out) *unit_out = 3;
+            return tvl1_run_iterations_tri<T>(ctx, L, P, S, n_out, err_out, ms_out, alt_out);
+        }
+    }
     const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
     const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
     // one launch touches 15 storage elements per pixel; beyond the Infinity Cache its output is streamed out
@@ -1126,6 +1384,71 @@ static int tvl1_run_iterations_tile(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Par
     return OFX_OK;
 }
 
+// tvl1_run_iterations through k_tvl1_iter3: launch unit j = iterations [3 j, 3 j + 3) reads buffer (b_g + j) % 3 and writes
+// (b_g + j + 1) % 3; a loop that ends inside a unit is finished by one more launch that re-runs the unit's first n - 3 j
+// iterations from its input (every pair with its own count) -- the scheme of the tile kernel.
+template <typename T>
+static int tvl1_run_iterations_tri(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, LoopSpec S, int *n_out, double *err_out,
+                                   float *ms_out, int *alt_out)
+{
+    const int nx = L.nx, ny = L.ny, G = L.G;
+    const double l_t = P.lambda * P.theta, taut = P.tau / P.theta, theta = P.theta;
+    const bool strict = sizeof(T) == sizeof(double) && !ctx->relaxed_dual;
+    const int rows = tvl1_pick_rows3(ctx, nx, ny, G);
+    const int strips_x = ofx_cdiv(nx, STRIP3_OUT), strips_pad = ofx_cdiv(strips_x, 4) * 4;
+    const dim3 grid((unsigned) (strips_pad / 4) * ofx_cdiv(ny, rows), G), block(256);
+    const bool nt_stores = ctx->nt_stores ? ctx->nt_stores == 1 : (double) nx * ny * G * 15.0 * sizeof(T) > 300e6;
+    S.pairs = false;
+    S.fuse = 3;
+    S.afac = 0.0;
+    const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
+    const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
+    unsigned b0[OFX_MAX_GROUP];
+    for (int g = 0; g < G; g++) b0[g] = L.curidx(g);
+    auto go = [&](int k0, int check, int slot0, double thr, unsigned incode, unsigned runmask, unsigned long long nit) -> int {
+        auto kern = nt_stores ? k_tvl1_iter3<T, true, false> : k_tvl1_iter3<T, false, false>;
+        if constexpr (sizeof(T) == sizeof(double)) {
+            if (strict) kern = nt_stores ? k_tvl1_iter3<T, true, true> : k_tvl1_iter3<T, false, true>;
+        }
+        hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A, (const T *) L.R, ctx->d_err, k0, check,
+                           slot0, nx, ny, rows, strips_x, strips_pad, l_t, theta, taut, thr, incode, runmask, nit, err_stride);
+        OFX_LAUNCH_CHECK(ctx);
+        return OFX_OK;
+    };
+    auto launch = [&](int k, int cnt, double thr) -> int {
+        unsigned incode = 0;
+        unsigned long long nit = 0;
+        for (int g = 0; g < G; g++) {
+            incode |= ((b0[g] + (unsigned) (k / 3)) % 3u) << (2 * g);
+            nit |= (unsigned long long) cnt << (4 * g);
+        }
+        return go(k, 1, k, thr, incode, all, nit);
+    };
+    auto redo = [&](const int *k_of) -> int {
+        unsigned incode = 0, runmask = 0;
+        unsigned long long nit = 0;
+        for (int g = 0; g < G; g++) {
+            if (k_of[g] < 0) continue;
+            const int n = k_of[g] + 1, j = (n - 1) / 3;
+            runmask |= 1u << g;
+            incode |= ((b0[g] + (unsigned) j) % 3u) << (2 * g);
+            nit |= (unsigned long long) (n - j * 3) << (4 * g);
+        }
+        return go(0, 0, S.max_iter, -1.0, incode, runmask, nit);     // no stopping test; errors into the scratch slot
+    };
+    int took_alt[OFX_MAX_GROUP];
+    OFX_TRY(ofx_run_loop_group(ctx, S, G, launch, redo, n_out, err_out, ms_out, 0u, took_alt));
+    unsigned cur = 0;
+    for (int g = 0; g < G; g++) {
+        const unsigned units = (unsigned) ((n_out[g] + 2) / 3);
+        cur |= ((b0[g] + units) % 3u) << (2 * g);
+        L.last_n[g] = n_out[g];
+        if (alt_out) alt_out[g] = (n_out[g] % 3 != 0 && n_out[g] != S.max_iter) ? 1 : 0;    // ended inside a unit: its first iterations were re-run
+    }
+    L.cur = cur;
+    return OFX_OK;
+}
+
 // src/tvl1flow.cpp:46-212 on device-resident level data; L.U[half of L.cur] holds the incoming flows.
 // stats[g] = work record of pair g.
 template <typename T>
@@ -1159,14 +1482,15 @@ static int tvl1_single_scale_dev(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params
         int it[OFX_MAX_GROUP];
         double error[OFX_MAX_GROUP];
         float ms = 0.f;
-        int odd[OFX_MAX_GROUP];
-        OFX_TRY(tvl1_run_iterations<T>(ctx, L, P, it, error, ctx->profile ? &ms : nullptr, odd));
+        int odd[OFX_MAX_GROUP], unit = 0;
+        OFX_TRY(tvl1_run_iterations<T>(ctx, L, P, it, error, ctx->profile ? &ms : nullptr, odd, &unit));
         if (P.verbose && G == 1) fprintf(stderr, "Warping: %d, Iterations: %d, Error: %f\n", w, it[0], error[0]);   // :184-188
         for (int g = 0; g < G; g++) {
             ofx_stats &S = stats[g];
             S.odd_stops += odd[g] != 0;
             S.odd_stops_stored += odd[g] == 2;
             if (scale < OFX_MAX_SCALES) {
+                S.fused[scale] = unit;
                 if (w < OFX_MAX_SOLVES) { S.iters[scale][w] = it[g]; S.error[scale][w] = error[g]; }
                 S.iter_ms[scale] += ms;
                 S.iter_launches[scale] += it[g];

@@ -21,15 +21,22 @@ FULL_SIZE_ONLY_DEFAULT = ("test_full_size", "test_4k_size", "test_headline_launc
                           "test_batch_dev_on_four_contexts", "test_f32_mode_is_as_accurate", "test_tile_kernel")
 
 
-@pytest.fixture(autouse=True, params=[0, 4], ids=["strips", "tile4"])
+@pytest.fixture(autouse=True, params=[0, 4, -3], ids=["strips", "tile4", "fuse3"])
 def tile_mode(request, gpu64, gpu32):
-    if request.param != 0 and request.node.name.startswith(FULL_SIZE_ONLY_DEFAULT):
-        pytest.skip("full-size case: default tile setting only")
+    """which iteration kernel: the marching strips with two iterations per launch (default), the 2-D tile kernel (tile = 4), the
+    marching strips with three iterations per launch (fuse3 = 1)"""
+    if request.node.name.startswith(FULL_SIZE_ONLY_DEFAULT):
+        if request.param != 0:
+            pytest.skip("full-size case: default kernel choice only")
+        yield 0                                              # the library's own choice (fuse3 = 2: by mode and group size)
+        return
     for c in (gpu64, gpu32):
-        c.set_option("tile", request.param)
+        c.set_option("tile", request.param if request.param > 0 else 0)
+        c.set_option("fuse3", 1 if request.param == -3 else 0)
     yield request.param
     for c in (gpu64, gpu32):
         c.set_option("tile", 0)
+        c.set_option("fuse3", 2)
 
 
 def linearised_state(orc, synth, nx, ny, seed=0):
@@ -442,6 +449,38 @@ def test_headline_launch_shape_1080p_group_of_5(gpu64, oracle_mod, synth):
         o.set_num_threads(1)
     assert np.array_equal(st[0].iterations(), it_o)
     assert np.array_equal(flo[0].cpu().numpy(), np.stack([uo, vo], axis=-1).astype(np.float32))
+
+
+@pytest.mark.timeout(900)
+def test_headline_launch_shape_tolerance_mode_three_iterations_per_launch(gpu64, orc, synth):
+    """What bench.py's headline times since round 3: 1920x1080, lockstep group of 5, the f64 tolerance mode, for which the
+    library picks k_tvl1_iter3 (three iterations per launch, non-temporal stores) on the levels of >= 500 000 pixels x pairs.
+    The pair solved alone runs the two-iteration kernel: every payload and iteration table must be equal bit for bit (same
+    per-pixel functions; the stop inside a launch unit is finished by re-running the unit's first iterations), pair 0 stays
+    within north_star's tolerance of the strict result -- and the 4K group of 4 (roofline_4k's launch) likewise."""
+    import torch
+    gpu64.set_option("relaxed_dual", 1)
+    try:
+        for nx, ny, G, warps in ((1920, 1080, 5, 5), (3840, 2160, 4, 2)):
+            kw = dict(nscales=5, warps=warps, **PAR)
+            dev = torch.device("cuda")
+            pairs = [synth.pair_device("P1", nx, ny, k, dev) for k in range(G)]
+            d0, d1 = [p[0] for p in pairs], [p[1] for p in pairs]
+            flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            gpu64.set_option("fuse3", 2)
+            st = gpu64.tvl1_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1], [flo[k].data_ptr() for k in range(G)],
+                                      nx, ny, **kw)
+            gpu64.synchronize()
+            gpu64.set_option("fuse3", 0)                       # the reference for the comparison: two iterations per launch
+            solo, its = _solo_flows(gpu64, d0, d1, nx, ny, **kw)
+            assert torch.equal(flo.view(torch.int32), solo.view(torch.int32)), (nx, ny)
+            for k in range(G):
+                assert np.array_equal(st[k].iterations(), its[k]), (nx, ny, k)
+            del pairs, d0, d1, flo, solo
+    finally:
+        gpu64.set_option("relaxed_dual", 0)
+        gpu64.set_option("fuse3", 2)
 
 
 @pytest.mark.timeout(900)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Driver for PMC passes on the iteration kernel AS THE JOB LAUNCHES IT: one fixed-work solve (1 scale, 1 warp = 150 launches of
-k_tvl1_iter2, two iterations each) of a lockstep group of G pairs at one size.   usage: pmc_group.py 1920x1080 G=16 [--f32] [relaxed=1]"""
+k_tvl1_iter2, two iterations each -- or 100 of k_tvl1_iter3, which the library picks for lockstep groups in tolerance mode unless
+fuse3=0) of a lockstep group of G pairs at one size.   usage: pmc_group.py 1920x1080 G=16 [--f32] [relaxed=1] [fuse3=0|1|2]"""
 import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +18,8 @@ for a in sys.argv[1:]:
         nt = int(a[3:])
     if a.startswith("relaxed="):
         relaxed = int(a[8:])
+    if a.startswith("fuse3="):
+        fuse3 = int(a[6:])
 dev = torch.device("cuda:0")
 ctx = ofx.Ofx(0, prec)
 I0, I1, out = [], [], []
@@ -28,6 +31,7 @@ if "nt" in dir():
     ctx.set_option("nt_stores", nt)
 if "relaxed" in dir():
     ctx.set_option("relaxed_dual", relaxed)
+ctx.set_option("fuse3", fuse3 if "fuse3" in dir() else 0)
 ctx.set_option("fixed_work", 1)
 ctx.tvl1_group_dev([t.data_ptr() for t in I0], [t.data_ptr() for t in I1], [t.data_ptr() for t in out], nx, ny, nscales=1, warps=1)
 ctx.synchronize()

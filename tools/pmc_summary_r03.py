@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_summary_r03.py <dir of tools/pmc_round3.sh>: per (size, group, mode) the HBM-side bytes per launch of k_tvl1_iter2
+"""tools/pmc_summary_r03.py <dir of tools/pmc_round3.sh>: per (size, group, mode) the HBM-side bytes per launch of k_tvl1_iter2 / k_tvl1_iter3
 (FETCH_SIZE doubled -- gfx950 tallies a wide coalesced read at half its bytes, MI355X_MICROARCH.md "HBM" -- WRITE_SIZE as
 reported, both in KiB), the rate at the launch time of the counter pass, VALU activity, and the rocprofv3 --stats average of
 the same launches.  Prints one JSON object (committed as profiles/r03_pmc_group_launches.json)."""
@@ -15,8 +15,8 @@ def newest(pat):
 out = {"note": __doc__.split("Prints")[0].strip()}
 for sz, G in (("1920x1080", 5), ("3840x2160", 4)):
     nx, ny = map(int, sz.split("x"))
-    for m, mode in ((0, "strict"), (1, "tolerance")):
-        tag = "%s_g%d_m%d" % (sz, G, m)
+    for m, mode, kern in ((0, "strict", "k_tvl1_iter2"), (1, "tolerance", "k_tvl1_iter2"), (1, "tolerance", "k_tvl1_iter3")):
+        tag = "%s_g%d_m%d%s" % (sz, G, m, "i3" if kern.endswith("3") else "")
         vals = {}
         for kind in ("fetch", "write", "sq"):
             cc = newest(os.path.join(src, "%s_%s" % (kind, tag), "**", "*_counter_collection.csv"))
@@ -25,11 +25,11 @@ for sz, G in (("1920x1080", 5), ("3840x2160", 4)):
                 continue
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(cc)):
-                if "k_tvl1_iter2" in r["Kernel_Name"]:
+                if kern in r["Kernel_Name"]:
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             for k, v in acc.items():
                 vals[k] = sum(v) / len(v)
-            d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt)) if "k_tvl1_iter2" in r["Kernel_Name"]]
+            d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt)) if kern in r["Kernel_Name"]]
             vals["launch_us_" + kind] = sum(d) / len(d)
         if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
             continue
@@ -52,11 +52,13 @@ for sz, G in (("1920x1080", 5), ("3840x2160", 4)):
         st = newest(os.path.join(src, "stats_" + tag, "**", "*_kernel_stats.csv"))
         if st:
             for r in csv.DictReader(open(st)):
-                if "k_tvl1_iter2" in r["Name"]:
+                if kern in r["Name"]:
                     rec["rocprofv3_stats_avg_us"] = float(r["AverageNs"]) / 1e3
                     rec["rocprofv3_stats_calls"] = int(r["Calls"])
                     rec["achieved_gbs_fused_compulsory"] = comp / (float(r["AverageNs"]) * 1e-9) / 1e9
                     rec["frac_of_8tbs"] = rec["achieved_gbs_fused_compulsory"] / 8000.0
                     break
-        out["%s_group%d_%s" % (sz, G, mode)] = rec
+        rec["kernel"] = kern
+        rec["iterations_per_launch"] = 3 if kern.endswith("3") else 2
+        out["%s_group%d_%s%s" % (sz, G, mode, "_iter3" if kern.endswith("3") else "")] = rec
 print(json.dumps(out, indent=1))
