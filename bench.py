@@ -359,16 +359,17 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None, mode="str
 def sor_leg(ofx_mod, synth, local, dev):
     """BASELINE configs 3 and 4 (parity-test cases, not the headline): exact-order Horn-Schunck 1920x1080 and Brox
     1280x720.  `one_pair`: one solve through the host entry point (the reference's calling convention, host arrays in /
-    out).  `batch`: 32 device-resident pairs (P0 + 31 P1 variants) through ofx_hs_batch_dev / ofx_brox_batch_dev, lockstep
-    groups of 16 pairs on 2 contexts; every flow is bit-identical to the pair solved alone (tests/test_gpu_sor.py).
+    out).  `batch`: 48 device-resident pairs (P0 + 47 P1 variants) through ofx_hs_batch_dev / ofx_brox_batch_dev, lockstep
+    groups of 16 pairs on 3 contexts (measured: 2 x 16 28.8k / 22.7k, 3 x 16 35.1k / 27.5k, 4 x 16 27.0k / 23.9k Mpix*sweeps/s,
+    profiles/r03_u_sor_batches_contexts_x_groups.txt); every flow is bit-identical to the pair solved alone (tests/test_gpu_sor.py).
     Algorithmic bytes per sweep: 56 B/px (HS), 80 B/px (Brox) -- SURVEY 8(d)."""
     import torch
     out = {}
     solo = ofx_mod.Ofx(local, ofx_mod.F64)
-    ctxs = [ofx_mod.Ofx(local, ofx_mod.F64) for _ in range(2)]
+    ctxs = [ofx_mod.Ofx(local, ofx_mod.F64) for _ in range(3)]
     for c in ctxs:
         c.set_option("lockstep", 16)
-    NB = 32
+    NB = 48
     for name, host_fn, batch_fn, size, bpp, kw in (
             ("hs_cfg3", solo.hs_pyramidal, ofx_mod.hs_batch_dev, (1920, 1080), 56.0,
              dict(alpha=20.0, nscales=5, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150)),
@@ -400,8 +401,8 @@ def sor_leg(ofx_mod, synth, local, dev):
         out[name] = {"size": "%dx%d" % size, "bytes_per_pixel_sweep": bpp,
                      "mode": "exact (reference sweep order, bit-identical to the reference)",
                      "one_pair": one,
-                     "batch": rec(sum(work), dt, {"pairs": NB, "contexts": 2, "lockstep_group": 16, "ms_per_pair": round(dt / NB * 1e3, 2),
-                                                  "pairs_desc": "P0 + 31 P1 variants, device-resident"})}
+                     "batch": rec(sum(work), dt, {"pairs": NB, "contexts": len(ctxs), "lockstep_group": 16, "ms_per_pair": round(dt / NB * 1e3, 2),
+                                                  "pairs_desc": "P0 + 47 P1 variants, device-resident"})}
         del ins, flo
     for c in ctxs + [solo]:
         c.close()

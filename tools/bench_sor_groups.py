@@ -25,6 +25,7 @@ for a in sys.argv[1:]:
         GRID = [tuple(int(x) for x in g.split("x")) for g in a.split("=")[1].split(",")]
 nowarm = "--no-warm" in sys.argv
 OPTS = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--opt=")]      # --opt=name=value for every context
+ODD = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--opt-odd=")]
 KW = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--kw=")]         # --kw=name=value overrides a solver parameter
 for name, (nx, ny), bpp, kw in CONFIGS:
     if only and name not in only:
@@ -40,9 +41,11 @@ for name, (nx, ny), bpp, kw in CONFIGS:
     fn = ofx.hs_batch_dev if name.startswith("hs") else ofx.brox_batch_dev
     for nctx, G in GRID:
         ctxs = [ofx.Ofx(0, ofx.F64) for _ in range(nctx)]
-        for c in ctxs:
+        for ci, c in enumerate(ctxs):
             c.set_option("lockstep", G)
             for o in OPTS:
+                c.set_option(o.split("=")[0], float(o.split("=")[1]))
+            for o in ODD if ci % 2 else []:                   # --opt-odd=name=value: only for every second context
                 c.set_option(o.split("=")[0], float(o.split("=")[1]))
         n = max(NPAIRS, nctx * G)
         args = ([t[0].data_ptr() for t in ins[:n]], [t[1].data_ptr() for t in ins[:n]], [flo[k].data_ptr() for k in range(n)], nx, ny)
