@@ -47,6 +47,15 @@ template <typename T> OFX_DEV double rnd_to(double x);
 template <> OFX_DEV double rnd_to<double>(double x) { return x; }
 template <> OFX_DEV double rnd_to<float>(double x) { return (double) (float) x; }
 
+// The wave index of the marching kernels: the same in every lane (256-thread blocks of four waves), but derived from threadIdx,
+// so the compiler takes it -- and the strip geometry, the row counter and every stage condition computed from it -- for
+// lane-varying: vector compares, exec-mask branches around every pipeline stage, the loop bounds in VGPRs.  readfirstlane
+// states the uniformity: scalar compares and branches, 13-15 fewer VGPRs.  (OFX_NO_RFL: the A/B build without it.)
+#ifdef OFX_NO_RFL
+#define OFX_WAVE_UNIFORM(x) (x)
+#else
+#define OFX_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 template <typename T> struct RowIn {
     double2 u, p1, p2, a;
     double r;
@@ -88,6 +97,9 @@ OFX_DEV double2 tvl1_primal(double2 u, double2 a, double r, double2 p1, double2 
 #ifdef OFX_CEIL_MEM   // ceiling experiment (tools/ceilings.sh): memory traffic and lane shifts kept, arithmetic replaced by a copy
     return make_double2(u.x + 1e-300 * (a.x + r + p1.x + l11 + up12), u.y + 1e-300 * (a.y + p2.x + p1.y + p2.y + l21 + up22));
 #endif
+    // (A variant with the interior divergence behind a wave-uniform test and the thresholding as selects -- fewer, longer basic
+    // blocks -- measured the same, profiles/r03_v_ab_wave_uniform_index.txt: the stalls of these kernels are the latencies of
+    // the dependent f64 chains, not their branches.)
     const double div1 = div_backward(p1.x, l11, p1.y, up12, lef, rig, top, bot);
     const double div2 = div_backward(p2.x, l21, p2.y, up22, lef, rig, top, bot);
     const double ix = a.x, iy = a.y;
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
 {
     using v2 = typename Pix<T>::v2;
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gw = OFX_WAVE_UNIFORM((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave index
     const int g = blockIdx.y;
     if (!((runmask >> g) & 1u)) return;
     const size_t npix = (size_t) nx * ny;
@@ -500,7 +512,7 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
 {
     using v2 = typename Pix<T>::v2;
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gw = OFX_WAVE_UNIFORM((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave index
     const int g = blockIdx.y;
     const size_t npix = (size_t) nx * ny;
     const TriSel<v2> hu = pick3(Ut, incode, g, npix), h1 = pick3(P1t, incode, g, npix), h2 = pick3(P2t, incode, g, npix);
@@ -609,10 +621,10 @@ OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const
             const double l21 = wave_shift_up(cur.p2.x);
             uA0 = tvl1_primal<T, STRICT>(cur.u, cur.a, cur.r, cur.p1, cur.p2, l11, l21, up12, up22, lef, rig, y == 0, y == nyl, l_t,
                                          theta);
-            if (owner && y >= y0 && y < yend) {
-                accA += (uA0.x - cur.u.x) * (uA0.x - cur.u.x) + (uA0.y - cur.u.y) * (uA0.y - cur.u.y);
-                if (CNT == 1) { stu = so; su = uA0; }
-            }
+            const bool mine = owner && y >= y0 && y < yend;
+            const double dA = (uA0.x - cur.u.x) * (uA0.x - cur.u.x) + (uA0.y - cur.u.y) * (uA0.y - cur.u.y);
+            accA += mine ? dA : 0.0;
+            if (CNT == 1 && mine) { stu = so; su = uA0; }
         }
         // S2: p_A(y-1)
         double2 pAna = z2, pAnb = z2;
@@ -632,10 +644,10 @@ OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const
                 const double l21 = wave_shift_up(pA1b.x);
                 uB0 = tvl1_primal<T, STRICT>(uA2, a2, r2c, pA1a, pA1b, l11, l21, pA2a.y, pA2b.y, lef, rig, y - 2 == 0, y - 2 == nyl,
                                              l_t, theta);
-                if (owner && y - 2 >= y0 && y - 2 < yend) {
-                    accB += (uB0.x - uA2.x) * (uB0.x - uA2.x) + (uB0.y - uA2.y) * (uB0.y - uA2.y);
-                    if (CNT == 2) { stu = so - 2 * row2; su = uB0; }
-                }
+                const bool mine = owner && y - 2 >= y0 && y - 2 < yend;
+                const double dB = (uB0.x - uA2.x) * (uB0.x - uA2.x) + (uB0.y - uA2.y) * (uB0.y - uA2.y);
+                accB += mine ? dB : 0.0;
+                if (CNT == 2 && mine) { stu = so - 2 * row2; su = uB0; }
             }
             // S4: p_B(y-3)
             if (y - 3 >= yB0 && y - 3 <= hiB) {
@@ -654,10 +666,11 @@ OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const
                 const double l21 = wave_shift_up(pB1b.x);
                 uC0 = tvl1_primal<T, STRICT>(uB2, a4, r4c, pB1a, pB1b, l11, l21, pB2a.y, pB2b.y, lef, rig, y - 4 == 0, y - 4 == nyl,
                                              l_t, theta);
-                if (owner && y - 4 < yend) {
-                    accC += (uC0.x - uB2.x) * (uC0.x - uB2.x) + (uC0.y - uB2.y) * (uC0.y - uB2.y);
-                    stu = so - 4 * row2; su = uC0;
-                }
+                const bool mine = owner && y - 4 < yend;
+                const double dC = (uC0.x - uB2.x) * (uC0.x - uB2.x) + (uC0.y - uB2.y) * (uC0.y - uB2.y);
+                accC += mine ? dC : 0.0;
+                stu = mine ? so - 4 * row2 : stu;
+                su = uC0;
             }
             // S6: p_C(y-5)
             if (y - 5 >= y0 && y - 5 < yend) {
@@ -703,7 +716,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFX_ITER3_W
 {
     using v2 = typename Pix<T>::v2;
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gw = OFX_WAVE_UNIFORM((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave index
     const int g = blockIdx.y;
     if (!((runmask >> g) & 1u)) return;
     const int niter = (int) ((nit >> (4 * g)) & 15ull);
