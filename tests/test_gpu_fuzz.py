@@ -11,6 +11,18 @@ pytestmark = pytest.mark.gpu
 FUZZ_SEED = int(os.environ.get("OFX_FUZZ_SEED", "2026"))
 FUZZ_N = int(os.environ.get("OFX_FUZZ_N", "24"))
 FUZZ_SOR = int(os.environ.get("OFX_FUZZ_SOR", "4"))
+# library options for the whole soak, e.g. OFX_FUZZ_OPTS="fuse3=1" (three iterations per launch at every size), "rof_pipe=0,chi_fuse=0"
+FUZZ_OPTS = [o.split("=") for o in os.environ.get("OFX_FUZZ_OPTS", "").split(",") if "=" in o]
+FUZZ_DEFAULTS = {"fuse3": 2, "rof_pipe": 1, "chi_fuse": 1, "gauss_fused": 1, "tile": 0, "sor_lds": 1}
+
+
+@pytest.fixture(autouse=True)
+def soak_options(gpu64):
+    for name, value in FUZZ_OPTS:
+        gpu64.set_option(name, float(value))
+    yield
+    for name, _ in FUZZ_OPTS:
+        gpu64.set_option(name, FUZZ_DEFAULTS.get(name, 0))
 
 
 def cases(seed, n):
