@@ -123,6 +123,7 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         1 (default) = by measurement (LDS for lone Horn-Schunck solves).  Results do not depend on it.
  *   "rof_pipe"       1/0  TV-L1 with occlusions / Scalar_ROF_BoxCellCentered: all iterations of a call in flight, the sweep
  *                         of iteration s 120 positions behind the sweep of s - 1 (default 1); 0 = one iteration at a time
+ *   "rof_window"     steps per launch of the ROF box sweeps: 10 (default) or 24 (the round-2 geometry, 143 KB of LDS per workgroup)
  *   "chi_fuse"       1/0  Solver_wrt_chi: 5 iterations per launch on overlapping LDS tiles (default 1); 0 = two launches per
  *                         iteration.  Results do not depend on either.
  *   "gauss_fused"    1/0  pyramids of lockstep groups: row + column pass of the Gaussian in one launch (default 1)

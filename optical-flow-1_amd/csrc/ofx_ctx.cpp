@@ -77,6 +77,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->spin_us = 150;
     ctx->rows_slots = 0;
     ctx->rof_pipe = 1;
+    ctx->rof_window = 0;
     ctx->chi_fuse = 1;
     ctx->fuse3 = 2;
     ctx->fuse3_min_px = 0.0;
@@ -226,6 +227,11 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     }
     if (!strcmp(name, "rows_slots")) { ctx->rows_slots = (int) value; return OFX_OK; }
     if (!strcmp(name, "rof_pipe")) { ctx->rof_pipe = value != 0; return OFX_OK; }
+    if (!strcmp(name, "rof_window")) {
+        if (value != 0 && value != 24 && value != 10) return ofx_fail(ctx, OFX_ERR_ARG, "rof_window must be 0, 10 or 24");
+        ctx->rof_window = (int) value;
+        return OFX_OK;
+    }
     if (!strcmp(name, "chi_fuse")) { ctx->chi_fuse = value != 0; return OFX_OK; }
     if (!strcmp(name, "fuse3")) {
         if (value != 0 && value != 1 && value != 2) return ofx_fail(ctx, OFX_ERR_ARG, "fuse3 must be 0, 1 or 2");

@@ -75,6 +75,7 @@ struct ofx_ctx {
     double fuse3_min_px;
     int rows_per_wave3; // strip height of k_tvl1_iter3 (0 = tvl1_pick_rows3)
     int chi_fuse;       // Solver_wrt_chi: 1 = CHI_N iterations per launch on LDS tiles (default), 0 = two launches per iteration
+    int rof_window;     // steps per launch of the ROF box sweeps: 10 (default, also 0) | 24
     int rof_pipe;       // ROF box sweeps (ofx_occ.hip): 1 = all iterations of a call in flight (default), 0 = one at a time
     int rows_slots;     // strip-height model of the fused kernel when contexts share the device: waves per "round" (0 = 1024)
     int spin_us;        // convergence polls: microseconds the host spins on the pinned record before it falls back to

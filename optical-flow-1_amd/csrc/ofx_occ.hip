@@ -661,9 +661,22 @@ extern "C" int ofx_solver_wrt_chi(ofx_ctx *ctx, const double *u1, const double *
 #define ROF_LAGI 120
 #define ROF_D_1 (ROF_K + 2)
 #define ROF_LAGI_1 56
-#define ROF_RING (ROF_K + 7)         // positions q0 - 4 .. q1 + 2
-#define ROF_COEF (ROF_K + 3)         // positions q0 - 2 .. q1 + 1
-#define ROF_LDS_BYTES ((size_t) ROF_NT * (ROF_RING * sizeof(double2) + ROF_COEF * (sizeof(double2) + sizeof(double))))
+// The window length K is a template parameter of the kernel: ROF_KG = 10 steps (75 KB of LDS, two workgroups per CU) is what
+// runs; 24 steps (143 KB, one workgroup per CU; the round-2 geometry that the text above describes) remains as option
+// "rof_window" = 24.  Everything derived from K follows the same formulas (tools/check_rof_pipeline.py
+// checks both parameter sets): blocks K + 8 apart, alfa stage K + LAG + 2 (K + 2 for one row block) ahead of its sweep, sweeps
+// D + K + LAG + 6 (D + K + 6) apart.
+#define ROF_KG 10
+template <int K> struct RofGeo {
+    static constexpr int LAG = K + 8;
+    static constexpr int RING = K + 7;       // positions q0 - 4 .. q1 + 2
+    static constexpr int COEF = K + 3;       // positions q0 - 2 .. q1 + 1
+    static constexpr size_t LDS = (size_t) ROF_NT * (RING * sizeof(double2) + COEF * (sizeof(double2) + sizeof(double)));
+    static constexpr int D = K + LAG + 2, LAGI = D + K + LAG + 6;      // several row blocks
+    static constexpr int D1 = K + 2, LAGI1 = D1 + K + 6;               // one row block
+};
+static_assert(RofGeo<ROF_K>::LAG == ROF_LAG && RofGeo<ROF_K>::D == ROF_D && RofGeo<ROF_K>::LAGI == ROF_LAGI &&
+              RofGeo<ROF_K>::D1 == ROF_D_1 && RofGeo<ROF_K>::LAGI1 == ROF_LAGI_1, "the documented lags of the 24-step window");
 struct RofArr {                      // all arrays hyperplane-major; PP = (Ps, Pe) and FF = (Fs, Fe) per cell: one 16-byte access each
     double2 *PP;
     const double2 *FF;
@@ -851,10 +864,10 @@ OFX_DEV double rof_u_cell(const double2 *__restrict__ PP, const double *__restri
 // alfa stage of one row block: alfa of the cells of its rows at positions [p0, p0 + ROF_K) (k_rof_alfa's expression on
 // u recomputed from the pairs).  No dependence between cells: consecutive threads take consecutive rows of one position.
 OFX_DEV void rof_alfa_band(const RofArr &a, const double *__restrict__ LF, const double *__restrict__ LG, double *__restrict__ AL,
-                           int b, int p0, double lambda)
+                           int b, int p0, double lambda, int K)
 {
     const int nx = a.nx, ny = a.ny;
-    for (int idx = (int) threadIdx.x; idx < ROF_R * ROF_K; idx += ROF_THREADS) {
+    for (int idx = (int) threadIdx.x; idx < ROF_R * K; idx += ROF_THREADS) {
         const int ci = b * ROF_R + idx % ROF_R, p = p0 + idx / ROF_R;
         const int cj = p - 2 * ci;
         if (ci >= ny || cj < 0 || cj >= nx) continue;
@@ -865,8 +878,10 @@ OFX_DEV void rof_alfa_band(const RofArr &a, const double *__restrict__ LF, const
         AL[k] = sqrt(ux * ux + uy * uy) / LG[k];
     }
 }
+template <int K>
 __global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, double w, double lambda)
 {
+    constexpr int ROF_RING = RofGeo<K>::RING, ROF_COEF = RofGeo<K>::COEF, LAG = RofGeo<K>::LAG;
     extern __shared__ double2 rof_lds[];
     double2 (*win)[ROF_NT] = reinterpret_cast<double2 (*)[ROF_NT]>(rof_lds);
     double2 (*cff)[ROF_NT] = reinterpret_cast<double2 (*)[ROF_NT]>(rof_lds + ROF_RING * ROF_NT);
@@ -880,7 +895,7 @@ __global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, do
     a.PP += off; a.FF += off; a.AL += off;
     const int nx = a.nx, ny = a.ny;
     const int t = (int) threadIdx.x, row0 = b * ROF_R - 2;
-    const int q0 = T0 - ROF_LAG * b - s.lagi * it, q1 = q0 + ROF_K - 1;
+    const int q0 = T0 - LAG * b - s.lagi * it, q1 = q0 + K - 1;
     // positions at which the block's own rows have cells: outside them the unit has nothing to do (uniform over the workgroup)
     const int p_lo = 2 * b * ROF_R, p_hi = 2 * (min(b * ROF_R + ROF_R, ny) - 1) + nx - 1;
     // The alfa stage of (iteration, block) has workgroups of its own.  (Run as the head of the sweep's workgroup instead -- half
@@ -888,7 +903,7 @@ __global__ __launch_bounds__(ROF_THREADS) void k_rof_window(RofSet s, int T0, do
     // triple either way, and costs a lone solve 7 %: measured, dropped.)
     if (alfa_stage) {
         if (it == 0 || q0 + s.d > p_hi || q1 + s.d < p_lo) return;          // alfa of iteration 0 comes from the seed (k_rof_alfa)
-        rof_alfa_band(a, (prob ? s.LF[1] : s.LF[0]) + off, s.LG + off, (prob ? s.ALw[1] : s.ALw[0]) + off, b, q0 + s.d, lambda);
+        rof_alfa_band(a, (prob ? s.LF[1] : s.LF[0]) + off, s.LG + off, (prob ? s.ALw[1] : s.ALw[0]) + off, b, q0 + s.d, lambda, K);
         return;
     }
     if (q0 > p_hi || q1 < p_lo) return;
@@ -1026,6 +1041,47 @@ __global__ void k_rof_u(RofPt a, int nx, int ny, double lambda)
     a.uo[k][c] = lambda * a.f[k][c] + lambda * (own.x - pn + own.y - pw);
 }
 
+// the launches of one Scalar_ROF_BoxCellCentered call with windows of K steps (see rof_box_dev)
+template <int K>
+static int rof_box_windows(ofx_ctx *ctx, RofSet set, const RofPt &pt, const double *g, dim3 grid, dim3 block, int nc, int G, int B,
+                           int qmax, int n_iter, double omega, double lambda)
+{
+    using Geo = RofGeo<K>;
+    const int nx = set.a[0].nx, ny = set.a[0].ny;
+    set.lagi = B > 1 ? Geo::LAGI : Geo::LAGI1;
+    set.d = B > 1 ? Geo::D : Geo::D1;
+    static std::atomic<unsigned> lds_set(0);           // bit d: the attribute has been set on device d (per device, any thread; per K)
+    if (!(lds_set.load() & (1u << (ctx->device & 31)))) {
+        OFX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_rof_window<K>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int) Geo::LDS));
+        lds_set.fetch_or(1u << (ctx->device & 31));
+    }
+    if (ctx->rof_pipe) {
+        const long total = (long) qmax + 1 + (long) Geo::LAG * (B - 1) + (long) set.lagi * (n_iter - 1);
+        hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
+        for (long T0 = 0; T0 < total; T0 += K) {
+            // the grid covers iterations 0 .. it_hi (the last one whose alfa stage has reached position 0); units outside
+            // their range of positions leave at once
+            long it_hi = (T0 + K + set.d) / set.lagi;
+            if (it_hi > n_iter - 1) it_hi = n_iter - 1;
+            hipLaunchKernelGGL(k_rof_window<K>, dim3(2 * B, nc * (int) (it_hi + 1), G), dim3(ROF_THREADS), Geo::LDS, ctx->stream, set,
+                               (int) T0, omega, lambda);
+        }
+        hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, pt, nx, ny, lambda);
+        OFX_LAUNCH_CHECK(ctx);
+        return OFX_OK;
+    }
+    const long total = (long) qmax + 1 + (long) Geo::LAG * (B - 1);
+    for (int it = 0; it < n_iter; it++) {
+        hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
+        for (long T0 = 0; T0 < total; T0 += K)
+            hipLaunchKernelGGL(k_rof_window<K>, dim3(B, nc, G), dim3(ROF_THREADS), Geo::LDS, ctx->stream, set, (int) T0, omega, lambda);
+        hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, pt, nx, ny, lambda);
+        OFX_LAUNCH_CHECK(ctx);
+    }
+    return OFX_OK;
+}
+
 // nc = 1 | 2 independent problems sharing g, lambda and the size (the two flow components of Solver_wrt_u), every launch
 // serving both -- and all G sets of them (lockstep groups: set s on planes offset by s * nx * ny / s * rof_skew_elems(),
 // sets whose bit of `mask` is clear are left alone).  Device arrays in place: u[k] (in: seed, out: result; row-major),
@@ -1057,40 +1113,15 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
     }
     const int B = ofx_cdiv(ny, ROF_R), qmax = 2 * (ny - 1) + nx - 1;
     set.LG = LG; set.stride = n; set.mask = mask; set.nc = nc; set.B = B;
-    set.lagi = B > 1 ? ROF_LAGI : ROF_LAGI_1;
-    set.d = B > 1 ? ROF_D : ROF_D_1;
     pt.nc = nc; pt.rm_stride = nrm; pt.sk_stride = n; pt.mask = mask;
-    static std::atomic<unsigned> lds_set(0);           // bit d: the attribute has been set on device d (per device, any thread)
-    if (!(lds_set.load() & (1u << (ctx->device & 31)))) {
-        OFX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_rof_window), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int) ROF_LDS_BYTES));
-        lds_set.fetch_or(1u << (ctx->device & 31));
-    }
     if (n_iter < 1) return OFX_OK;
-    if (ctx->rof_pipe) {
-        const long total = (long) qmax + 1 + (long) ROF_LAG * (B - 1) + (long) set.lagi * (n_iter - 1);
-        hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
-        for (long T0 = 0; T0 < total; T0 += ROF_K) {
-            // the grid covers iterations 0 .. it_hi (the last one whose alfa stage has reached position 0); units outside
-            // their range of positions leave at once
-            long it_hi = (T0 + ROF_K + set.d) / set.lagi;
-            if (it_hi > n_iter - 1) it_hi = n_iter - 1;
-            hipLaunchKernelGGL(k_rof_window, dim3(2 * B, nc * (int) (it_hi + 1), G), dim3(ROF_THREADS), ROF_LDS_BYTES,
-                               ctx->stream, set, (int) T0, omega, lambda);
-        }
-        hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, pt, nx, ny, lambda);
-        OFX_LAUNCH_CHECK(ctx);
-        return OFX_OK;
-    }
-    const long total = (long) qmax + 1 + (long) ROF_LAG * (B - 1);
-    for (int it = 0; it < n_iter; it++) {
-        hipLaunchKernelGGL(k_rof_alfa, grid, block, 0, ctx->stream, pt, g, nx, ny, lambda);
-        for (long T0 = 0; T0 < total; T0 += ROF_K)
-            hipLaunchKernelGGL(k_rof_window, dim3(B, nc, G), dim3(ROF_THREADS), ROF_LDS_BYTES, ctx->stream, set, (int) T0, omega, lambda);
-        hipLaunchKernelGGL(k_rof_u, grid, block, 0, ctx->stream, pt, nx, ny, lambda);
-        OFX_LAUNCH_CHECK(ctx);
-    }
-    return OFX_OK;
+    // window length: option "rof_window" (24 | 10), else 24 steps for a lone solve and 10 for lockstep groups of 4 and more
+    // window length: 10 steps per launch unless option "rof_window" = 24.  Measured (profiles/r03_x_rof_window_length.txt; 6 / 8 / 10 /
+    // 12 / 16 / 24 steps): one 640x480 triple 21.7 / 21.4 / 21.4 / 22.3 / 23.2 / 26.0 ms, 320x240 12.9 / 12.7 / 12.9 / 13.4 / 14.2 /
+    // 16.2 ms -- with all iterations in flight the pipeline's depth (9 LAGI, LAGI ~ 4 K) outweighs the per-launch fill a long
+    // window amortises -- and batches of 32 5.1 ms per triple against 5.7 (two 75 KB windows per CU instead of one of 143 KB).
+    if (ctx->rof_window == ROF_K) return rof_box_windows<ROF_K>(ctx, set, pt, g, grid, block, nc, G, B, qmax, n_iter, omega, lambda);
+    return rof_box_windows<ROF_KG>(ctx, set, pt, g, grid, block, nc, G, B, qmax, n_iter, omega, lambda);
 }
 // host-facing state planes: upload both row-major planes, interleave; split, download.  tmp = 2 nx ny doubles
 static int rof_state_in(ofx_ctx *ctx, const double *hps, const double *hpe, double2 **dev, double *tmp, int nx, int ny)

@@ -13,16 +13,21 @@ pytestmark = pytest.mark.gpu
 # * ROF box sweeps: all iterations of a call in flight (option rof_pipe = 1, default: sweeps ROF_LAGI positions apart, alfa of
 #   the next iteration computed between the wavefronts) or one iteration at a time (0);
 # * Solver_wrt_chi: CHI_N iterations per launch on overlapping LDS tiles (chi_fuse = 1, default) or two launches per iteration (0).
-@pytest.fixture(autouse=True, params=[1, 0], ids=["pipelined", "serial"])
+# * window length of the sweeps (rof_window): 10 steps per launch (default; two LDS windows per CU), or the round-2 geometry
+#   of 24 steps in the "...24" runs.
+@pytest.fixture(autouse=True, params=[(1, 0), (1, 24), (0, 0), (0, 24)], ids=["pipelined", "pipelined24", "serial", "serial24"])
 def rof_schedule(request, gpu64):
-    if request.param == 0 and not request.node.name.startswith(("test_rof", "test_occlusion_solvers", "test_tvl1occ_multiscale",
-                                                                "test_tvl1occ_lockstep")):
+    pipe, window = request.param
+    if (pipe, window) != (1, 0) and not request.node.name.startswith(("test_rof", "test_occlusion_solvers", "test_tvl1occ_multiscale",
+                                                                      "test_tvl1occ_lockstep")):
         pytest.skip("does not reach the iterative solvers: once is enough")
-    gpu64.set_option("rof_pipe", request.param)
-    gpu64.set_option("chi_fuse", request.param)
+    gpu64.set_option("rof_pipe", pipe)
+    gpu64.set_option("chi_fuse", pipe)
+    gpu64.set_option("rof_window", window)
     yield request.param
     gpu64.set_option("rof_pipe", 1)
     gpu64.set_option("chi_fuse", 1)
+    gpu64.set_option("rof_window", 0)
 
 
 @pytest.mark.parametrize("ny,nx,nz", [(9, 13, 3), (40, 70, 3), (17, 8, 2), (6, 6, 1), (130, 97, 4)])

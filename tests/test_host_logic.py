@@ -202,6 +202,14 @@ def test_rof_iteration_pipeline_schedule():
     for nx, ny in [(40, 30), (160, 120), (9, 9), (2, 2), (3, 125), (125, 3)]:            # one row block: the shorter lags
         assert mod.violations(nx, ny, 125, 24, 32, 56, 26) == 0, (nx, ny)
     assert mod.violations(17, 260, 125, 24, 32, 56, 26) > 0                              # ... which several blocks do not allow
+    # the 10-step window of lockstep groups (RofGeo<10>): blocks 18 apart, D = 30 / 12, LAGI = 64 / 28
+    assert "#define ROF_KG 10" in src and "static constexpr int D = K + LAG + 2, LAGI = D + K + LAG + 6;" in src
+    assert "static constexpr int D1 = K + 2, LAGI1 = D1 + K + 6;" in src
+    for nx, ny, R in [(40, 30, 125), (17, 260, 125), (9, 9, 125), (33, 20, 7), (5, 40, 3)]:
+        assert mod.violations(nx, ny, R, 10, 18, 64, 30) == 0, (nx, ny, R)
+    for nx, ny in [(40, 30), (160, 120), (2, 2), (3, 125)]:
+        assert mod.violations(nx, ny, 125, 10, 18, 28, 12) == 0, (nx, ny)
+    assert mod.violations(33, 20, 7, 10, 18, 58, 30) > 0
     assert mod.violations(33, 20, 7, 24, 32, 112, 58) > 0 and mod.violations(33, 20, 7, 24, 32, 120, 50) > 0    # the checker does bite
 
 
