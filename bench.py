@@ -646,7 +646,10 @@ def main():
                                  [flo[i].data_ptr() for i in range(gsz)], nx, ny, **PAR)
         ctx.synchronize()
         odd = {"loops": gsz * PAR["nscales"] * PAR["warps"], "odd_stops": sum(s_.odd_stops for s_ in st_),
-               "served_from_stored_state": sum(s_.odd_stops_stored for s_ in st_)}
+               "served_from_stored_state": sum(s_.odd_stops_stored for s_ in st_),
+               "iterations_per_launch_by_level": [int(st_[0].fused[s_]) for s_ in range(PAR["nscales"])],
+               "note": "odd_stops = loops that ended inside a launch unit (2 or 3 fused iterations): the unit's first iterations are "
+                       "re-run from its input, or -- two-iteration units only -- taken from the stored intermediate state"}
 
     # ---- the other f64 mode on the same command (same pairs, same grouping, same repetitions) ---------------------------------
     other = None
