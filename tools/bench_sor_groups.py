@@ -34,7 +34,7 @@ for name, (nx, ny), bpp, kw in CONFIGS:
         k_, v_ = o.split("=")
         if k_ in kw:
             kw[k_] = type(kw[k_])(float(v_))
-    nmax = max(c * g for c, g in GRID)
+    nmax = max(NPAIRS, max(c * g for c, g in GRID))
     ins = [synth.pair_device("P0" if k == 0 else "P1", nx, ny, k, dev) for k in range(nmax)]
     flo = torch.empty((nmax, ny, nx, 2), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
