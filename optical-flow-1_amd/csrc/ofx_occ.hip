@@ -443,7 +443,9 @@ __global__ void k_occ_chi(OccChi a, int nx, int ny, double lambda, double theta,
 // two branches of F and G, beta div u -- are computed once per launch and stay in registers.  100 iterations = 20 launches
 // instead of 200; a small level is a chain of launch latencies, so that is most of its time.
 #define CHI_T 32
+#ifndef CHI_N
 #define CHI_N 5
+#endif
 #define CHI_IN (CHI_T - 2 * CHI_N)
 struct OccChiState {
     const double *chi, *eta1, *eta2;     // in
