@@ -420,11 +420,11 @@ def occ_leg(ofx_mod, synth, local):
     solo = ofx_mod.Ofx(local, ofx_mod.F64)
     ctxs = [ofx_mod.Ofx(local, ofx_mod.F64) for _ in range(2)]
     seq = synth.sequence(nx, ny, 3, 1)
-    solo.tvl1occ_multiscale(seq[0], seq[1], seq[2], **dict(kw, nscales=1, warps=1))      # warm (arena, clocks)
+    res = solo.tvl1occ_multiscale(seq[0], seq[1], seq[2], **kw)                          # warm (arena, clocks, result planes)
     reps = []
     for _ in range(3):
         t0 = time.perf_counter()
-        solo.tvl1occ_multiscale(seq[0], seq[1], seq[2], **kw)
+        solo.tvl1occ_multiscale(seq[0], seq[1], seq[2], out=res, **kw)
         reps.append(time.perf_counter() - t0)
     dt1 = sorted(reps)[1]                                                                # median of three
     st = solo.stats()

@@ -526,11 +526,13 @@ class Ofx:
         return u, P1, P2
 
     def tvl1occ_multiscale(self, I_1, I0, I1, filtI0=None, lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=3, zfactor=0.5,
-                           warps=2, epsilon=0.01, verbose=0):
-        """Dual_TVL1_optic_flow_multiscale with occlusions (src/tvl1occflow.h) -> (u1, u2, chi); stats() has the outer iterations"""
+                           warps=2, epsilon=0.01, verbose=0, out=None):
+        """Dual_TVL1_optic_flow_multiscale with occlusions (src/tvl1occflow.h) -> (u1, u2, chi); stats() has the outer iterations.
+        out = (u1, u2, chi): result planes to reuse (freshly allocated planes cost ~3 ms of page faults per 16 MB when the
+        library writes them -- a measuring artefact of a benchmark loop, not of the solve)"""
         ny, nx = I0.shape
         filtI0 = I0 if filtI0 is None else filtI0
-        u1, u2, chi = np.empty((ny, nx)), np.empty((ny, nx)), np.empty((ny, nx))
+        u1, u2, chi = out if out is not None else (np.empty((ny, nx)), np.empty((ny, nx)), np.empty((ny, nx)))
         self._ck(self.L.ofx_tvl1occ_multiscale(self.h, _f64(I_1), _f64(I0), _f64(I1), _f64(filtI0), u1, u2, chi, nx, ny, lam, alpha,
                                                beta, theta, nscales, zfactor, warps, epsilon, verbose))
         return u1, u2, chi
