@@ -196,14 +196,15 @@ def brox_batch_dev(ctxs, dI1, dI2, d_flo, nx, ny, alpha=50.0, gamma=10.0, nscale
     return _batch_call(lib().ofx_brox_batch_dev, ctxs, dI1, dI2, d_flo, nx, ny, alpha, gamma, nscales, nu, TOL, inner, outer)
 
 
-def tvl1occ_batch(ctxs, triples, lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=3, zfactor=0.5, warps=2, epsilon=0.01):
+def tvl1occ_batch(ctxs, triples, lam=0.15, alpha=0.01, beta=0.15, theta=0.3, nscales=3, zfactor=0.5, warps=2, epsilon=0.01, out=None):
     """ofx_tvl1occ_batch: triples = list of (I_1, I0, I1) or (I_1, I0, I1, filtI0) host images; lockstep groups of up to 16
     consecutive triples, group q on ctxs[q % len(ctxs)] (one host thread per context inside the library).  Returns a list of
-    (u1, u2, chi)."""
+    (u1, u2, chi); out = such a list from an earlier call: its planes are reused (fresh planes are first touched -- page
+    faults -- while the library writes them, which a benchmark loop would otherwise time)."""
     n = len(triples)
     ny, nx = triples[0][1].shape
     ins = [[_f64(t[k] if k < len(t) else t[1]) for t in triples] for k in range(4)]
-    outs = [[np.empty((ny, nx)) for _ in range(n)] for _ in range(3)]
+    outs = [[o[k] for o in out] for k in range(3)] if out is not None else [[np.empty((ny, nx)) for _ in range(n)] for _ in range(3)]
     ptr = lambda arrs: (_vp * n)(*[a.ctypes.data for a in arrs])
     s = lib().ofx_tvl1occ_batch((_vp * len(ctxs))(*[c.h.value for c in ctxs]), len(ctxs), n, *[ptr(a) for a in ins],
                                 *[ptr(a) for a in outs], nx, ny, lam, alpha, beta, theta, nscales, zfactor, warps, epsilon)

@@ -64,9 +64,9 @@ for size in a.size or ["320x240"]:
             for o in a.opt:
                 c_.set_option(o.split("=")[0], float(o.split("=")[1]))
         triples = [tuple(synth.sequence(nx, ny, 3, k + 1)) for k in range(n_tr)]
-        ofx.tvl1occ_batch(ctxs, triples[:n_ctx], **dict(kw, nscales=1, warps=1))                # warm every context
+        res_b = ofx.tvl1occ_batch(ctxs, triples, **kw)                                          # warm every context, arena, result planes
         t = time.perf_counter()
-        ofx.tvl1occ_batch(ctxs, triples, **kw)
+        ofx.tvl1occ_batch(ctxs, triples, out=res_b, **kw)
         bt = time.perf_counter() - t
         rec["batch"] = {"contexts": n_ctx, "triples": n_tr, "seconds": round(bt, 4), "s_per_triple": round(bt / n_tr, 4)}
     print(json.dumps(rec), flush=True)
