@@ -384,12 +384,16 @@ def sor_leg(ofx_mod, synth, local, dev):
             r.update(extra)
             return r
         I1, I2 = synth.pair("P0", nx, ny)
-        host_fn(I1, I2, **kw)                            # warm (arena, clocks)
-        t0 = time.perf_counter()
-        host_fn(I1, I2, **kw)
-        dt = time.perf_counter() - t0
+        res = host_fn(I1, I2, **kw)                      # warm (arena, clocks, result planes)
+        reps = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            host_fn(I1, I2, out=res, **kw)
+            reps.append(time.perf_counter() - t0)
+        dt = sorted(reps)[1]                             # median of three (single solves vary by ~10 % from run to run)
         st = solo.stats()
-        one = rec(st.work_pix_iters, dt, {"sweeps": int(st.iterations().sum()), "pair": "P0, host arrays in/out"})
+        one = rec(st.work_pix_iters, dt, {"sweeps": int(st.iterations().sum()), "pair": "P0, host arrays in/out",
+                                          "repetitions": [round(r_, 4) for r_ in reps]})
         ins = [synth.pair_device("P0" if k == 0 else "P1", nx, ny, k, dev) for k in range(NB)]
         flo = torch.empty((NB, ny, nx, 2), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()

@@ -408,16 +408,17 @@ class Ofx:
         self._ck(self.L.ofx_hs_single_scale(self.h, _f64(I1), _f64(I2), u, v, nx, ny, alpha, warps, TOL, maxiter, verbose))
         return u, v
 
-    def hs_pyramidal(self, I1, I2, alpha=7.0, nscales=10, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150, verbose=0):
+    def hs_pyramidal(self, I1, I2, alpha=7.0, nscales=10, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150, verbose=0, out=None):
+        """out = (u, v) planes to reuse (the library overwrites them; fresh planes are page-faulted while it does)"""
         ny, nx = I1.shape
-        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        u, v = out if out is not None else (np.zeros((ny, nx)), np.zeros((ny, nx)))
         self._ck(self.L.ofx_hs_pyramidal(self.h, _f64(I1), _f64(I2), u, v, nx, ny, alpha, nscales, zfactor, warps, TOL,
                                          maxiter, verbose))
         return u, v
 
-    def brox_spatial(self, I1, I2, alpha=50.0, gamma=10.0, nscales=10, nu=0.5, TOL=1e-4, inner=1, outer=15, verbose=0):
+    def brox_spatial(self, I1, I2, alpha=50.0, gamma=10.0, nscales=10, nu=0.5, TOL=1e-4, inner=1, outer=15, verbose=0, out=None):
         ny, nx = I1.shape
-        u, v = np.zeros((ny, nx)), np.zeros((ny, nx))
+        u, v = out if out is not None else (np.zeros((ny, nx)), np.zeros((ny, nx)))
         self._ck(self.L.ofx_brox_spatial(self.h, _f64(I1), _f64(I2), u, v, nx, ny, alpha, gamma, nscales, nu, TOL,
                                          inner, outer, verbose))
         return u, v

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 3 session 50: after the timing fixes (result planes reused): bench tests, the driver's command
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r03ax; mkdir -p $O
+cd $R
+timeout -k 10 900 python -m pytest tests/test_gpu_bench.py tests/test_gpu_occ.py tests/test_gpu_sor.py -m gpu -x -q > $O/tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 $O/tests.log
+[ $rc -ne 0 ] && exit 1
+timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; echo "bench rc=$?"
+python3 -c "
+import json; d=json.loads(open('$O/bench_driver.json').read().strip().splitlines()[-1])
+print('value', d['value'], d['config']['arithmetic_mode'], d['repetitions']['seconds'], 'strict', d['strict']['value'])
+print('single', d['single_pair']['device_resident']['ms_per_pair'], d['single_pair']['host_entry']['ms_per_pair'], 'fixed', d['fixed_work']['value'])
+print('sor', {k: (v['one_pair']['seconds'], v['batch']['ms_per_pair'], v['batch']['frac_of_hbm_peak']) for k, v in d['sor'].items()}); print('occ', d['occ']['one_triple'], d['occ']['batch'])"
