@@ -44,6 +44,15 @@ def test_bench_one_gpu_line_has_roofline_keys():
     # quoted on the launch as the job issues it (a lockstep group), with the one-pair launch beside it; bytes scale with the group
     assert r["pairs_per_launch"] > 1 and 0 < r["single_pair"]["frac"] <= 1.0
     assert abs(r["achieved"] * r["avg_launch_us"] * 1e3 - r["fused_algorithmic_bytes_per_launch"]) < 1e-3 * r["fused_algorithmic_bytes_per_launch"]
+    # the unit size is the one the library ran (stats.fused); the SURVEY 8(d) figure scales with it; a three-iteration launch
+    # carries the two-iteration launch of the same shape beside it
+    F = r["iterations_per_launch"]
+    assert F in (2, 3) and ("k_tvl1_iter%d" % F) in r["kernel"]
+    assert abs(r["algorithmic_equivalent_bytes_per_launch"] - F * r["fused_algorithmic_bytes_per_launch"]) < 1.0
+    if F == 3:
+        assert 0 < r["two_iterations_per_launch"]["frac"] <= 1.0
+    assert d["config"]["arithmetic_mode"] == "tolerance" and d["strict"]["value"] > 0
+    assert set(d["loop_ends"]["iterations_per_launch_by_level"]) <= {1, 2, 3}
 
 
 @pytest.mark.gpu
