@@ -85,6 +85,8 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->fixed_work = 0;
     ctx->sor_exact = 1;
     ctx->sor_batch = 0;
+    ctx->sor_fuse = 0;
+    ctx->sor_tile = 0;
     ctx->sor_window = 0;
     ctx->sor_rows = 0;
     ctx->sor_spw = 0;
@@ -187,6 +189,16 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "sor_exact")) {
         if (value != 0 && value != 1 && value != 2) return ofx_fail(ctx, OFX_ERR_ARG, "sor_exact must be 0, 1 or 2");
         ctx->sor_exact = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "sor_fuse")) {
+        if (value < -1 || value > 4) return ofx_fail(ctx, OFX_ERR_ARG, "sor_fuse must be -1 .. 4");
+        ctx->sor_fuse = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "sor_tile")) {
+        if (value < 0 || value > 3) return ofx_fail(ctx, OFX_ERR_ARG, "sor_tile must be 0 .. 3");
+        ctx->sor_tile = (int) value;
         return OFX_OK;
     }
     if (!strcmp(name, "sor_rows")) {

@@ -20,6 +20,7 @@
 #include "ofx_ops.h"
 #include "ofx_device.h"
 #include "ofx_loop.h"
+#include "ofx_sor_tile.h"
 
 #include <algorithm>
 
@@ -55,15 +56,17 @@ static int sor_pick_chunk(const ofx_ctx *ctx, int nx, int ny, int launches_per_s
 // ============================================================================================
 
 // warp of (I2, I2x, I2y) + constant parts of the system, src/horn_schunck_pyramidal.cpp:123-137
+// (ucode: bit g set = the flow of pair g lives in U1, the second buffer of the tile sweeps' ping-pong, ofx_sor_tile.hip)
 template <typename T>
 __global__ void k_hs_warp(const typename Pix<T>::v2 *__restrict__ pa, const T *__restrict__ pb, const T *__restrict__ I1,
-                          const typename Pix<T>::v2 *__restrict__ U, typename Pix<T>::v2 *__restrict__ A,
-                          T *__restrict__ Dif, int nx, int ny)
+                          const typename Pix<T>::v2 *__restrict__ U, const typename Pix<T>::v2 *__restrict__ U1, unsigned ucode,
+                          typename Pix<T>::v2 *__restrict__ A, T *__restrict__ Dif, int nx, int ny)
 {
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= ny) return;
     const size_t go = (size_t) blockIdx.z * nx * ny;             // pair of a lockstep group
+    if ((ucode >> blockIdx.z) & 1u) U = U1;
     pa += go; pb += go; I1 += go; U += go; A += go; Dif += go;
     const size_t p = (size_t) i * nx + j;
     const double2 u = ldw2(U + p);
@@ -755,7 +758,9 @@ template <typename T> struct HsLevel {
     T *Difs;
     int snap_planes;
     int sweep_hint;             // sweeps of the previous solve at this level (sizes the next first batch)
+    unsigned cur;               // tile sweeps (sor_exact = 0): bit g set = the flow of pair g lives in Uck, not U
     size_t n() const { return (size_t) nx * ny; }
+    typename Pix<T>::v2 *flow(int g) const { return (((cur >> g) & 1u) ? Uck : U) + (size_t) g * n(); }
 };
 
 template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int nx, int ny, int G, bool images)
@@ -779,6 +784,7 @@ template <typename T> static int hs_level_alloc(ofx_ctx *ctx, HsLevel<T> &L, int
     L.Difs = nullptr;
     L.snap_planes = 0;
     L.sweep_hint = 0;
+    L.cur = 0;
     return OFX_OK;
 }
 
@@ -799,22 +805,26 @@ static int hs_single_scale_dev(ofx_ctx *ctx, HsLevel<T> &L, const HsParams &P, i
         fprintf(stderr, "Single-scale Horn-Schunck of a %dx%d image\n\ta=%g nw=%d eps=%g mi=%d v=%d\n", nx, ny, P.alpha,
                 P.warps, P.TOL, P.maxiter, P.verbose);
     const bool windowed = ctx->sor_exact == 1 && nx >= 3 && ny >= 3;
-    if (G > 1 && !windowed)
-        return ofx_fail(ctx, OFX_ERR_ARG, "hs: lockstep groups need sor_exact = 1 and levels of at least 3x3 (%dx%d)", nx, ny);
+    const bool tiled = ctx->sor_exact == 0 && ctx->sor_fuse >= 0;        // colour order, K sweeps per launch (ofx_sor_tile.hip)
+    if (G > 1 && !windowed && !tiled)
+        return ofx_fail(ctx, OFX_ERR_ARG, "hs: lockstep groups need sor_exact = 1 (levels of at least 3x3, this one %dx%d) or the tile sweeps of sor_exact = 0", nx, ny);
     for (int g = 0; g < G; g++)
         OFX_TRY(op_grad_pack<T>(ctx, L.I2 + g * npix, L.pa + g * npix, L.pb + g * npix, nx, ny));      // :114
     const dim3 gw(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), G);
     const dim3 gc(ofx_cdiv(ofx_cdiv(nx, 2), 64), ofx_cdiv(ofx_cdiv(ny, 2), 4));
     for (int w = 0; w < P.warps; w++) {
         if (P.verbose && G == 1) fprintf(stderr, "Warping %d:", w);
-        hipLaunchKernelGGL(k_hs_warp<T>, gw, b2d(), 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I1, L.U, L.A, L.Dif,
-                           nx, ny);                                                           // :123-137
+        hipLaunchKernelGGL(k_hs_warp<T>, gw, b2d(), 0, ctx->stream, L.pa, (const T *) L.pb, (const T *) L.I1, L.U, L.Uck, L.cur,
+                           L.A, L.Dif, nx, ny);                                               // :123-137
         OFX_LAUNCH_CHECK(ctx);
         int niter[OFX_MAX_GROUP] = {0};
         double error[OFX_MAX_GROUP];
         for (int g = 0; g < G; g++) error[g] = 1000;                                          // :140
         float ms = 0.f;
-        if (windowed) {
+        if (tiled) {
+            OFX_TRY(ofx_hs_tile_solve<T>(ctx, G, L.U, L.Uck, &L.cur, L.A, (const T *) L.Dif, nx, ny, alpha2, P.TOL, P.maxiter,
+                                         ctx->sor_fuse, niter, error, ctx->profile ? &ms : nullptr));
+        } else if (windowed) {
             // windowed exact mode (default): the sweeps run on hyperplane-major copies of U, A, Dif
             const size_t ps = skew_plane_elems(nx, ny, HS_PLANE_C_SKEW);
             const size_t ub = ps * sizeof(typename Pix<T>::v2);
@@ -986,11 +996,11 @@ static int hs_single_scale_host(ofx_ctx *ctx, const double *I1, const double *I2
     OFX_HIP(ctx, hipMemcpyAsync(d2, v, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     OFX_TRY(op_interleave2<T>(ctx, d1, d2, L.U, n));
     OFX_TRY(hs_single_scale_dev<T>(ctx, L, P, 0, &ctx->stats));
-    return download_flow<T>(ctx, L.U, u, v, n);
+    return download_flow<T>(ctx, L.flow(0), u, v, n);
 }
 
 // src/horn_schunck_pyramidal.cpp:258-370 for G pairs in lockstep.  dI1[g] / dI2[g]: device images of storage type T.
-// On success lv[0].U holds the flows (pair g at element g * nx * ny).
+// On success lv[0].flow(g) holds the flow of pair g.
 template <typename T>
 static int hs_pyramidal_dev(ofx_ctx *ctx, int G, const T *const *dI1, const T *const *dI2, int nx, int ny, const HsParams &P,
                             int nscales, double zfactor, std::vector<HsLevel<T>> &lv, ofx_stats *stats)
@@ -1025,7 +1035,7 @@ static int hs_pyramidal_dev(ofx_ctx *ctx, int G, const T *const *dI1, const T *c
         OFX_TRY(hs_single_scale_dev<T>(ctx, lv[s], P, s, stats));
         if (!s) break;
         for (int g = 0; g < G; g++)
-            OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].U + g * lv[s].n(), lv[s - 1].U + g * lv[s - 1].n(), lv[s].nx, lv[s].ny,
+            OFX_TRY(op_zoom_in_flow<T>(ctx, lv[s].flow(g), lv[s - 1].U + g * lv[s - 1].n(), lv[s].nx, lv[s].ny,
                                        lv[s - 1].nx, lv[s - 1].ny, 1.0 / zfactor));                    // :345-352
     }
     return OFX_OK;
@@ -1042,7 +1052,7 @@ static int hs_pyramidal_host(ofx_ctx *ctx, const double *I1, const double *I2, d
     std::vector<HsLevel<T>> lv;
     const T *a = dI1, *b = dI2;
     OFX_TRY(hs_pyramidal_dev<T>(ctx, 1, &a, &b, nx, ny, P, nscales, zfactor, lv, &ctx->stats));
-    return download_flow<T>(ctx, lv[0].U, u, v, n);
+    return download_flow<T>(ctx, lv[0].flow(0), u, v, n);
 }
 
 template <typename T>
@@ -1052,7 +1062,7 @@ static int hs_group_devapi(ofx_ctx *ctx, int G, const void *const *dI1, const vo
     std::vector<HsLevel<T>> lv;
     OFX_TRY(hs_pyramidal_dev<T>(ctx, G, (const T *const *) dI1, (const T *const *) dI2, nx, ny, P, nscales, zfactor, lv, stats));
     const size_t n = (size_t) nx * ny;
-    for (int g = 0; g < G; g++) OFX_TRY(op_to_flo<T>(ctx, lv[0].U + g * n, (float2 *) d_flo[g], n));
+    for (int g = 0; g < G; g++) OFX_TRY(op_to_flo<T>(ctx, lv[0].flow(g), (float2 *) d_flo[g], n));
     return OFX_OK;
 }
 

@@ -1,0 +1,16 @@
+// ofx_sor_tile.h -- tolerance-mode SOR sweeps of Horn-Schunck and Brox (ofx_sor_tile.hip), private to libofx.so.
+//
+// Both entry points run ONE solve (src/horn_schunck_pyramidal.cpp:143-231, src/brox_optic_flow_spatial.cpp:315-390:
+// `while (error > TOL && n < maxiter) sweep`) for the G pairs of a lockstep group and return the reference loop's
+// n and error per pair.  They are reached with option sor_exact = 0; the default (exact) mode never comes here.
+#pragma once
+
+#include "ofx_internal.h"
+
+// Horn-Schunck, colour order ((i%2, j%2) = (0,0) (0,1) (1,0) (1,1), the order of oracle.set_sor_order(1)), K sweeps per
+// launch on LDS tiles.  U0 / U1: the two buffers of the unknowns (every array holds the G pairs back to back); bit g of
+// *cur says which one holds pair g's flow, on entry and on return.  K = 0 picks it from the level size.
+template <typename T>
+int ofx_hs_tile_solve(ofx_ctx *ctx, int G, typename Pix<T>::v2 *U0, typename Pix<T>::v2 *U1, unsigned *cur,
+                      const typename Pix<T>::v2 *A, const T *Dif, int nx, int ny, double alpha2, double TOL, int maxiter, int K,
+                      int *niter, double *error, float *ms);

@@ -1,0 +1,453 @@
+// ofx_sor_tile.hip -- tolerance-mode SOR sweeps (option sor_exact = 0): K sweeps per launch on LDS tiles.
+//
+// The exact mode (ofx_sor.hip) keeps the reference's sequential sweep order and is a latency chain; north_star's
+// parity bar is an average end-point error below 1e-4 px, and inside that bar the sweeps may be re-ordered.
+//
+// Horn-Schunck (src/horn_schunck_pyramidal.cpp:31-71,143-231): four colours (i % 2, j % 2) in the order (0,0) (0,1)
+// (1,0) (1,1) -- no pixel of a colour reads another pixel of that colour, so a colour step is a plain parallel map and
+// the result does not depend on how the image is cut into tiles.  It is the order of oracle.set_sor_order(1), which
+// these kernels reproduce bit for bit (same expressions, -ffp-contract=off); against the reference's lexicographic order
+// the flows of BASELINE config 3 differ by AEPE 9e-6 (tests/test_gpu_sor.py).
+//
+// k_hs_tile: one 256-thread workgroup owns a tile of 128 x TH pixels = 64 x TH/2 cells of 2 x 2 pixels (one pixel of
+// every colour).  Lane = cell column, wave w owns cell rows w, w + 4, ...; a thread keeps the unknowns and the constant
+// operands (A, dif) of its cells in registers for the whole launch and publishes the unknowns in LDS, one plane per
+// colour, so that the eight neighbours of a pixel are eight conflict-free 16-byte reads at fixed offsets.  One colour
+// step = read neighbours, update, write own plane, barrier.  The dependency cone of one sweep is 4 pixels in x and 2 in
+// y (colour (1,1) sees (1,0) sees (0,1) sees (0,0) horizontally, vertically only two links), so K sweeps need a halo of
+// 4 K columns and 2 K rows that is recomputed, not exchanged: the workgroup loads the tile once, runs K sweeps and
+// stores the inner (128 - 8 K) x (TH - 4 K) pixels.  Sweep s only updates the part of the tile that can still reach
+// the output (shrunk by 4 s + 1 / 2 s + 1).  HBM traffic per launch: 40 B read per tile pixel + 16 B written per output
+// pixel for K sweeps, against 56 B per pixel and sweep of the one-sweep-per-launch form.
+// The reference's replicated border indices are clamped neighbour coordinates; in the tile they are an apron: whoever
+// updates a pixel of the image border also writes its mirror image one pixel outside (the halo has room for it).
+// Unknowns are ping-pong buffered (neighbouring tiles read this tile's input).  The stopping test looks at the K error
+// slots of the previous launch; a loop that ends inside a launch is finished by re-running the first n - k0 sweeps of
+// that launch from its untouched input (ofx_loop.h, the scheme of the TV-L1 tile kernel).
+#include "ofx_sor_tile.h"
+#include "ofx_device.h"
+#include "ofx_loop.h"
+
+#define HST_SOR_W 1.9                // src/horn_schunck_pyramidal.cpp:21
+#define HST_W 128                    // tile width in pixels
+#define HST_CW 64                    // ... in cells = lanes of a wave
+#define HST_PW (HST_CW + 2)          // row pitch of a colour plane in LDS: one spare cell column on either side, and one spare
+                                     // cell row above and below, so that EVERY cell can read its neighbours -- the updates of a
+                                     // thread's cells are computed unconditionally (straight-line code) and committed by select
+// LDS index of cell (row, col) of colour plane `plane`; row in [-1, CR], col in [-1, 64]
+template <int CR> OFX_DEV constexpr int hst_at(int plane, int row, int col) { return (plane * (CR + 2) + row + 1) * HST_PW + col + 1; }
+
+template <typename V> OFX_DEV const V *hst_off(const V *base, unsigned byte_off)
+{
+    return reinterpret_cast<const V *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <typename V> OFX_DEV V *hst_off(V *base, unsigned byte_off)
+{
+    return reinterpret_cast<V *>(reinterpret_cast<char *>(base) + byte_off);
+}
+
+template <typename T> OFX_DEV double tile_rnd(double x);
+template <> OFX_DEV double tile_rnd<double>(double x) { return x; }
+template <> OFX_DEV double tile_rnd<float>(double x) { return (double) (float) x; }
+
+// n / d with the reciprocal r = rcp_newton(d) prepared once per launch: quotient estimate, remainder, correction -- the
+// compiler's own f64 division (v_div_scale x2, v_rcp, two Newton steps, q = n r, rem = n - d q, v_div_fmas, v_div_fixup) minus
+// its scaling and fix-up steps, which are the identity unless an operand or the quotient sits at the edge of the exponent range.
+// d = a^2 + alpha^2 lies in [alpha^2, 1e5 + alpha^2] and the numerators are flow-sized, so the result is the IEEE quotient bit
+// for bit (tests/test_gpu_sor_tile.py compares whole solves with the oracle's plain divisions).  OFX_HST_IEEE_DIV: the A/B build.
+OFX_DEV double hst_div(double n, double d, double r)
+{
+#ifdef OFX_HST_IEEE_DIV
+    (void) r;
+    return n / d;
+#else
+    const double q = n * r;
+    const double rem = __builtin_fma(-d, q, n);
+    return __builtin_fma(rem, r, q);
+#endif
+}
+
+// constant operands of a pixel for the whole launch: (I2wx, I2wy), dif and the two reciprocals
+struct HstCoef {
+    double ax, ay, dif, ru, rv;
+};
+OFX_DEV HstCoef hst_coef(double2 a, double dif, double alpha2)
+{
+    HstCoef k;
+    k.ax = a.x;
+    k.ay = a.y;
+    k.dif = dif;
+    k.ru = rcp_newton(a.x * a.x + alpha2);
+    k.rv = rcp_newton(a.y * a.y + alpha2);
+    return k;
+}
+
+template <int CR> OFX_DEV void hst_put(double2 *s_u, int li, int lj, double2 v)
+{
+    // (an image border in the LAST row / column of a tile has its mirror outside the tile: that pixel is never updated here and
+    // nothing that reaches the output reads beyond it)
+    if (li < 0 || li >= 2 * CR || lj < 0 || lj >= HST_W) return;
+    const int plane = ((li & 1) << 1) | (lj & 1);
+    s_u[hst_at<CR>(plane, li >> 1, lj >> 1)] = v;
+}
+// A pixel of the image border also lives one pixel outside the image (clamped neighbour indices, :161-228): in LDS for the
+// neighbours in other cells and, when the mirror falls into the pixel's own cell (bottom / right mirror of an even row / column),
+// in the registers uc[] of that cell, where its owner reads the in-cell neighbours from.
+template <int CR, int CI, int CJ>
+OFX_DEV void hst_mirror(double2 *s_u, int li, int lj, int ii, int jj, int nx, int ny, double2 v, double2 (&uc)[4])
+{
+    const int di = ii == 0 ? -1 : (ii == ny - 1 ? 1 : 0), dj = jj == 0 ? -1 : (jj == nx - 1 ? 1 : 0);
+    if (di) {
+        hst_put<CR>(s_u, li + di, lj, v);
+        if (CI == 0 && di == 1) uc[2 + CJ] = v;
+    }
+    if (dj) {
+        hst_put<CR>(s_u, li, lj + dj, v);
+        if (CJ == 0 && dj == 1) uc[CI * 2 + 1] = v;
+    }
+    if (di && dj) {
+        hst_put<CR>(s_u, li + di, lj + dj, v);
+        if (CI == 0 && CJ == 0 && di == 1 && dj == 1) uc[3] = v;
+    }
+}
+
+// neighbour (DI, DJ) of the pixel of colour (CI, CJ) of cell (a_row, lane): from the cell's registers when it is one of the cell's
+// own pixels, else from the colour plane it lives in
+template <int CR, int CI, int CJ, int DI, int DJ>
+OFX_DEV double2 hst_nb(const double2 *s_u, int a_row, int lane, const double2 (&uc)[4])
+{
+    constexpr int si = CI + DI, sj = CJ + DJ;                             // -1 .. 2
+    if constexpr (si >= 0 && si <= 1 && sj >= 0 && sj <= 1) {
+        return uc[si * 2 + sj];
+    } else {
+        constexpr int plane = ((si & 1) << 1) | (sj & 1);
+        constexpr int drow = si < 0 ? -1 : si / 2, dcol = sj < 0 ? -1 : sj / 2;
+        return s_u[hst_at<CR>(plane, a_row + drow, lane + dcol)];
+    }
+}
+
+// SOR update of one pixel, src/horn_schunck_pyramidal.cpp:31-71 (the expressions of hs_point_finish in ofx_sor.hip):
+// p1..p4 = up-left, up-right, bottom-left, bottom-right, p5..p8 = up, left, bottom, right; the bottom-right corner of the image
+// lists its diagonal taps bottom pair first (:222-228).  Returns the new value; e = the squared update (:70).
+template <typename T, int CR, int CI, int CJ>
+OFX_DEV double2 hst_update(const double2 *s_u, int a_row, int lane, const double2 (&uc)[4], const HstCoef &k, double alpha2, bool corner,
+                           double &e)
+{
+    double2 p1 = hst_nb<CR, CI, CJ, -1, -1>(s_u, a_row, lane, uc), p2 = hst_nb<CR, CI, CJ, -1, 1>(s_u, a_row, lane, uc);
+    double2 p3 = hst_nb<CR, CI, CJ, 1, -1>(s_u, a_row, lane, uc), p4 = hst_nb<CR, CI, CJ, 1, 1>(s_u, a_row, lane, uc);
+    const double2 p5 = hst_nb<CR, CI, CJ, -1, 0>(s_u, a_row, lane, uc), p6 = hst_nb<CR, CI, CJ, 0, -1>(s_u, a_row, lane, uc);
+    const double2 p7 = hst_nb<CR, CI, CJ, 1, 0>(s_u, a_row, lane, uc), p8 = hst_nb<CR, CI, CJ, 0, 1>(s_u, a_row, lane, uc);
+    if (corner) {
+        const double2 t1 = p1, t2 = p2;
+        p1 = p3; p2 = p4; p3 = t1; p4 = t2;
+    }
+    const double w = HST_SOR_W;
+    // The five coefficients are recomputed in every update (7 of its ~50 instructions).  Left alone the compiler hoists them out
+    // of the sweep loop -- 10 more registers per pixel, which spills (and a kernel with a scratch segment starts microseconds
+    // later); the empty asm makes the three operands opaque to that motion.
+    double ax = k.ax, ay = k.ay, dif = k.dif;
+#ifndef OFX_HST_HOIST
+    asm volatile("" : "+v"(ax), "+v"(ay), "+v"(dif));
+#endif
+    const double Au = dif * ax, Av = dif * ay;                                // :133-134
+    const double Du = ax * ax + alpha2, Dv = ay * ay + alpha2;                // :135-136
+    const double D = ax * ay;                                                 // :137
+    const double ula = 1. / 12. * (p1.x + p2.x + p3.x + p4.x) + 1. / 6. * (p5.x + p6.x + p7.x + p8.x);
+    const double vla = 1. / 12. * (p1.y + p2.y + p3.y + p4.y) + 1. / 6. * (p5.y + p6.y + p7.y + p8.y);
+    const double uk = uc[CI * 2 + CJ].x, vk = uc[CI * 2 + CJ].y;
+    const double un = tile_rnd<T>((1.0 - w) * uk + hst_div(w * (Au - D * vk + alpha2 * ula), Du, k.ru));   // :66
+    const double vn = tile_rnd<T>((1.0 - w) * vk + hst_div(w * (Av - D * un + alpha2 * vla), Dv, k.rv));   // :67
+    e = (un - uk) * (un - uk) + (vn - vk) * (vn - vk);                        // :70
+    return make_double2(un, vn);
+}
+
+// Per-thread pixel flags, one bit per pixel (bit m * 4 + c): kept as three integers in VGPRs and tested bit by bit -- as separate
+// booleans they are two SGPRs each, and a thread has up to 24 pixels x 4 flags (the scalar file spilled into the vector one).
+struct HstFlags {
+    unsigned inside, owner, border;       // inside the image / in the output region and inside / on the image border and inside
+};
+OFX_DEV bool hst_bit(unsigned f, int b) { return (f >> b) & 1u; }
+
+// one colour of one sweep for the CPT cells of a thread: all updates computed, the active ones committed
+template <typename T, int K, int TH, int NW, int CI, int CJ>
+OFX_DEV double hst_colour_step(double2 *s_u, int w, int lane, int x0, int y0, int nx, int ny, int s, double2 (&u)[TH / 2 / NW][4],
+                               const HstCoef (&kf)[TH / 2 / NW][4], const HstFlags &fl, double alpha2)
+{
+    constexpr int CR = TH / 2, CPT = CR / NW, C = CI * 2 + CJ;
+    const int lj = 2 * lane + CJ;
+    // sweep s updates the pixels that can still reach the output: columns [4 s + 1, W - 2 - 4 s], rows [2 s + 1, TH - 2 - 2 s]
+    const bool colx = (unsigned) (lj - (4 * s + 1)) <= (unsigned) (HST_W - 3 - 8 * s);
+    double e = 0.0;
+    bool border = false;
+    unsigned f_in = fl.inside, f_own = fl.owner, f_brd = fl.border;
+    asm volatile("" : "+v"(f_in), "+v"(f_own), "+v"(f_brd));   // the bit tests stay here (hoisted, each is a pair of SGPRs for the whole loop)
+#pragma unroll
+    for (int m = 0; m < CPT; m++) {
+        const int a_row = w + NW * m;
+        const int li = 2 * a_row + CI;
+        const bool rowy = (unsigned) (li - (2 * s + 1)) <= (unsigned) (TH - 3 - 4 * s);          // wave-uniform
+        const bool active = colx && rowy && hst_bit(f_in, m * 4 + C);
+        const bool corner = y0 + li == ny - 1 && x0 + lj == nx - 1;
+        double e1;
+        const double2 un = hst_update<T, CR, CI, CJ>(s_u, a_row, lane, u[m], kf[m][C], alpha2, corner, e1);
+        e += (active && hst_bit(f_own, m * 4 + C)) ? e1 : 0.0;
+        u[m][C].x = active ? un.x : u[m][C].x;
+        u[m][C].y = active ? un.y : u[m][C].y;
+        // (an inactive cell must not touch its LDS entry -- outside the image that is somebody's mirror; its store goes to the spare
+        // row of its plane and column, a wave-uniform distance away)
+        s_u[hst_at<CR>(C, a_row, lane) - (active ? 0 : (a_row + 1) * HST_PW)] = u[m][C];
+        border = border || (active && hst_bit(f_brd, m * 4 + C));
+    }
+    if (border) {                                           // rare: tiles on the image border only
+#pragma unroll
+        for (int m = 0; m < CPT; m++) {
+            const int a_row = w + NW * m;
+            const int li = 2 * a_row + CI;
+            const bool rowy = (unsigned) (li - (2 * s + 1)) <= (unsigned) (TH - 3 - 4 * s);
+            if (colx && rowy && hst_bit(f_brd, m * 4 + C)) hst_mirror<CR, CI, CJ>(s_u, li, lj, y0 + li, x0 + lj, nx, ny, u[m][C], u[m]);
+        }
+    }
+    return e;
+}
+
+template <int CR, int CI, int CJ>
+OFX_DEV void hst_mirror_init(double2 *s_u, int a_row, int lane, int x0, int y0, int nx, int ny, double2 (&uc)[4])
+{
+    const int li = 2 * a_row + CI, lj = 2 * lane + CJ, ii = y0 + li, jj = x0 + lj;
+    const bool inside = ii >= 0 && ii < ny && jj >= 0 && jj < nx;
+    if (inside && (ii == 0 || ii == ny - 1 || jj == 0 || jj == nx - 1)) hst_mirror<CR, CI, CJ>(s_u, li, lj, ii, jj, nx, ny, uc[CI * 2 + CJ], uc);
+}
+
+// Launch unit = sweeps [k0, k0 + niter) of every pair of the group (blockIdx.y = pair; bit g of incode: pair g reads U1 and writes
+// U0, else the other way; 4 bits of `nit` per pair: its sweep count in this launch).  `check`: the stopping test on the K error
+// slots of the previous unit (0 for the re-run of a unit's first sweeps, whose errors all go to the scratch slot slot0).
+// NW waves per workgroup: wave w owns the cell rows w, w + NW, ...
+template <typename T, int K, int TH, int NW>
+__global__ __launch_bounds__(64 * NW) void k_hs_tile(typename Pix<T>::v2 *U0, typename Pix<T>::v2 *U1,
+                                                     const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Difg,
+                                                     double *__restrict__ errg, int k0, int check, int slot0, int nx, int ny,
+                                                     int tiles_x, double alpha2, double tol, unsigned incode, unsigned runmask,
+                                                     unsigned long long nit, int err_stride)
+{
+    using v2 = typename Pix<T>::v2;
+    static_assert((TH / 2) % NW == 0 && TH % 2 == 0 && K >= 1 && K < 16 && HST_W - 8 * K > 0 && TH - 4 * K > 0, "tile geometry");
+    constexpr int CR = TH / 2, CPT = CR / NW, HX = 4 * K, HY = 2 * K, OW = HST_W - 2 * HX, OH = TH - 2 * HY;
+    extern __shared__ double2 s_u[];                        // [4 colour planes][CR + 2 cell rows][64 + 2 cell columns], hst_at
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int g = blockIdx.y;
+    if (!((runmask >> g) & 1u)) return;
+    const int niter = (int) ((nit >> (4 * g)) & 15ull);
+    const size_t npix = (size_t) nx * ny;
+    const bool from1 = (incode >> g) & 1u;
+    const v2 *__restrict__ Uin = (from1 ? U1 : U0) + (size_t) g * npix;
+    v2 *__restrict__ Uout = (from1 ? U0 : U1) + (size_t) g * npix;
+    const v2 *__restrict__ A = Ag + (size_t) g * npix;
+    const T *__restrict__ Dif = Difg + (size_t) g * npix;
+    double *__restrict__ err = errg + (size_t) g * err_stride;
+    double prev[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) prev[i] = (check && k0 - i > 0) ? loop_fetch_prev(err, k0 - i) : 0.0;
+
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x0 = tx * OW - HX, y0 = ty * OH - HY;         // both even: tile parity = image parity
+    double2 u[CPT][4];
+    HstCoef kf[CPT][4];
+    {
+        // every load of the thread issued back to back: addresses clamped into the image, the values of pixels outside it zeroed
+        double2 la[CPT][4];
+        double ld[CPT][4];
+#pragma unroll
+        for (int m = 0; m < CPT; m++) {
+            const int a_row = w + NW * m;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int ii = y0 + 2 * a_row + (c >> 1), jj = x0 + 2 * lane + (c & 1);
+                const int ic = ii < 0 ? 0 : (ii > ny - 1 ? ny - 1 : ii), jc = jj < 0 ? 0 : (jj > nx - 1 ? nx - 1 : jj);
+                // uniform base + 32-bit byte offset (the addressing mode of global_load: one VGPR per address; the host checks
+                // that a plane of pairs stays below 4 GiB)
+                const unsigned p = ((unsigned) ic * (unsigned) nx + (unsigned) jc) * (unsigned) sizeof(v2);
+                u[m][c] = ldw2(hst_off(Uin, p));
+                la[m][c] = ldw2(hst_off(A, p));
+                ld[m][c] = ldw(hst_off(Dif, p >> 1));
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < CPT; m++) {
+            const int a_row = w + NW * m;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int ii = y0 + 2 * a_row + (c >> 1), jj = x0 + 2 * lane + (c & 1);
+                const bool inside = ii >= 0 && ii < ny && jj >= 0 && jj < nx;
+                u[m][c].x = inside ? u[m][c].x : 0.0;
+                u[m][c].y = inside ? u[m][c].y : 0.0;
+                kf[m][c] = hst_coef(la[m][c], ld[m][c], alpha2);
+            }
+        }
+    }
+    HstFlags fl = {0u, 0u, 0u};
+#pragma unroll
+    for (int m = 0; m < CPT; m++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int li = 2 * (w + NW * m) + (c >> 1), lj = 2 * lane + (c & 1), ii = y0 + li, jj = x0 + lj;
+            const bool inside = ii >= 0 && ii < ny && jj >= 0 && jj < nx;
+            const unsigned bit = 1u << (m * 4 + c);
+            fl.inside |= inside ? bit : 0u;
+            fl.owner |= (inside && li >= HY && li < TH - HY && lj >= HX && lj < HST_W - HX) ? bit : 0u;
+            fl.border |= (inside && (ii == 0 || ii == ny - 1 || jj == 0 || jj == nx - 1)) ? bit : 0u;
+        }
+    }
+    asm volatile("" : "+v"(fl.inside), "+v"(fl.owner), "+v"(fl.border));          // keep them integers
+    if (check) {                                            // :143 -- the same decision in every wave, before the first barrier
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if (k0 - i > 0 && !(loop_error_from_sum(wave_allreduce_sum(prev[i]), nx * ny, OFX_CRIT_SQRT_MEAN) > tol)) return;
+    }
+#pragma unroll
+    for (int m = 0; m < CPT; m++) {
+        const int a_row = w + NW * m;
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_u[hst_at<CR>(c, a_row, lane)] = u[m][c];
+    }
+    // (the spare ring is read by the discarded updates of the tile's outermost cells only: whatever it holds)
+    __syncthreads();                                        // aprons after the planes: a mirror may land in another thread's cell
+#pragma unroll
+    for (int m = 0; m < CPT; m++) {
+        const int a_row = w + NW * m;
+        hst_mirror_init<CR, 0, 0>(s_u, a_row, lane, x0, y0, nx, ny, u[m]);
+        hst_mirror_init<CR, 0, 1>(s_u, a_row, lane, x0, y0, nx, ny, u[m]);
+        hst_mirror_init<CR, 1, 0>(s_u, a_row, lane, x0, y0, nx, ny, u[m]);
+        hst_mirror_init<CR, 1, 1>(s_u, a_row, lane, x0, y0, nx, ny, u[m]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < niter; s++) {
+        double e = hst_colour_step<T, K, TH, NW, 0, 0>(s_u, w, lane, x0, y0, nx, ny, s, u, kf, fl, alpha2);
+        __syncthreads();
+        e += hst_colour_step<T, K, TH, NW, 0, 1>(s_u, w, lane, x0, y0, nx, ny, s, u, kf, fl, alpha2);
+        __syncthreads();
+        e += hst_colour_step<T, K, TH, NW, 1, 0>(s_u, w, lane, x0, y0, nx, ny, s, u, kf, fl, alpha2);
+        __syncthreads();
+        e += hst_colour_step<T, K, TH, NW, 1, 1>(s_u, w, lane, x0, y0, nx, ny, s, u, kf, fl, alpha2);
+        __syncthreads();
+        loop_accumulate(err, slot0 + (check ? s : 0), e, blockIdx.x * NW + w);
+    }
+#pragma unroll
+    for (int m = 0; m < CPT; m++) {
+        const int a_row = w + NW * m;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int ii = y0 + 2 * a_row + (c >> 1), jj = x0 + 2 * lane + (c & 1);
+            if (hst_bit(fl.owner, m * 4 + c)) stn2(hst_off(Uout, ((unsigned) ii * (unsigned) nx + (unsigned) jj) * (unsigned) sizeof(v2)), u[m][c]);
+        }
+    }
+}
+
+static_assert(OFX_MAX_GROUP * 4 <= 64, "4 bits of `nit` per pair of a lockstep group");
+static_assert(OFX_MAX_GROUP <= 32, "one bit of incode / runmask per pair of a lockstep group");
+
+template <typename T, int K, int TH, int NW>
+static int hs_tile_launch(ofx_ctx *ctx, int G, typename Pix<T>::v2 *U0, typename Pix<T>::v2 *U1, const typename Pix<T>::v2 *A,
+                          const T *Dif, int k0, int check, int slot0, int nx, int ny, double alpha2, double thr, unsigned incode,
+                          unsigned runmask, unsigned long long nit, int err_stride)
+{
+    constexpr int OW = HST_W - 8 * K, OH = TH - 4 * K;
+    const int tiles_x = ofx_cdiv(nx, OW), tiles_y = ofx_cdiv(ny, OH);
+    const size_t lds = (size_t) 4 * (TH / 2 + 2) * HST_PW * sizeof(double2);
+    if (lds > 64 * 1024)
+        OFX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hs_tile<T, K, TH, NW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipLaunchKernelGGL((k_hs_tile<T, K, TH, NW>), dim3((unsigned) (tiles_x * tiles_y), G), dim3(64 * NW), lds, ctx->stream, U0, U1, A, Dif,
+                       ctx->d_err, k0, check, slot0, nx, ny, tiles_x, alpha2, thr, incode, runmask, nit, err_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "hs tile launch failed: %s", hipGetErrorString(e));
+    return OFX_OK;
+}
+
+template <typename T>
+int ofx_hs_tile_solve(ofx_ctx *ctx, int G, typename Pix<T>::v2 *U0, typename Pix<T>::v2 *U1, unsigned *cur,
+                      const typename Pix<T>::v2 *A, const T *Dif, int nx, int ny, double alpha2, double TOL, int maxiter, int K,
+                      int *niter, double *error, float *ms)
+{
+    if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "hs: group of %d pairs", G);
+    if ((double) nx * ny * sizeof(typename Pix<T>::v2) >= 4294967296.0)
+        return ofx_fail(ctx, OFX_ERR_ARG, "hs: tile sweeps address a level with 32-bit byte offsets (%dx%d is too large)", nx, ny);
+    for (int g = 0; g < G; g++) { niter[g] = 0; error[g] = 1000; }                                   // :140
+    if (maxiter <= 0 || !(1000.0 > TOL)) return OFX_OK;
+    if (K <= 0) K = 2;
+    if (K > 4) K = 4;
+    LoopSpec S;
+    S.max_iter = maxiter;
+    S.size = nx * ny;
+    S.thr = TOL;
+    S.crit = OFX_CRIT_SQRT_MEAN;
+    S.fixed = ctx->fixed_work != 0;
+    S.pairs = K == 2;
+    S.fuse = K > 2 ? K : 0;
+    S.afac = 0.0;
+    if (ctx->chunk > 0) S.chunk = ctx->chunk;
+    else {
+        // a launch of K sweeps: ~3 us + the tile's 4 K colour steps (~1 us each) per round of 256 workgroups; one poll per ~80 us
+        const double tiles = (double) ofx_cdiv(nx, HST_W - 8 * K) * ofx_cdiv(ny, 32) * G;
+        const double est_us = 3.0 + 4.0 * K * (tiles < 256.0 ? 1.0 : tiles / 256.0);
+        int units = (int) (80.0 / est_us);
+        units = units < 1 ? 1 : (units > 8 ? 8 : units);
+        S.chunk = units * K;
+    }
+    const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
+    const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
+    const unsigned b0 = *cur & all;
+    // tile geometry (option "sor_tile": 0 = default): 1 = 128 x 32 pixels on 16 waves (one cell row per wave), 2 = 128 x 32 on 8,
+    // 3 = 128 x 48 on 12
+    const int geom = ctx->sor_tile > 0 ? ctx->sor_tile : 2;
+    auto go = [&](int k0, int check, int slot0, double thr, unsigned incode, unsigned runmask, unsigned long long nit) -> int {
+#define HST_GO(K_, TH_, NW_)                                                                                                    \
+    return hs_tile_launch<T, K_, TH_, NW_>(ctx, G, U0, U1, A, Dif, k0, check, slot0, nx, ny, alpha2, thr, incode, runmask, nit, err_stride)
+#define HST_GEOM(K_)                                                                                                            \
+    do {                                                                                                                        \
+        if (geom == 1) HST_GO(K_, 32, 16);                                                                                      \
+        if (geom == 2) HST_GO(K_, 32, 8);                                                                                       \
+        HST_GO(K_, 48, 12);                                                                                                     \
+    } while (0)
+        switch (K) {
+        case 1: HST_GEOM(1);
+        case 2: HST_GEOM(2);
+        case 3: HST_GEOM(3);
+        default: HST_GEOM(4);
+        }
+#undef HST_GEOM
+#undef HST_GO
+    };
+    auto launch = [&](int k, int cnt, double thr) -> int {
+        // unit j = k / K reads the buffer pair g started in when j is even
+        const unsigned flip = ((k / K) & 1) ? all : 0u;
+        unsigned long long nit = 0;
+        for (int g = 0; g < G; g++) nit |= (unsigned long long) cnt << (4 * g);
+        return go(k, 1, k, thr, b0 ^ flip, all, nit);
+    };
+    auto redo = [&](const int *k_of) -> int {
+        unsigned incode = 0, runmask = 0;
+        unsigned long long nit = 0;
+        for (int g = 0; g < G; g++) {
+            if (k_of[g] < 0) continue;
+            const int n = k_of[g] + 1, j = (n - 1) / K;
+            runmask |= 1u << g;
+            incode |= (((b0 >> g) ^ (unsigned) j) & 1u) << g;
+            nit |= (unsigned long long) (n - j * K) << (4 * g);
+        }
+        return go(0, 0, S.max_iter, -1.0, incode, runmask, nit);     // no stopping test; errors into the scratch slot
+    };
+    OFX_TRY(ofx_run_loop_group(ctx, S, G, launch, redo, niter, error, ms));
+    unsigned c = 0;
+    for (int g = 0; g < G; g++) {
+        const unsigned units = (unsigned) ((niter[g] + K - 1) / K);
+        c |= (((b0 >> g) ^ units) & 1u) << g;
+    }
+    *cur = c;
+    return OFX_OK;
+}
+
+template int ofx_hs_tile_solve<double>(ofx_ctx *, int, double2 *, double2 *, unsigned *, const double2 *, const double *, int, int, double,
+                                       double, int, int, int *, double *, float *);
+template int ofx_hs_tile_solve<float>(ofx_ctx *, int, float2 *, float2 *, unsigned *, const float2 *, const float *, int, int, double,
+                                      double, int, int, int *, double *, float *);

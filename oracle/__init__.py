@@ -279,6 +279,17 @@ class Oracle(_Lib):
         """0 = reference (lexicographic) sweeps, 1 = the HIP path's colour order (checker aid)."""
         self._fn("set_sor_order", None, C.c_int)(order)
 
+    def set_sor_colour_levels(self, mask):
+        """With order 1: bit s set = pyramid level s in colour order, clear = reference order (the HIP option of that name)."""
+        self._fn("set_sor_colour_levels", None, C.c_uint)(mask & 0xFFFFFFFF)
+
+    def set_sor_tile(self, w, h):
+        self._fn("set_sor_tile", None, C.c_int, C.c_int)(w, h)
+
+    def set_sor_exact_tail(self, tail):
+        """With order 1: the last `tail` solves of the finest level keep the reference's order (the HIP option of that name)."""
+        self._fn("set_sor_exact_tail", None, C.c_int)(tail)
+
     def tvl1_single_scale(self, I0, I1, u1, u2, tau=0.25, lam=0.15, theta=0.3, warps=5, epsilon=0.01,
                           verbose=0):
         ny, nx = I0.shape

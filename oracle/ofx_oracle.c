@@ -627,6 +627,30 @@ static inline double hs_point_clamped(const double *Au, const double *Av, const 
  * kernel right" from "how far does the colouring move the result" (tests/test_gpu_sor.py). */
 static int g_sor_order = 0;
 void orc_set_sor_order(int order) { g_sor_order = order; }
+/* Checker aid for the HIP path's option "sor_colour_levels": with order 1, pyramid level s is swept in colour order only
+ * when bit s of the mask is set; the other levels keep the reference's order (0). */
+static unsigned g_sor_colour_levels = ~0u;
+void orc_set_sor_colour_levels(unsigned mask) { g_sor_colour_levels = mask; }
+/* ... and "sor_exact_tail": with order 1, the last `tail` solves of the finest level (level 0) keep the reference's order */
+static int g_sor_exact_tail = 0, g_sor_level = -1;
+void orc_set_sor_exact_tail(int tail) { g_sor_exact_tail = tail < 0 ? 0 : tail; }
+static int sor_order_enter_level(int s)
+{
+    const int saved = g_sor_order;
+    g_sor_level = s;
+    if (g_sor_order == 1 && s < 32 && !((g_sor_colour_levels >> s) & 1u)) g_sor_order = 0;
+    return saved;
+}
+/* order 3 (EXPERIMENT): block-lexicographic -- tiles of g_tile_w x g_tile_h pixels, lexicographic inside a tile, values of
+ * the previous sweep across tile borders */
+static int g_tile_w = 64, g_tile_h = 64;
+void orc_set_sor_tile(int w, int h) { g_tile_w = w; g_tile_h = h; }
+/* order of solve `k` of `n` at the current level */
+static int sor_order_of_solve(int k, int n)
+{
+    if (g_sor_order == 1 && g_sor_level == 0 && k >= n - g_sor_exact_tail) return 0;
+    return g_sor_order;
+}
 
 static double hs_sweep_coloured(const double *Au, const double *Av, const double *Du, const double *Dv,
                                 const double *D, double *u, double *v, double a2, int nx, int ny)
@@ -786,6 +810,8 @@ void orc_hs_single_scale(const double *I1, const double *I2, double *u, double *
         }
         int niter = 0;
         double error = 1000;
+        const int order_all = g_sor_order;
+        g_sor_order = sor_order_of_solve(w, warps);
         if (g_sor_order == 2 && nx >= 3 && ny >= 3) {
             /* batches of pipelined sweeps; a batch that runs past the stopping sweep is rolled back to
              * its checkpoint and re-run with exactly the sweeps that count */
@@ -815,6 +841,7 @@ void orc_hs_single_scale(const double *I1, const double *I2, double *u, double *
             error = hs_sweep(Au, Av, Du, Dv, D, u, v, alpha2, nx, ny);
             error = sqrt(error / size);                                /* :230 */
         }
+        g_sor_order = order_all;
         if (verbose) fprintf(stderr, "Iterations %d (%g)\n", niter, error);
         if (iters) iters[w] = niter;
     }
@@ -834,8 +861,10 @@ int orc_hs_pyramidal(const double *I1, const double *I2, double *u, double *v, i
     int rc = pyramid_build(&P, I1, I2, u, v, nx, ny, nscales, zfactor, HS_PRESMOOTH_SIGMA);
     for (int s = nscales - 1; s >= 0 && !rc; s--) {
         if (verbose) fprintf(stderr, "Scale: %d %dx%d\n", s, P.nx[s], P.ny[s]);
+        const int order = sor_order_enter_level(s);
         orc_hs_single_scale(P.A[s], P.B[s], P.u[s], P.v[s], P.nx[s], P.ny[s], alpha, warps, TOL,
                             maxiter, verbose, iters ? iters + s * warps : NULL);
+        g_sor_order = order;
         if (s) pyramid_upsample(&P, s, zfactor);
     }
     pyramid_free(&P);
@@ -997,6 +1026,8 @@ static void brox_single_scale(const double *I1, const double *I2, double *u, dou
 
             double error = 1000;
             int nsor = 0;
+            const int order_all = g_sor_order;
+            g_sor_order = sor_order_of_solve(no * inner_iter + ni, outer_iter * inner_iter);
             if (g_sor_order == 2 && nx >= 3 && ny >= 3) {
                 plane_index PI;
                 plane_index_build(&PI, nx, ny, brox_pos);
@@ -1035,6 +1066,21 @@ static void brox_single_scale(const double *I1, const double *I2, double *u, dou
             while (error > TOL && nsor < BROX_MAXITER) {       /* :315 */
                 error = 0;
                 nsor++;
+                if (g_sor_order == 3) {     /* EXPERIMENT: checkerboard of tiles, lexicographic inside a tile, in place */
+                    for (int col = 0; col < 2; col++)
+                        for (int ti = 0; ti < ny; ti += g_tile_h)
+                            for (int tj = 0; tj < nx; tj += g_tile_w) {
+                                if (((ti / g_tile_h + tj / g_tile_w) & 1) != col) continue;
+                                const int i1e = ti + g_tile_h < ny ? ti + g_tile_h : ny, j1e = tj + g_tile_w < nx ? tj + g_tile_w : nx;
+                                for (int i = ti; i < i1e; i++)
+                                    for (int j = tj; j < j1e; j++)
+                                        error += brox_sor_point(Au, Av, Du, Dv, D, du, dv, alpha, psi1, psi2, psi3, psi4, i,
+                                                                i > 0 ? nx : 0, i < ny - 1 ? nx : 0, j, nx, j > 0 ? 1 : 0,
+                                                                j < nx - 1 ? 1 : 0);
+                            }
+                    error = sqrt(error / size);
+                    continue;
+                }
                 if (g_sor_order == 1) {     /* checker aid: red-black order of the HIP path */
                     for (int col = 0; col < 2; col++)
                         for (int i = 0; i < ny; i++)
@@ -1072,6 +1118,7 @@ static void brox_single_scale(const double *I1, const double *I2, double *u, dou
                                         ny - 1, nx, 0, nx - 1, nx, 1, 0);
                 error = sqrt(error / size);                    /* :389 */
             }
+            g_sor_order = order_all;
             if (verbose) printf("Iterations: %d\n", nsor);
             if (iters) iters[solve] = nsor;
             solve++;
@@ -1091,9 +1138,11 @@ int orc_brox_spatial(const double *I1, const double *I2, double *u, double *v, i
     const int nthreads = orc_max_threads();
     for (int s = nscales - 1; s >= 0 && !rc; s--) {
         if (verbose) printf("Scale: %d\n", s);
+        const int order = sor_order_enter_level(s);
         brox_single_scale(P.A[s], P.B[s], P.u[s], P.v[s], P.nx[s], P.ny[s], alpha, gamma, TOL,
                           inner_iter, outer_iter, nthreads, verbose,
                           iters ? iters + s * inner_iter * outer_iter : NULL);
+        g_sor_order = order;
         if (s) pyramid_upsample(&P, s, nu);
     }
     pyramid_free(&P);

@@ -66,6 +66,10 @@ double orc_tvl1_iterations(double *u1, double *u2, double *p11, double *p12, dou
 /* checker aids, see ofx_oracle.c: 0 = reference sweep order (default), 1 = the HIP path's colour order,
  * 2 = the HIP path's exact hyperplane-pipelined schedule (bit-identical to 0 by construction) */
 void orc_set_sor_order(int order);
+/* with order 1: bit s of the mask = pyramid level s is swept in colour order, clear = in the reference's order (default: all set) */
+void orc_set_sor_colour_levels(unsigned mask);
+/* with order 1: the last `tail` solves (warps / outer x inner iterations) of level 0 keep the reference's order (default 0) */
+void orc_set_sor_exact_tail(int tail);
 void orc_set_plane_batch(int sweeps_in_flight);
 
 /* horn_schunck_pyramidal.cpp */
