@@ -87,6 +87,8 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->sor_batch = 0;
     ctx->sor_fuse = 0;
     ctx->sor_tile = 0;
+    ctx->sor_tile_w = 0;
+    ctx->sor_wave_levels = 1;
     ctx->sor_window = 0;
     ctx->sor_rows = 0;
     ctx->sor_spw = 0;
@@ -199,6 +201,16 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "sor_tile")) {
         if (value < 0 || value > 3) return ofx_fail(ctx, OFX_ERR_ARG, "sor_tile must be 0 .. 3");
         ctx->sor_tile = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "sor_tile_w")) {
+        if (value < 0 || value > 65536) return ofx_fail(ctx, OFX_ERR_ARG, "sor_tile_w out of range");
+        ctx->sor_tile_w = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "sor_wave_levels")) {
+        if (value < 0 || value > 64) return ofx_fail(ctx, OFX_ERR_ARG, "sor_wave_levels out of range");
+        ctx->sor_wave_levels = (int) value;
         return OFX_OK;
     }
     if (!strcmp(name, "sor_rows")) {

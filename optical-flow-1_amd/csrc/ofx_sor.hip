@@ -1479,12 +1479,16 @@ OFX_DEV double brox_point_skew(typename Pix<T>::v2 *DU, const typename Pix<T>::v
 }
 
 // one colour of one SOR sweep (fast, order-changing mode): every pixel with (i + j) % 2 == colour
+// (blockIdx.z = pair of a lockstep group: its own error slots, err_stride doubles apart)
 template <typename T>
 __global__ __launch_bounds__(256) void k_brox_sor(typename Pix<T>::v2 *__restrict__ DU,
                                                   const typename Pix<T>::v4 *__restrict__ CO, const T *__restrict__ Dm,
                                                   const T *__restrict__ Psis, double *__restrict__ err, int k, int nx,
-                                                  int ny, int colour, double alpha, double tol)
+                                                  int ny, int colour, double alpha, double tol, int err_stride)
 {
+    const size_t go = (size_t) blockIdx.z * nx * ny;
+    DU += go; CO += go; Dm += go; Psis += go;
+    err += (size_t) blockIdx.z * err_stride;
     const double prev = loop_fetch_prev(err, k);
     const int i = blockIdx.y * 4 + threadIdx.y;
     const int j = 2 * (blockIdx.x * 64 + threadIdx.x) + ((i + colour) & 1);
@@ -1742,6 +1746,9 @@ template <typename T> struct BroxLevel {
     v2 *DUs, *Snap;
     v4 *COs;
     T  *Dms, *Psiss;
+    v2 *DUb = nullptr;    // tolerance mode (k_brox_wave): band-skewed copies of DU, CO, Dm, psi_s, allocated on first use
+    v4 *COb = nullptr;
+    T  *Dmb = nullptr, *Psb = nullptr;
     T  *Expo = nullptr;   // robust_expo: the smoothness weight of the level (allocated when needed)
     int snap_planes;
     int sweep_hint;
@@ -1839,8 +1846,12 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
     const dim3 gc(ofx_cdiv(ofx_cdiv(nx, 2) + 1, 64), ofx_cdiv(ny, 4));
     if ((long long) npix * G >= (1LL << 31)) return ofx_fail(ctx, OFX_ERR_ARG, "brox: group larger than 2^31 pixels");
     const bool windowed = ctx->sor_exact == 1 && nx >= 3 && ny >= 3;
-    if (G > 1 && !windowed)
-        return ofx_fail(ctx, OFX_ERR_ARG, "brox: lockstep groups need sor_exact = 1 and levels of at least 3x3 (%dx%d)", nx, ny);
+    // tolerance mode (sor_exact = 0, ofx_sor_tile.hip): the finest levels sweep a checkerboard of tiles in the reference's order
+    // inside a tile, the coarser ones red-black; both serve lockstep groups
+    const bool tol_mode = ctx->sor_exact == 0 && ctx->sor_fuse >= 0 && !P.robust;
+    const bool wave = tol_mode && scale < ctx->sor_wave_levels;
+    if (G > 1 && !windowed && !tol_mode)
+        return ofx_fail(ctx, OFX_ERR_ARG, "brox: lockstep groups need sor_exact = 1 (levels of at least 3x3, this one %dx%d) or the tile sweeps of sor_exact = 0", nx, ny);
     int solve = 0;
     const int rx = P.robust;
     if (rx && (!windowed || G != 1))
@@ -1861,7 +1872,23 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
             double error[OFX_MAX_GROUP];
             for (int q = 0; q < G; q++) error[q] = 1000;                                          // :312
             float ms = 0.f;
-            if (windowed) {
+            if (wave) {
+                // band-skewed copies of DU, CO, Dm, psi_s (k_brox_wave)
+                const size_t ps = ofx_band_plane_elems(nx, ny);
+                if (!L.DUb) {
+                    OFX_TRY(ofx_alloc(ctx, ps * G, &L.DUb));
+                    OFX_TRY(ofx_alloc(ctx, ps * G, &L.COb));
+                    OFX_TRY(ofx_alloc(ctx, ps * G, &L.Dmb));
+                    OFX_TRY(ofx_alloc(ctx, ps * G, &L.Psb));
+                }
+                OFX_TRY((ofx_band_copy<typename Pix<T>::v2, true>(ctx, L.DU, L.DUb, nx, ny, G)));
+                OFX_TRY((ofx_band_copy<typename Pix<T>::v4, true>(ctx, L.CO, L.COb, nx, ny, G)));
+                OFX_TRY((ofx_band_copy<T, true>(ctx, L.Dm, L.Dmb, nx, ny, G)));
+                OFX_TRY((ofx_band_copy<T, true>(ctx, L.Psis, L.Psb, nx, ny, G)));
+                OFX_TRY(ofx_brox_wave_solve<T>(ctx, G, L.DUb, L.COb, (const T *) L.Dmb, (const T *) L.Psb, nx, ny, P.alpha, P.TOL,
+                                               OFX_BROX_MAX_ITERATIONS, nsor, error, ctx->profile ? &ms : nullptr));
+                OFX_TRY((ofx_band_copy<typename Pix<T>::v2, false>(ctx, L.DUb, L.DU, nx, ny, G)));
+            } else if (windowed) {
                 // the sweeps run on hyperplane-major copies of DU, CO, Dm, psi_s
                 const size_t ps = skew_plane_elems(nx, ny, BROX_PLANE_C_SKEW);
                 const size_t ub = ps * sizeof(typename Pix<T>::v2);
@@ -1964,14 +1991,16 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
                 LS.chunk = sor_pick_chunk(ctx, nx, ny, 2);
                 LS.fixed = ctx->fixed_work != 0;
                 LS.pairs = false;
+                const int err_stride = (LS.max_iter + 1) * OFX_NSHARD;
+                const dim3 gcg(gc.x, gc.y, G);
                 auto launch = [&](int k, int, double thr) -> int {
                     for (int col = 0; col < 2; col++)
-                        hipLaunchKernelGGL(k_brox_sor<T>, gc, b, 0, ctx->stream, L.DU, L.CO, (const T *) L.Dm,
-                                           (const T *) L.Psis, ctx->d_err, k, nx, ny, col, P.alpha, thr);
+                        hipLaunchKernelGGL(k_brox_sor<T>, gcg, b, 0, ctx->stream, L.DU, L.CO, (const T *) L.Dm,
+                                           (const T *) L.Psis, ctx->d_err, k, nx, ny, col, P.alpha, thr, err_stride);
                     OFX_LAUNCH_CHECK(ctx);
                     return OFX_OK;
                 };
-                OFX_TRY(ofx_run_loop(ctx, LS, launch, [](int) { return OFX_OK; }, &nsor[0], &error[0], ctx->profile ? &ms : nullptr));
+                OFX_TRY(ofx_run_loop_group(ctx, LS, G, launch, [](const int *) { return OFX_OK; }, nsor, error, ctx->profile ? &ms : nullptr));
             }
             if (P.verbose && G == 1) {                                                            // :392-394 / robust :414-416
                 if (rx) printf("Iterations: %d Error: %g\n", nsor[0], error[0]);

@@ -14,3 +14,12 @@ template <typename T>
 int ofx_hs_tile_solve(ofx_ctx *ctx, int G, typename Pix<T>::v2 *U0, typename Pix<T>::v2 *U1, unsigned *cur,
                       const typename Pix<T>::v2 *A, const T *Dif, int nx, int ny, double alpha2, double TOL, int maxiter, int K,
                       int *niter, double *error, float *ms);
+
+// Brox, checkerboard of 64-row tiles with the reference's order inside a tile (ofx_sor_tile.hip, k_brox_wave), on BAND-SKEWED
+// planes: ofx_band_plane_elems(nx, ny) elements per pair and plane, converted from / to row-major by ofx_band_copy<V, IN>
+// (IN = true: row-major -> band).  DUb is updated in place.
+size_t ofx_band_plane_elems(int nx, int ny);
+template <typename V, bool IN> int ofx_band_copy(ofx_ctx *ctx, const V *src, V *dst, int nx, int ny, int G);
+template <typename T>
+int ofx_brox_wave_solve(ofx_ctx *ctx, int G, typename Pix<T>::v2 *DUb, const typename Pix<T>::v4 *COb, const T *Dmb, const T *Psb,
+                        int nx, int ny, double alpha, double TOL, int maxiter, int *niter, double *error, float *ms);

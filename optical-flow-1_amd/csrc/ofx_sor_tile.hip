@@ -451,3 +451,236 @@ template int ofx_hs_tile_solve<double>(ofx_ctx *, int, double2 *, double2 *, uns
                                        double, int, int, int *, double *, float *);
 template int ofx_hs_tile_solve<float>(ofx_ctx *, int, float2 *, float2 *, unsigned *, const float2 *, const float *, int, int, double,
                                       double, int, int, int *, double *, float *);
+
+// ============================================================================================================================
+// Brox (src/brox_optic_flow_spatial.cpp:129-172,315-390): checkerboard of tiles, the reference's order inside a tile
+// ============================================================================================================================
+// Red-black sweeps of the 5-point stencil end BASELINE config 4 at AEPE 1.3e-4 from the reference -- over the 1e-4 bar.  The
+// solves stop long before they converge (the flow moves by 1.8e-4 when TOL is tightened tenfold), so what a truncated solve
+// returns depends on the DIRECTION in which a sweep carries information, and a red-black sweep has none.  What keeps the
+// trajectory is to stay lexicographic locally: the image is cut into tiles of 64 rows x TW columns, coloured as a checkerboard;
+// a sweep updates the tiles of colour 0, then those of colour 1, each tile in the reference's row-major order, in place -- a
+// consistent Gauss-Seidel ordering (every pair of neighbouring pixels has a definite first), so omega = 1.9 stays stable
+// (Jacobi coupling across tile borders diverges).  AEPE against the reference at config 4: 1.1e-5 (the reference's own
+// 1-vs-16-thread spread is 2.7e-5); oracle order 3 restates the schedule and is reproduced bit for bit.
+//
+// k_brox_wave: ONE WAVE PER TILE, lane r = row r of the tile's band, marching over the anti-diagonals h = r + j -- lane r
+// updates pixel (r, h - r) at step h.  Row-major order only constrains "up and left first", and on an anti-diagonal nobody is
+// up or left of anybody, so the steps are the reference's order.  The up neighbour's new value comes from lane r - 1's result of
+// the previous step (one wave shift), the left neighbour's from the lane's own; right and down are old values: the lane's own
+// next operand and lane r + 1's.  Nothing is read that this launch writes (tiles of the other colour are stable), so the
+// operands are prefetched P steps ahead into a register queue and the update is the only dependent chain.
+// Band-skewed storage: element (i, j) of a plane lives at band(i) * BS + (i % 64 + j) * 64 + i % 64, so that the 64 pixels of
+// an anti-diagonal of a band are 64 consecutive elements -- every access of the wave is one contiguous run.  (Row-major, every
+// lane would sit in its own cache line: the layout problem of the exact windows, ofx_sor.hip LaySkew.)  The rows above and
+// below the band are other bands: two single-lane loads per step.
+#define BRW_SOR_W 1.9                // src/brox_optic_flow_spatial.cpp:25
+
+size_t ofx_band_plane_elems(int nx, int ny) { return (size_t) ((ny + 63) / 64) * (size_t) (nx + 64) * 64; }
+
+// row-major <-> band-skewed copies of one array of a lockstep group (blockIdx.z = pair)
+template <typename V, bool IN>
+__global__ void k_band(const V *__restrict__ src, V *__restrict__ dst, int nx, int ny, size_t plane)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= ny) return;
+    const size_t rm = (size_t) blockIdx.z * nx * ny + (size_t) i * nx + j;
+    const size_t bd = blockIdx.z * plane + (size_t) (i >> 6) * (size_t) (nx + 64) * 64 + (size_t) ((i & 63) + j) * 64 + (i & 63);
+    if (IN) dst[bd] = src[rm];
+    else dst[rm] = src[bd];
+}
+template <typename V, bool IN> int ofx_band_copy(ofx_ctx *ctx, const V *src, V *dst, int nx, int ny, int G)
+{
+    hipLaunchKernelGGL((k_band<V, IN>), dim3(ofx_cdiv(nx, 64), ofx_cdiv(ny, 4), G), dim3(64, 4), 0, ctx->stream, src, dst, nx, ny,
+                       ofx_band_plane_elems(nx, ny));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "band copy launch failed: %s", hipGetErrorString(e));
+    return OFX_OK;
+}
+template int ofx_band_copy<double2, true>(ofx_ctx *, const double2 *, double2 *, int, int, int);
+template int ofx_band_copy<double2, false>(ofx_ctx *, const double2 *, double2 *, int, int, int);
+template int ofx_band_copy<double4, true>(ofx_ctx *, const double4 *, double4 *, int, int, int);
+template int ofx_band_copy<double, true>(ofx_ctx *, const double *, double *, int, int, int);
+template int ofx_band_copy<float2, true>(ofx_ctx *, const float2 *, float2 *, int, int, int);
+template int ofx_band_copy<float2, false>(ofx_ctx *, const float2 *, float2 *, int, int, int);
+template int ofx_band_copy<float4, true>(ofx_ctx *, const float4 *, float4 *, int, int, int);
+template int ofx_band_copy<float, true>(ofx_ctx *, const float *, float *, int, int, int);
+
+// operands of one anti-diagonal of a tile, as prefetched: own (du, dv), (Au, Av, Du, Dv), D, psi_s
+struct BrwSlot {
+    double2 du;
+    double4 co;
+    double  dm, ps;
+};
+#define BRW_TW_MAX 128               // columns per tile the edge rows in LDS have room for
+
+// One colour of one sweep (launch k = sweep k; the stopping test of :315 on the error of sweep k - 1).
+// The row above the band and the row below it (other bands, stable during the launch) are gathered once into LDS, (du, dv, psi_s)
+// per column; in the march every fetch is the same five loads for every lane, so the compiler's wait counters stay exact and the
+// queue really is P steps deep.
+template <typename T, int P>
+__global__ __launch_bounds__(256) void k_brox_wave(typename Pix<T>::v2 *DUg, const typename Pix<T>::v4 *__restrict__ COg,
+                                                   const T *__restrict__ Dmg, const T *__restrict__ Psg, double *__restrict__ errg,
+                                                   int k, int nx, int ny, int TW, int ntx, int ntiles, int colour, double alpha,
+                                                   double tol, unsigned runmask, int err_stride, size_t plane)
+{
+    using v2 = typename Pix<T>::v2;
+    using v4 = typename Pix<T>::v4;
+    static_assert(P >= 2, "the right neighbour is the next slot of the queue");
+    __shared__ double4 s_edge[4][2][BRW_TW_MAX];                            // [wave][above / below][column of the tile] = (du, dv, psi_s, -)
+    const int lane = threadIdx.x & 63, wl = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int wv = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * 4)) + wl;
+    const int g = blockIdx.y;
+    if (!((runmask >> g) & 1u)) return;
+    double *__restrict__ err = errg + (size_t) g * err_stride;
+    const double prev = loop_fetch_prev(err, k);
+    if (wv >= ntiles) return;
+    const int b = wv / ntx, t = wv % ntx;
+    if (((b + t) & 1) != colour) return;
+    if (!loop_continues(prev, k, nx * ny, tol, OFX_CRIT_SQRT_MEAN)) return;
+
+    const int nbands = (ny + 63) >> 6;
+    const unsigned BS = (unsigned) (nx + 64) * 64u;                         // elements per band
+    const int nr = ny - b * 64 < 64 ? ny - b * 64 : 64;                     // rows of this band
+    const int r = lane, i = b * 64 + r;
+    const int c0 = t * TW, c1 = c0 + TW < nx ? c0 + TW : nx;               // columns [c0, c1)
+    const size_t boff = (size_t) g * plane + (size_t) b * BS;
+    v2 *DU = DUg + boff;
+    const v4 *__restrict__ CO = COg + boff;
+    const T *__restrict__ Dm = Dmg + boff;
+    const T *__restrict__ Ps = Psg + boff;
+    const bool top = i == 0, bot = i == ny - 1, rowok = r < nr;
+    const bool first = r == 0, last = r == nr - 1;
+
+    // edge rows: pixel (64 b - 1, j) = row 63 of the band above, pixel (64 b + nr, j) = row 0 of the band below
+    double4 (*edge)[BRW_TW_MAX] = s_edge[wl];
+    for (int jj = c0 + lane; jj < c1; jj += 64) {
+        double4 up = make_double4(0.0, 0.0, 0.0, 0.0), dn = up;
+        if (b > 0) {
+            const unsigned e = (unsigned) (63 + jj) * 64u + 63u;
+            const double2 d = ldw2(DU - BS + e);
+            up = make_double4(d.x, d.y, ldw(Ps - BS + e), 0.0);
+        }
+        if (b < nbands - 1) {
+            const unsigned e = (unsigned) jj * 64u;
+            const double2 d = ldw2(DU + BS + e);
+            dn = make_double4(d.x, d.y, ldw(Ps + BS + e), 0.0);
+        }
+        edge[0][jj - c0] = up;
+        edge[1][jj - c0] = dn;
+    }
+    // the column left of the tile: one (strided) load per lane, before the march
+    double2 left_du = make_double2(0.0, 0.0);
+    double left_ps = 0.0;
+    if (c0 > 0 && rowok) {
+        const unsigned e = (unsigned) (r + c0 - 1) * 64u + (unsigned) r;
+        left_du = ldw2(DU + e);
+        left_ps = ldw(Ps + e);
+    }
+    const int h0 = c0, hend = c1 - 1 + nr - 1;                              // anti-diagonals of the tile, inclusive
+    const int hmax = nx + 63;                                               // last anti-diagonal that is storage
+    auto fetch = [&](int hh) -> BrwSlot {
+        const unsigned e = (unsigned) (hh < hmax ? hh : hmax) * 64u + (unsigned) r;
+        BrwSlot s;
+        s.du = ldw2(DU + e);
+        s.co = ldw4(CO + e);
+        s.dm = ldw(Dm + e);
+        s.ps = ldw(Ps + e);
+        return s;
+    };
+    BrwSlot q[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) q[p] = fetch(h0 + p);
+
+    const double w = BRW_SOR_W;
+    const int tw1 = c1 - c0 - 1;                                            // last column index of the edge rows
+    double2 newp = make_double2(0.0, 0.0);                                  // the lane's result of the previous step
+    double psp = 0.0;                                                       // ... and its psi_s there
+    double e = 0.0;
+    for (int hb = h0; hb <= hend; hb += P) {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const int h = hb + p;
+            const BrwSlot s = q[p];
+            const BrwSlot &n = q[(p + 1) % P];                              // anti-diagonal h + 1
+            const int j = h - r;
+            const bool active = rowok && j >= c0 && j < c1 && h <= hend;
+            const bool lef = j == 0, rig = j == nx - 1, edge_col = j == c0;
+            const double2 c = s.du;
+            // lane 0's pixel is in column h, the last lane's in column h - (nr - 1): their rows above / below, from LDS
+            const int ju = h - c0, jd = h - (nr - 1) - c0;
+            const double4 eu = edge[0][ju < 0 ? 0 : (ju > tw1 ? tw1 : ju)], ed = edge[1][jd < 0 ? 0 : (jd > tw1 ? tw1 : jd)];
+            // a missing neighbour is the pixel itself with psi = 0 (:332-388)
+            const double sx = wave_shift_down(n.du.x), sy = wave_shift_down(n.du.y), sp = wave_shift_down(n.ps);
+            const double ux = wave_shift_up(newp.x), uy = wave_shift_up(newp.y), up_ps = wave_shift_up(psp);
+            // (selects on scalars: a ?: on a double2 / double4 goes through a private array, i.e. scratch)
+            const double dnx = bot ? c.x : (last ? ed.x : sx), dny = bot ? c.y : (last ? ed.y : sy);
+            const double upx = top ? c.x : (first ? eu.x : ux), upy = top ? c.y : (first ? eu.y : uy);
+            const double pdn = last ? ed.z : sp, pup = first ? eu.z : up_ps;
+            const double rtx = rig ? c.x : n.du.x, rty = rig ? c.y : n.du.y;
+            const double lfx = lef ? c.x : (edge_col ? left_du.x : newp.x), lfy = lef ? c.y : (edge_col ? left_du.y : newp.y);
+            const double plf = edge_col ? left_ps : psp;
+            const double p1 = bot ? 0.0 : 0.5 * (pdn + s.ps);               // src/brox_spatial_mask.cpp:16-93
+            const double p2 = top ? 0.0 : 0.5 * (pup + s.ps);
+            const double p3 = rig ? 0.0 : 0.5 * (n.ps + s.ps);
+            const double p4 = lef ? 0.0 : 0.5 * (plf + s.ps);
+            const double ru = rcp_newton(s.co.z), rv = rcp_newton(s.co.w);  // off the dependent chain (hst_div)
+            const double div_du = p1 * dnx + p2 * upx + p3 * rtx + p4 * lfx;         // :153-154
+            const double div_dv = p1 * dny + p2 * upy + p3 * rty + p4 * lfy;         // :155-156
+            const double duk = c.x, dvk = c.y;
+            const double dun = tile_rnd<T>((1. - w) * duk + hst_div(w * (s.co.x - s.dm * dvk + alpha * div_du), s.co.z, ru));   // :162
+            const double dvn = tile_rnd<T>((1. - w) * dvk + hst_div(w * (s.co.y - s.dm * dun + alpha * div_dv), s.co.w, rv));   // :163
+            if (active) stn2(DU + ((unsigned) h * 64u + (unsigned) r), make_double2(dun, dvn));
+            e += active ? (dun - duk) * (dun - duk) + (dvn - dvk) * (dvn - dvk) : 0.0;     // :166
+            newp = make_double2(dun, dvn);
+            psp = s.ps;
+            q[p] = fetch(h + P);
+        }
+    }
+    loop_accumulate(err, k, e, wv);
+}
+
+template <typename T>
+int ofx_brox_wave_solve(ofx_ctx *ctx, int G, typename Pix<T>::v2 *DUb, const typename Pix<T>::v4 *COb, const T *Dmb, const T *Psb,
+                        int nx, int ny, double alpha, double TOL, int maxiter, int *niter, double *error, float *ms)
+{
+    if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "brox: group of %d pairs", G);
+    const size_t plane = ofx_band_plane_elems(nx, ny);
+    if ((double) plane * sizeof(typename Pix<T>::v4) >= 4294967296.0)
+        return ofx_fail(ctx, OFX_ERR_ARG, "brox: tile sweeps address a level with 32-bit offsets (%dx%d is too large)", nx, ny);
+    for (int g = 0; g < G; g++) { niter[g] = 0; error[g] = 1000; }                                    // :312
+    if (maxiter <= 0 || !(1000.0 > TOL)) return OFX_OK;
+    const int TW = ctx->sor_tile_w > 0 ? (ctx->sor_tile_w > BRW_TW_MAX ? BRW_TW_MAX : ctx->sor_tile_w) : 64;
+    const int ntx = ofx_cdiv(nx, TW), ntiles = ntx * ((ny + 63) / 64);
+    LoopSpec S;
+    S.max_iter = maxiter;
+    S.size = nx * ny;
+    S.thr = TOL;
+    S.crit = OFX_CRIT_SQRT_MEAN;
+    S.fixed = ctx->fixed_work != 0;
+    S.pairs = false;
+    if (ctx->chunk > 0) S.chunk = ctx->chunk;
+    else {
+        // a sweep = two launches of TW + 63 dependent steps (~0.3 us each)
+        const double est_us = 2.0 * (TW + 63) * 0.3;
+        int c = (int) (120.0 / est_us);
+        S.chunk = c < 2 ? 2 : (c > 16 ? 16 : c);
+    }
+    const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
+    const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
+    const dim3 grid((unsigned) ofx_cdiv(ntiles, 4), G), block(256);
+    auto launch = [&](int k, int, double thr) -> int {
+        for (int col = 0; col < 2; col++)
+            hipLaunchKernelGGL((k_brox_wave<T, 4>), grid, block, 0, ctx->stream, DUb, COb, Dmb, Psb, ctx->d_err, k, nx, ny, TW, ntx, ntiles,
+                               col, alpha, thr, all, err_stride, plane);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "brox wave launch failed: %s", hipGetErrorString(e));
+        return OFX_OK;
+    };
+    return ofx_run_loop_group(ctx, S, G, launch, [](const int *) { return OFX_OK; }, niter, error, ms);
+}
+template int ofx_brox_wave_solve<double>(ofx_ctx *, int, double2 *, const double4 *, const double *, const double *, int, int, double,
+                                         double, int, int *, double *, float *);
+template int ofx_brox_wave_solve<float>(ofx_ctx *, int, float2 *, const float4 *, const float *, const float *, int, int, double, double,
+                                        int, int *, double *, float *);

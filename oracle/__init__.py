@@ -284,7 +284,12 @@ class Oracle(_Lib):
         self._fn("set_sor_colour_levels", None, C.c_uint)(mask & 0xFFFFFFFF)
 
     def set_sor_tile(self, w, h):
+        """Brox order 3: tile size of the checkerboard sweeps (the HIP path: 64 rows x option sor_tile_w columns)."""
         self._fn("set_sor_tile", None, C.c_int, C.c_int)(w, h)
+
+    def set_sor_wave_levels(self, n):
+        """With order 1: Brox levels 0 .. n - 1 are swept as a checkerboard of tiles (order 3) -- the HIP option of that name."""
+        self._fn("set_sor_wave_levels", None, C.c_int)(n)
 
     def set_sor_exact_tail(self, tail):
         """With order 1: the last `tail` solves of the finest level keep the reference's order (the HIP option of that name)."""

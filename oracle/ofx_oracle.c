@@ -641,10 +641,13 @@ static int sor_order_enter_level(int s)
     if (g_sor_order == 1 && s < 32 && !((g_sor_colour_levels >> s) & 1u)) g_sor_order = 0;
     return saved;
 }
-/* order 3 (EXPERIMENT): block-lexicographic -- tiles of g_tile_w x g_tile_h pixels, lexicographic inside a tile, values of
- * the previous sweep across tile borders */
-static int g_tile_w = 64, g_tile_h = 64;
+/* order 3 (Brox; checker aid for the HIP path's tolerance mode, ofx_sor_tile.hip k_brox_wave): the image cut into tiles of
+ * g_tile_w x g_tile_h pixels coloured as a checkerboard; a sweep updates the tiles of colour 0, then those of colour 1, each
+ * tile in row-major order, in place.  With order 1, the Brox levels below g_sor_wave_levels use it (the HIP option
+ * "sor_wave_levels"; 0 = none, the default here). */
+static int g_tile_w = 64, g_tile_h = 64, g_sor_wave_levels = 0;
 void orc_set_sor_tile(int w, int h) { g_tile_w = w; g_tile_h = h; }
+void orc_set_sor_wave_levels(int n) { g_sor_wave_levels = n < 0 ? 0 : n; }
 /* order of solve `k` of `n` at the current level */
 static int sor_order_of_solve(int k, int n)
 {
@@ -1028,6 +1031,7 @@ static void brox_single_scale(const double *I1, const double *I2, double *u, dou
             int nsor = 0;
             const int order_all = g_sor_order;
             g_sor_order = sor_order_of_solve(no * inner_iter + ni, outer_iter * inner_iter);
+            if (g_sor_order == 1 && g_sor_level >= 0 && g_sor_level < g_sor_wave_levels) g_sor_order = 3;
             if (g_sor_order == 2 && nx >= 3 && ny >= 3) {
                 plane_index PI;
                 plane_index_build(&PI, nx, ny, brox_pos);
@@ -1066,7 +1070,7 @@ static void brox_single_scale(const double *I1, const double *I2, double *u, dou
             while (error > TOL && nsor < BROX_MAXITER) {       /* :315 */
                 error = 0;
                 nsor++;
-                if (g_sor_order == 3) {     /* EXPERIMENT: checkerboard of tiles, lexicographic inside a tile, in place */
+                if (g_sor_order == 3) {     /* checkerboard of tiles, row-major inside a tile, in place */
                     for (int col = 0; col < 2; col++)
                         for (int ti = 0; ti < ny; ti += g_tile_h)
                             for (int tj = 0; tj < nx; tj += g_tile_w) {

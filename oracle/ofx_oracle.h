@@ -70,6 +70,9 @@ void orc_set_sor_order(int order);
 void orc_set_sor_colour_levels(unsigned mask);
 /* with order 1: the last `tail` solves (warps / outer x inner iterations) of level 0 keep the reference's order (default 0) */
 void orc_set_sor_exact_tail(int tail);
+/* Brox, order 3 / order 1 below `levels`: checkerboard of w x h tiles, row-major inside a tile (the HIP path's tolerance mode) */
+void orc_set_sor_tile(int w, int h);
+void orc_set_sor_wave_levels(int levels);
 void orc_set_plane_batch(int sweeps_in_flight);
 
 /* horn_schunck_pyramidal.cpp */

@@ -60,6 +60,8 @@ for name, (nx, ny), bpp, kw in CONFIGS:
                           "algorithmic_gbs": round(mps * bpp / 1e3, 1), "frac_of_hbm_peak": round(mps * bpp / 8e6, 4)}), flush=True)
         if check and (nctx, G) == GRID[-1]:
             solo = ofx.Ofx(0, ofx.F64)
+            for o in OPTS:
+                solo.set_option(o.split("=")[0], float(o.split("=")[1]))
             one = torch.empty((ny, nx, 2), dtype=torch.float32, device=dev)
             gfn = solo.hs_group_dev if name.startswith("hs") else solo.brox_group_dev
             bad = 0
