@@ -89,6 +89,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->sor_tile = 0;
     ctx->sor_tile_w = 0;
     ctx->sor_wave_levels = 1;
+    ctx->sor_wave_p = 0;
     ctx->sor_window = 0;
     ctx->sor_rows = 0;
     ctx->sor_spw = 0;
@@ -206,6 +207,11 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "sor_tile_w")) {
         if (value < 0 || value > 65536) return ofx_fail(ctx, OFX_ERR_ARG, "sor_tile_w out of range");
         ctx->sor_tile_w = (int) value;
+        return OFX_OK;
+    }
+    if (!strcmp(name, "sor_wave_p")) {
+        if (value < 0 || value > 8) return ofx_fail(ctx, OFX_ERR_ARG, "sor_wave_p out of range");
+        ctx->sor_wave_p = (int) value;
         return OFX_OK;
     }
     if (!strcmp(name, "sor_wave_levels")) {

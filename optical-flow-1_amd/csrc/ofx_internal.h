@@ -85,7 +85,8 @@ struct ofx_ctx {
     int sor_fuse;       // sor_exact = 0: K sweeps per launch on LDS tiles (ofx_sor_tile.hip): 0 = automatic (default), 1..4 = K,
                         // -1 = one launch per colour and sweep (k_hs_sor / k_brox_sor; single pairs only)
     int sor_tile;       // tile geometry of the sor_exact = 0 sweeps (0 = default; ofx_sor_tile.hip)
-    int sor_tile_w;     // Brox, sor_exact = 0: columns per tile of the checkerboard sweeps (0 = 64)
+    int sor_tile_w;     // Brox, sor_exact = 0: columns per tile of the checkerboard sweeps (0 = 128, the maximum)
+    int sor_wave_p;     // ... anti-diagonals of operand prefetch in k_brox_wave (0 = 4)
     int sor_wave_levels;// Brox, sor_exact = 0: pyramid levels 0 .. n - 1 use the checkerboard-of-tiles sweeps, the coarser ones red-black (default 1)
     int sor_batch;      // sweeps in flight per batch in exact mode (0 = default)
     int sor_window;     // time steps per launch of the windowed exact mode (0 = 8)

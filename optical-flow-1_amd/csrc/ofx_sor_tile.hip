@@ -651,7 +651,7 @@ int ofx_brox_wave_solve(ofx_ctx *ctx, int G, typename Pix<T>::v2 *DUb, const typ
         return ofx_fail(ctx, OFX_ERR_ARG, "brox: tile sweeps address a level with 32-bit offsets (%dx%d is too large)", nx, ny);
     for (int g = 0; g < G; g++) { niter[g] = 0; error[g] = 1000; }                                    // :312
     if (maxiter <= 0 || !(1000.0 > TOL)) return OFX_OK;
-    const int TW = ctx->sor_tile_w > 0 ? (ctx->sor_tile_w > BRW_TW_MAX ? BRW_TW_MAX : ctx->sor_tile_w) : 64;
+    const int TW = ctx->sor_tile_w > 0 ? (ctx->sor_tile_w > BRW_TW_MAX ? BRW_TW_MAX : ctx->sor_tile_w) : BRW_TW_MAX;
     const int ntx = ofx_cdiv(nx, TW), ntiles = ntx * ((ny + 63) / 64);
     LoopSpec S;
     S.max_iter = maxiter;
@@ -670,10 +670,18 @@ int ofx_brox_wave_solve(ofx_ctx *ctx, int G, typename Pix<T>::v2 *DUb, const typ
     const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
     const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
     const dim3 grid((unsigned) ofx_cdiv(ntiles, 4), G), block(256);
+    const int P = ctx->sor_wave_p > 0 ? ctx->sor_wave_p : 4;                // steps of prefetch (option "sor_wave_p": 2 | 4 | 6 | 8)
     auto launch = [&](int k, int, double thr) -> int {
-        for (int col = 0; col < 2; col++)
-            hipLaunchKernelGGL((k_brox_wave<T, 4>), grid, block, 0, ctx->stream, DUb, COb, Dmb, Psb, ctx->d_err, k, nx, ny, TW, ntx, ntiles,
-                               col, alpha, thr, all, err_stride, plane);
+        for (int col = 0; col < 2; col++) {
+#define BRW_GO(P_)                                                                                                             \
+    hipLaunchKernelGGL((k_brox_wave<T, P_>), grid, block, 0, ctx->stream, DUb, COb, Dmb, Psb, ctx->d_err, k, nx, ny, TW, ntx, ntiles, \
+                       col, alpha, thr, all, err_stride, plane)
+            if (P <= 2) BRW_GO(2);
+            else if (P <= 4) BRW_GO(4);
+            else if (P <= 6) BRW_GO(6);
+            else BRW_GO(8);
+#undef BRW_GO
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "brox wave launch failed: %s", hipGetErrorString(e));
         return OFX_OK;

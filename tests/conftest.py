@@ -56,6 +56,10 @@ def orc(_orc_session):
     so both are reset before every test."""
     _orc_session.set_num_threads(1)
     _orc_session.set_sor_order(0)
+    _orc_session.set_sor_colour_levels(0xFFFFFFFF)
+    _orc_session.set_sor_exact_tail(0)
+    _orc_session.set_sor_tile(128, 64)
+    _orc_session.set_sor_wave_levels(0)
     return _orc_session
 
 

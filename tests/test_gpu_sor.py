@@ -42,9 +42,11 @@ def colour_orc(orc, gpu64):
     """oracle AND GPU context both in colour-order mode"""
     orc.set_sor_order(1)
     gpu64.set_option("sor_exact", 0)
+    gpu64.set_option("sor_fuse", -1)        # the one-launch-per-colour kernels; the tile sweeps: tests/test_gpu_sor_tile.py
     yield orc
     orc.set_sor_order(0)
     gpu64.set_option("sor_exact", 1)
+    gpu64.set_option("sor_fuse", 0)
 
 
 @pytest.mark.parametrize("pair,nx,ny,warps", [("P0", 64, 48, 4), ("P1", 135, 68, 3), ("P1", 33, 47, 4), ("P1", 9, 8, 2)])
@@ -443,9 +445,12 @@ def test_sor_batch_entry_points(ofx_mod, synth):
         c.close()
 
 
-def test_sor_groups_need_the_exact_mode(ofx_mod, gpu64, synth):
+def test_sor_groups_need_the_exact_mode_or_the_tile_sweeps(ofx_mod, gpu64, synth):
+    """the one-launch-per-colour kernels (sor_exact = 0, sor_fuse = -1) serve single pairs only; groups in the tolerance
+    mode's tile sweeps: tests/test_gpu_sor_tile.py"""
     pairs, d0, d1, flo = _group_inputs(synth, 2, 64, 48)
     gpu64.set_option("sor_exact", 0)
+    gpu64.set_option("sor_fuse", -1)
     try:
         with pytest.raises(ofx_mod.OfxError) as e:
             gpu64.hs_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1], [flo[k].data_ptr() for k in range(2)],
@@ -453,6 +458,7 @@ def test_sor_groups_need_the_exact_mode(ofx_mod, gpu64, synth):
         assert e.value.status == 1
     finally:
         gpu64.set_option("sor_exact", 1)
+        gpu64.set_option("sor_fuse", 0)
     with pytest.raises(ofx_mod.OfxError):
         gpu64.brox_group_dev([], [], [], 64, 48)
 
