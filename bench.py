@@ -22,7 +22,7 @@ own stream) while round r + 1 computes, so only the last round's transfer is exp
 The line also carries: `fixed_work` (option "fixed_work": every warp runs exactly 300 iterations, SURVEY 8d);
 `roofline` / `roofline_4k` for the dominant kernel k_tvl1_iter2 as the job launches it (one launch = a lockstep group of
 up to 16 pairs), measured on fixed-work passes with HIP events on the library's own stream, with the one-pair launch beside
-it (`single_pair`); `sor` (BASELINE configs 3 / 4: exact Horn-Schunck and Brox solves); `occ` (TV-L1 with occlusions); `cpu_baseline` (the compiled
+it (`single_pair`); `sor` (BASELINE configs 3 / 4: Horn-Schunck and Brox solves, exact and tolerance mode); `occ` (TV-L1 with occlusions); `cpu_baseline` (the compiled
 reference, oracle/_ref, on the host cores; rank 0 at N = 1 only).
 """
 import argparse
@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-other-mode", action="store_true", help="skip the leg that repeats the timed command in the other f64 mode")
     ap.add_argument("--no-single", action="store_true", help="skip the single_pair leg (one pair at a time, device-resident and host entry)")
     ap.add_argument("--no-sor", action="store_true", help="skip the sor leg (BASELINE configs 3 / 4)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the cli leg (end-to-end time of bin/tvl1flow in a fresh process)")
     ap.add_argument("--no-occ", action="store_true", help="skip the occ leg (TV-L1 with occlusions, SURVEY 8f.1)")
     ap.add_argument("--lockstep", type=int, default=0,
                     help="pairs per lockstep group (they share every kernel launch of one context); 0 = the library's choice")
@@ -205,6 +206,16 @@ def cpu_baseline(synth, nx, ny, pair, gpu_flows=None):
     return out
 
 
+def kernel_source_sha16():
+    """hash of the sources the TV-L1 iteration kernels are compiled from: stored with the counter passes (tools/pmc_summary_r03.py),
+    compared here -- counters collected on other kernel sources are reported as stale, not silently reused"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ofx_tvl1.hip", "ofx_device.h", "ofx_loop.h"):
+        h.update(open(os.path.join(ROOT, "optical-flow-1_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc():
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -305,16 +316,24 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None, mode="str
                                "note": "the same kernel launched for one pair alone: start-up and drain of every launch exposed "
                                        "(at 1080p one pair is 2880 waves, less than one round of the 3072 wave slots)"}
     pmc = load_pmc()
-    # round-3 counter passes on the group launches, per f64 mode (tools/pmc_round3.sh): preferred when they cover this launch
-    try:
-        r3 = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_group_launches.json"))).get(
-            "%dx%d_group%d_%s%s" % (nx, ny, G, mode, "_iter3" if F == 3 else ""))
-    except Exception:
-        r3 = None
+    # counter passes on the group launches, per f64 mode (tools/pmc_round3.sh): preferred when they cover this launch; the newest
+    # collection wins, and its source hash says whether it was taken on the kernels this run executes
+    r3, pmc_file, pmc_sha = None, None, None
+    for cand in ("r04_pmc_group_launches.json", "r03_pmc_group_launches.json"):
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", cand)))
+        except Exception:
+            continue
+        r3 = j.get("%dx%d_group%d_%s%s" % (nx, ny, G, mode, "_iter3" if F == 3 else ""))
+        if r3:
+            pmc_file, pmc_sha = cand, j.get("kernel_source_sha16")
+            break
     if r3 and precision == "f64":
         roof["traffic"] = r3["bytes_per_launch"]
-        roof["traffic_source"] = ("profiles/r03_pmc_group_launches.json (builder-run rocprofv3 --pmc passes on the same launch shape and "
-                                  "mode, FETCH_SIZE doubled per MI355X_MICROARCH.md; not measured by this run)")
+        roof["traffic_stale"] = pmc_sha != kernel_source_sha16()
+        roof["traffic_source"] = ("profiles/%s (builder-run rocprofv3 --pmc passes on the same launch shape and "
+                                  "mode, FETCH_SIZE doubled per MI355X_MICROARCH.md; not measured by this run; kernel sources at "
+                                  "collection %s, now %s)" % (pmc_file, pmc_sha, kernel_source_sha16()))
         roof["hbm_frac_counter"] = round(r3["bytes_per_launch"] / (us_launch * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         roof["traffic_over_compulsory"] = round(r3["traffic_over_fused_compulsory"], 4)
         roof["valu_active"] = round(r3["valu_active_fraction"], 3)
@@ -356,12 +375,17 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None, mode="str
     return roof, levels, work, secs
 
 
-def sor_leg(ofx_mod, synth, local, dev):
-    """BASELINE configs 3 and 4 (parity-test cases, not the headline): exact-order Horn-Schunck 1920x1080 and Brox
-    1280x720.  `one_pair`: one solve through the host entry point (the reference's calling convention, host arrays in /
-    out).  `batch`: 48 device-resident pairs (P0 + 47 P1 variants) through ofx_hs_batch_dev / ofx_brox_batch_dev, lockstep
-    groups of 16 pairs on 3 contexts (measured: 2 x 16 28.8k / 22.7k, 3 x 16 35.1k / 27.5k, 4 x 16 27.0k / 23.9k Mpix*sweeps/s,
-    profiles/r03_u_sor_batches_contexts_x_groups.txt); every flow is bit-identical to the pair solved alone (tests/test_gpu_sor.py).
+def sor_leg(ofx_mod, synth, local, dev, with_cpu=True):
+    """BASELINE configs 3 and 4 (parity-test cases, not the headline): Horn-Schunck 1920x1080 and Brox 1280x720, in both modes
+    of the library.  `exact` (the default; also at the top level of each entry, where round 3 had it): the reference's sweep
+    order, bit-identical to the reference.  `tolerance` (option sor_exact = 0, csrc/ofx_sor_tile.hip): re-ordered sweeps inside
+    north_star's bar (AEPE < 1e-4 against the reference) -- Horn-Schunck four-colour sweeps, K per launch on LDS tiles; Brox a
+    checkerboard of tiles swept in the reference's order on the finest level, red-black below -- with the AEPE and max |delta|
+    of pair P0 against the reference run of the same pair on this host (one thread: the reference's only deterministic
+    configuration) and, beside it, the reference's own 1-vs-8-thread spread on that pair.
+    `one_pair`: one solve through the host entry point (the reference's calling convention, host arrays in / out).  `batch`: 48
+    device-resident pairs (P0 + 47 P1 variants) through ofx_hs_batch_dev / ofx_brox_batch_dev, lockstep groups of 16 pairs on 3
+    contexts; every flow is bit-identical to the pair solved alone (tests/test_gpu_sor.py, tests/test_gpu_sor_tile.py).
     Algorithmic bytes per sweep: 56 B/px (HS), 80 B/px (Brox) -- SURVEY 8(d)."""
     import torch
     out = {}
@@ -370,10 +394,15 @@ def sor_leg(ofx_mod, synth, local, dev):
     for c in ctxs:
         c.set_option("lockstep", 16)
     NB = 48
-    for name, host_fn, batch_fn, size, bpp, kw in (
-            ("hs_cfg3", solo.hs_pyramidal, ofx_mod.hs_batch_dev, (1920, 1080), 56.0,
+    ref = None
+    if with_cpu:
+        import oracle
+        if oracle.have_ref():
+            ref = oracle.Ref()
+    for name, host_fn, batch_fn, ref_name, size, bpp, kw in (
+            ("hs_cfg3", solo.hs_pyramidal, ofx_mod.hs_batch_dev, "hs_pyramidal", (1920, 1080), 56.0,
              dict(alpha=20.0, nscales=5, zfactor=0.5, warps=10, TOL=1e-4, maxiter=150)),
-            ("brox_cfg4", solo.brox_spatial, ofx_mod.brox_batch_dev, (1280, 720), 80.0,
+            ("brox_cfg4", solo.brox_spatial, ofx_mod.brox_batch_dev, "brox_spatial", (1280, 720), 80.0,
              dict(alpha=50.0, gamma=10.0, nscales=6, nu=0.5, TOL=1e-4, inner=1, outer=15))):
         nx, ny = size
 
@@ -384,33 +413,109 @@ def sor_leg(ofx_mod, synth, local, dev):
             r.update(extra)
             return r
         I1, I2 = synth.pair("P0", nx, ny)
-        res = host_fn(I1, I2, **kw)                      # warm (arena, clocks, result planes)
-        reps = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            host_fn(I1, I2, out=res, **kw)
-            reps.append(time.perf_counter() - t0)
-        dt = sorted(reps)[1]                             # median of three (single solves vary by ~10 % from run to run)
-        st = solo.stats()
-        one = rec(st.work_pix_iters, dt, {"sweeps": int(st.iterations().sum()), "pair": "P0, host arrays in/out",
-                                          "repetitions": [round(r_, 4) for r_ in reps]})
         ins = [synth.pair_device("P0" if k == 0 else "P1", nx, ny, k, dev) for k in range(NB)]
         flo = torch.empty((NB, ny, nx, 2), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         args = ([t[0].data_ptr() for t in ins], [t[1].data_ptr() for t in ins], [flo[k].data_ptr() for k in range(NB)], nx, ny)
-        batch_fn(ctxs, *args, **kw)                      # warm
-        t0 = time.perf_counter()
-        work = batch_fn(ctxs, *args, **kw)
-        dt = time.perf_counter() - t0
-        out[name] = {"size": "%dx%d" % size, "bytes_per_pixel_sweep": bpp,
-                     "mode": "exact (reference sweep order, bit-identical to the reference)",
-                     "one_pair": one,
-                     "batch": rec(sum(work), dt, {"pairs": NB, "contexts": len(ctxs), "lockstep_group": 16, "ms_per_pair": round(dt / NB * 1e3, 2),
-                                                  "pairs_desc": "P0 + 47 P1 variants, device-resident"})}
+        modes = {}
+        flows = {}
+        for mode, exact in (("exact", 1), ("tolerance", 0)):
+            for c in ctxs + [solo]:
+                c.set_option("sor_exact", exact)
+            res = host_fn(I1, I2, **kw)                      # warm (arena, clocks, result planes)
+            reps = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                host_fn(I1, I2, out=res, **kw)
+                reps.append(time.perf_counter() - t0)
+            dt = sorted(reps)[1]                             # median of three (single solves vary by ~10 % from run to run)
+            st = solo.stats()
+            flows[mode] = (res[0].copy(), res[1].copy())
+            one = rec(st.work_pix_iters, dt, {"sweeps": int(st.iterations().sum()), "pair": "P0, host arrays in/out",
+                                              "repetitions": [round(r_, 4) for r_ in reps]})
+            batch_fn(ctxs, *args, **kw)                      # warm
+            t0 = time.perf_counter()
+            work = batch_fn(ctxs, *args, **kw)
+            dt = time.perf_counter() - t0
+            modes[mode] = {"one_pair": one,
+                           "batch": rec(sum(work), dt, {"pairs": NB, "contexts": len(ctxs), "lockstep_group": 16,
+                                                        "ms_per_pair": round(dt / NB * 1e3, 2),
+                                                        "pairs_desc": "P0 + 47 P1 variants, device-resident"})}
+        for c in ctxs + [solo]:
+            c.set_option("sor_exact", 1)
+        modes["exact"]["mode"] = "exact (reference sweep order, bit-identical to the reference)"
+        modes["tolerance"]["mode"] = ("sor_exact = 0: " + ("four-colour sweeps, 2 per launch on LDS tiles (k_hs_tile)" if name.startswith("hs") else
+                                      "finest level: checkerboard of 64 x 128 tiles, the reference's order inside a tile (k_brox_wave); coarser levels red-black"))
+        if ref is not None:
+            fn = getattr(ref, ref_name)
+            ref.set_num_threads(1)
+            t0 = time.perf_counter()
+            r1 = fn(I1, I2, **kw)
+            t1 = time.perf_counter() - t0
+            ref.set_num_threads(8)
+            t0 = time.perf_counter()
+            r8 = fn(I1, I2, **kw)
+            t8 = time.perf_counter() - t0
+            ref.set_num_threads(1)
+
+            def cmp(a_, b_):
+                return {"aepe": float(np.mean(np.hypot(a_[0] - b_[0], a_[1] - b_[1]))),
+                        "max_abs": float(max(np.abs(a_[0] - b_[0]).max(), np.abs(a_[1] - b_[1]).max()))}
+            for mode in modes:
+                modes[mode]["vs_reference_one_thread"] = dict(cmp(flows[mode], r1), pair="P0", tolerance_aepe=1e-4)
+            modes["tolerance"]["reference_8_threads_vs_1"] = dict(cmp(r8, r1), pair="P0",
+                                                                  note="the reference's own spread: its in-place sweeps race under OpenMP")
+            modes["tolerance"]["reference_seconds"] = {"threads_1": round(t1, 3), "threads_8": round(t8, 3)}
+        out[name] = {"size": "%dx%d" % size, "bytes_per_pixel_sweep": bpp}
+        out[name].update(modes["exact"])                     # the default mode at the top level, as in round 3
+        out[name]["tolerance"] = modes["tolerance"]
         del ins, flo
     for c in ctxs + [solo]:
         c.close()
     return out
+
+
+def cli_leg(synth, local):
+    """What `bin/tvl1flow a.pgm b.pgm out.flo` costs end to end (src/tvl1flow_main.cpp:177-214): a FRESH process per run -- dynamic
+    loading, HIP initialisation, context, arena, PGM read, solve, .flo write, teardown -- on the 1080p pair P1 with the headline's
+    parameters (strict mode, the front-end's default), images and output on tmpfs.  wall = perf_counter around the child;
+    `phases_ms` from the front-end's own clock (OFX_STATS); `outside_main_ms` = wall - the phases = loader + exit."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "optical-flow-1_amd", "bin", "tvl1flow")
+    if not os.path.exists(exe):
+        return {"error": "bin/tvl1flow not built"}
+    nx, ny = 1920, 1080
+    I0, I1 = synth.pair("P1", nx, ny)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=base) as d:
+        for name, img in (("a.pgm", I0), ("b.pgm", I1)):
+            with open(os.path.join(d, name), "wb") as f:
+                f.write(b"P5\n%d %d\n255\n" % (nx, ny))
+                f.write(np.clip(img, 0, 255).astype(np.uint8).tobytes())
+        env = dict(os.environ, OFX_DEVICE=str(local), OFX_STATS=os.path.join(d, "stats.json"))
+        args = [exe, os.path.join(d, "a.pgm"), os.path.join(d, "b.pgm"), os.path.join(d, "out.flo"), "0", str(PAR["tau"]), str(PAR["lam"]),
+                str(PAR["theta"]), str(PAR["nscales"]), str(PAR["zfactor"]), str(PAR["warps"]), str(PAR["epsilon"]), "0"]
+        runs = []
+        for _ in range(4):                                   # the first run also pages the binaries in: reported, not used for the median
+            t0 = time.perf_counter()
+            r = subprocess.run(args, env=env, capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if r.returncode:
+                return {"error": "tvl1flow exited %d: %s" % (r.returncode, r.stderr[-300:])}
+            st = json.load(open(os.path.join(d, "stats.json")))
+            runs.append((wall, st))
+        flo_bytes = os.path.getsize(os.path.join(d, "out.flo"))
+    warm = sorted(runs[1:], key=lambda x: x[0])
+    wall, st = warm[len(warm) // 2]
+    ph = st.get("phases_ms", {})
+    return {"program": "bin/tvl1flow a.pgm b.pgm out.flo 0 %g %g %g %d %g %d %g 0" % (PAR["tau"], PAR["lam"], PAR["theta"], PAR["nscales"],
+                                                                                      PAR["zfactor"], PAR["warps"], PAR["epsilon"]),
+            "pair": "P1 1920x1080, 8-bit PGM on tmpfs", "wall_s": round(wall, 4), "wall_s_all_runs": [round(w, 4) for w, _ in runs],
+            "phases_ms": {k: round(v, 2) for k, v in ph.items()}, "solve_call_ms": round(st.get("total_ms", 0.0), 2),
+            "outside_main_ms": round(wall * 1e3 - sum(ph.values()), 2), "flo_bytes": flo_bytes,
+            "note": "fresh process per run; median of the three runs after the first; the solve is the host-array entry point "
+                    "(2 x 16.6 MB up, 2 x 16.6 MB down), strict mode"}
 
 
 def occ_leg(ofx_mod, synth, local):
@@ -770,9 +875,13 @@ def main():
         elif (nx, ny) == (3840, 2160):
             roof4k = None
 
+    cli = None
+    if rank == 0 and world == 1 and not a.no_cli:
+        cli = cli_leg(synth, local)
+        log("cli leg done")
     sor = None
     if rank == 0 and world == 1 and not a.no_sor:
-        sor = sor_leg(ofx_mod, synth, local, dev)
+        sor = sor_leg(ofx_mod, synth, local, dev, with_cpu=not a.no_cpu)
         log("sor leg done")
     occ = None
     if rank == 0 and world == 1 and not a.no_occ:
@@ -842,6 +951,8 @@ def main():
         line["roofline_4k"] = roof4k
     if sor:
         line["sor"] = sor
+    if cli:
+        line["cli"] = cli
     if occ:
         line["occ"] = occ
     if cpu:

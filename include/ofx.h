@@ -96,7 +96,22 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         test disabled; the reference with epsilon = 0)
  *   "sor_exact"      HS / Brox: 1 (default) = the reference's sweep order, bit-identical results, K time steps
  *                         of the pipelined schedule per launch; 2 = the same schedule, one launch per time step;
- *                         0 = colour-ordered sweeps (much faster, result drifts by ~1e-5..1e-3 px)
+ *                         0 = the TOLERANCE mode, re-ordered sweeps inside north_star's bar (AEPE < 1e-4 against the reference
+ *                         on the BASELINE configs; csrc/ofx_sor_tile.hip): Horn-Schunck four-colour sweeps, K per launch on LDS
+ *                         tiles (AEPE 9e-6 at config 3); Brox a checkerboard of 64 x 128-pixel tiles swept in the reference's
+ *                         order inside a tile on the finest level and red-black sweeps below (AEPE 1.1e-5 at config 4; red-black
+ *                         everywhere: 1.3e-4).  Lone solves 5-10x faster than exact, lockstep groups supported.  On inputs where
+ *                         the solves run into maxiter unconverged (the discontinuous pair P1 at 1080p) ANY re-ordering moves the
+ *                         flow by as much as the reference's own OpenMP threads do (AEPE 2.5e-2) -- use the exact mode there.
+ *   "sor_fuse"       sor_exact = 0, Horn-Schunck: sweeps per launch K = 1..4 (0 = default 2); -1 = the round-1 kernels, one
+ *                         launch per colour and sweep (single pairs only; Brox: red-black on every level).  Results do not
+ *                         depend on K.
+ *   "sor_tile"       sor_exact = 0, Horn-Schunck: tile geometry 1 = 128 x 32 pixels on 16 waves, 2 = on 8 waves (default),
+ *                         3 = 128 x 48 on 12 waves.  Results do not depend on it.
+ *   "sor_wave_levels"  sor_exact = 0, Brox: pyramid levels 0 .. n - 1 use the checkerboard-of-tiles sweeps (default 1: the
+ *                         finest), the coarser ones red-black.  PART OF THE RESULT (as is "sor_tile_w").
+ *   "sor_tile_w"     ... columns per tile, 1..128 (default 128); "sor_wave_p": anti-diagonals of operand prefetch, 2 | 4 | 6 | 8
+ *                         (default 4; results do not depend on it)
  *   "sor_batch"      sweeps in flight per batch in the exact modes (default 32 / 64)
  *   "sor_window"     time steps per launch of sor_exact = 1 (default 8; 4 for Brox in lockstep groups of >= 4 pairs)
  *   "sor_rows"       rows per workgroup (row block of a sweep) of sor_exact = 1 (default 64; 125 in lockstep groups
@@ -243,6 +258,12 @@ int ofx_tvl1_iterations(ofx_ctx *ctx, double *u1, double *u2, double *p11, doubl
  * double range.  An operator entry for direct parity tests of the one libm function on the path. */
 int ofx_hypot(ofx_ctx *ctx, const double *x, const double *y, double *out, int n);
 
+/* How ofx_tvl1_batch_dev reaches a buffer on `mem_device` (-1 = host memory) from a context on `ctx_device`: 0 = in place,
+ * 1 = one copy (host <-> device, or a peer copy when hipDeviceCanAccessPeer says yes), 2 = two copies through a pinned host
+ * bounce buffer (the GPUs cannot address each other; the call succeeds and leaves a note in ofx_last_error).  A pure decision,
+ * exported for the host-logic tests.  The cross-GPU path itself has never executed: no multi-GPU box was available in any round. */
+int ofx_staging_route(int ctx_device, int mem_device, int can_access_peer);
+
 /* ---- Horn-Schunck pyramidal (replace src/horn_schunck.h:15-48) --------------------------------*/
 int ofx_hs_single_scale(ofx_ctx *ctx, const double *I1, const double *I2, double *u, double *v,
                         int nx, int ny, double alpha, int warps, double TOL, int maxiter, int verbose);
@@ -256,7 +277,7 @@ int ofx_hs_pyramidal(ofx_ctx *ctx, const double *I1, const double *I2, double *u
  * exact sweeps (blockIdx.z = pair) -- a lone solve is a latency chain of thousands of dependent steps with little
  * work each -- while every pair keeps its own error slots, snapshots, sweep counts and stopping test: each flow is
  * bit-identical to the one ofx_hs_pyramidal / ofx_brox_spatial compute for that pair alone.  Groups need the
- * default option sor_exact = 1.  The group size of the batch calls is option "lockstep" of ctxs[0] if > 0, else
+ * default option sor_exact = 1 or the tile sweeps of sor_exact = 0.  The group size of the batch calls is option "lockstep" of ctxs[0] if > 0, else
  * as large as possible (<= 16), evened out over the contexts. */
 int ofx_hs_group_dev(ofx_ctx *ctx, int n_pairs, const void *const *dI1, const void *const *dI2, void *const *d_flo,
                      int nx, int ny, double alpha, int nscales, double zfactor, int warps, double TOL, int maxiter,

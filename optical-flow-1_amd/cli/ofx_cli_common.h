@@ -30,6 +30,25 @@ static ofx_ctx *cli_context(void)
 /* OFX_STATS=path (or "-" for stderr): the work record of the solve as one JSON object -- what the reference only prints as
  * text when `verbose` (src/tvl1flow.cpp:184-188,284-286: scale sizes, iterations and error per warp), plus the kernel time
  * of the iteration launches per scale and the wall time of the call.  Nothing is written when the variable is unset. */
+/* wall-clock phases of a front-end run (OFX_STATS only): cli_phase("name") closes the phase that began at the previous call (or
+ * at the first call, which only starts the clock) */
+#include <time.h>
+#define CLI_MAX_PHASES 8
+static struct { const char *name; double ms; } cli_phases[CLI_MAX_PHASES];
+static int cli_nphases = 0;
+static double cli_phase_t0 = -1.0;
+__attribute__((unused)) static void cli_phase(const char *name)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    if (cli_phase_t0 >= 0.0 && name && cli_nphases < CLI_MAX_PHASES) {
+        cli_phases[cli_nphases].name = name;
+        cli_phases[cli_nphases++].ms = now - cli_phase_t0;
+    }
+    cli_phase_t0 = now;
+}
+
 __attribute__((unused)) static void cli_write_stats(const ofx_ctx *ctx, const char *program)
 {
     const char *path = getenv("OFX_STATS");
@@ -38,7 +57,13 @@ __attribute__((unused)) static void cli_write_stats(const ofx_ctx *ctx, const ch
     FILE *f = strcmp(path, "-") ? fopen(path, "w") : stderr;
     if (!f) { fprintf(stderr, "warning: cannot write OFX_STATS file \"%s\"\n", path); return; }
     const char *base = strrchr(program, '/');
-    fprintf(f, "{\"program\": \"%s\", \"nscales\": %d, \"solves_per_scale\": %d, \"work_pix_iters\": %.17g, \"total_ms\": %.6g, "
+    fprintf(f, "{");
+    if (cli_nphases) {
+        fprintf(f, "\"phases_ms\": {");
+        for (int k = 0; k < cli_nphases; k++) fprintf(f, "%s\"%s\": %.3f", k ? ", " : "", cli_phases[k].name, cli_phases[k].ms);
+        fprintf(f, "}, ");
+    }
+    fprintf(f, "\"program\": \"%s\", \"nscales\": %d, \"solves_per_scale\": %d, \"work_pix_iters\": %.17g, \"total_ms\": %.6g, "
                "\"odd_stops\": %d, \"odd_stops_served_from_stored_state\": %d, \"scales\": [",
             base ? base + 1 : program, st.nscales, st.nsolves, st.work_pix_iters, st.total_ms, st.odd_stops, st.odd_stops_stored);
     const int ns = st.nscales < OFX_MAX_SCALES ? st.nscales : OFX_MAX_SCALES;

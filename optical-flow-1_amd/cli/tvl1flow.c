@@ -32,6 +32,7 @@ int main(int argc, char *argv[])
         return EXIT_FAILURE;
     }
     const char *image1_name = argv[1], *image2_name = argv[2];
+    cli_phase(NULL);
     cli_val o[O_COUNT];
     cli_parse(argc, argv, 3, OPTS, O_COUNT, o);
     const char *outfile = o[O_OUT].text;
@@ -51,6 +52,7 @@ int main(int argc, char *argv[])
         return EXIT_FAILURE;
     }
 
+    cli_phase("read_images");
     /* smallest pyramid image not below ~16x16, :185-188 (N is truncated when assigned to the int) */
     const double N = 1 + log(hypot(nx, ny) / 16.0) / log(1 / zfactor);
     if (N < nscales) nscales = (int) N;
@@ -60,11 +62,13 @@ int main(int argc, char *argv[])
 
     ofx_ctx *ctx = cli_context();
     if (!ctx) return EXIT_FAILURE;
+    cli_phase("create_context");
     double *u = (double *) malloc(sizeof(double) * 2 * (size_t) nx * ny);
     double *v = u + (size_t) nx * ny;
     int rc = EXIT_SUCCESS;
     const int s = ofx_tvl1_multiscale(ctx, I0, I1, u, v, nx, ny, tau, lambda, theta, nscales, zfactor, nwarps, epsilon,
                                       verbose);
+    cli_phase("solve");
     if (s != OFX_OK) {
         /* the reference dies with an uncaught C++ exception here (e.g. "GaussianSmooth: sigma too large") */
         fprintf(stderr, "ERROR: %s (%s)\n", ofx_strerror(s), ofx_last_error(ctx));
@@ -72,6 +76,7 @@ int main(int argc, char *argv[])
     } else if (cli_save_flow(outfile, u, v, nx, ny)) {
         rc = EXIT_FAILURE;
     }
+    cli_phase("write_flo");
     free(u); free(I0); free(I1);
     cli_write_stats(ctx, argv[0]);
     ofx_ctx_destroy(ctx);

@@ -103,6 +103,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->d_err = nullptr;
     ctx->d_state = nullptr;
     ctx->h_state = nullptr;
+    ctx->h_aux = nullptr;
     ctx->ev_t0 = ctx->ev_t1 = nullptr;
     for (int i = 0; i < OFX_NPOLL; i++) ctx->ev_poll[i] = nullptr;
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
@@ -110,7 +111,14 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ok = ok && hipMalloc((void **) &ctx->d_state, OFX_STATE_BYTES + sizeof(double) * OFX_TVL1_MAX_ITERATIONS * OFX_NSHARD) == hipSuccess;
     if (ok) ctx->d_err = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_state) + OFX_STATE_BYTES);
     ctx->d_err_cap = OFX_TVL1_MAX_ITERATIONS;
-    ok = ok && hipHostMalloc((void **) &ctx->h_state, sizeof(OfxIterState) * OFX_NPOLL * OFX_MAX_GROUP, hipHostMallocDefault) == hipSuccess;
+    // the poll ring, and behind it OFX_MAX_GROUP doubles of pinned scratch (h_aux: the occlusion solver's per-triple errors); the
+    // ring starts zeroed -- ofx_loop_wait_poll reads a record's `seq` == 0 as "not published yet"
+    ok = ok && hipHostMalloc((void **) &ctx->h_state, sizeof(OfxIterState) * OFX_NPOLL * OFX_MAX_GROUP + sizeof(double) * OFX_MAX_GROUP,
+                             hipHostMallocDefault) == hipSuccess;
+    if (ok) {
+        memset(ctx->h_state, 0, sizeof(OfxIterState) * OFX_NPOLL * OFX_MAX_GROUP + sizeof(double) * OFX_MAX_GROUP);
+        ctx->h_aux = reinterpret_cast<double *>(ctx->h_state + OFX_NPOLL * OFX_MAX_GROUP);
+    }
     for (int i = 0; ok && i < OFX_NPOLL; i++)
         ok = hipEventCreateWithFlags(&ctx->ev_poll[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->ev_t0) == hipSuccess && hipEventCreate(&ctx->ev_t1) == hipSuccess;

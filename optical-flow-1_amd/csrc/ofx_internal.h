@@ -51,6 +51,7 @@ struct ofx_ctx {
     int           d_err_cap;
     OfxIterState *d_state;  // device copy [OFX_MAX_GROUP], start of the allocation
     OfxIterState *h_state;  // pinned ring [OFX_NPOLL][OFX_MAX_GROUP]
+    double       *h_aux;    // pinned, OFX_MAX_GROUP doubles behind the ring (same allocation): results that are not loop records
     hipEvent_t    ev_poll[OFX_NPOLL];
     hipEvent_t    ev_t0, ev_t1;
 
@@ -65,7 +66,8 @@ struct ofx_ctx {
     int lockstep;       // pairs per lockstep group in ofx_tvl1_batch_dev (0 = default)
     int nt_stores;      // fused TV-L1 kernel: 0 (default) non-temporal stores once a launch's working set exceeds the Infinity Cache, 1 always, 2 never
     int relaxed_dual;   // TV-L1 in double storage: 1 = the fast mode's dual stage (sqrt(x^2 + y^2), one reciprocal per denominator) --
-                        // the "tolerance" mode, AEPE vs the reference ~1e-9..1e-6, not bit-identical; 0 (default) strict
+                        // the "tolerance" mode, AEPE vs the reference ~1e-12 px on the BASELINE configs (profiles/r03_b_relaxed_dual_accuracy.jsonl),
+                        // not bit-identical; 0 (default) strict
     int tile;           // TV-L1 small levels: K iterations per launch on 2-D tiles (k_tvl1_tile): 4 | 6 | 0 = off (default)
     double tile_max_px; // ... for levels of at most this many pixels x pairs (0 = default 200 000)
     int gauss_fused;    // pyramids of lockstep groups: row + column pass of the Gaussian in one launch through LDS (1 default)
@@ -91,7 +93,8 @@ struct ofx_ctx {
     int sor_batch;      // sweeps in flight per batch in exact mode (0 = default)
     int sor_window;     // time steps per launch of the windowed exact mode (0 = 8)
     int sor_rows;       // rows per block (workgroup) of a sweep in the windowed exact mode (0 = 64)
-    int sor_lds;        // windowed exact sweeps with the launch window staged in LDS (1 default; 0 = the per-step global round trip)
+    int sor_lds;        // windowed exact sweeps: 0 = one global round trip per step, 2 = the launch window staged in LDS, 1 (default) = by
+                        // measurement: LDS for lone Horn-Schunck solves, global otherwise (sor_use_lds)
     int sor_spw;        // sweeps per workgroup of the windowed exact kernels (0 = automatic: 1 alone, 2 in lockstep groups)
     double mem_budget;  // bytes all contexts of a batch may use for level arrays (0 = half of the free device memory)
     unsigned long long poll_seq;

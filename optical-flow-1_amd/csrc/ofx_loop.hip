@@ -104,7 +104,11 @@ int ofx_loop_wait_poll(ofx_ctx *ctx, int slot, int G, int seq)
             for (int g = 0; g < G && all; g++) all = __atomic_load_n((const int *) &rec[g].seq, __ATOMIC_ACQUIRE) == seq;
             if (all) return OFX_OK;
             if ((spins & 63) == 63 && ofx_now_ms() > t_end) break;
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            __asm__ __volatile__("" ::: "memory");
+#endif
         }
     }
     OFX_HIP(ctx, hipEventSynchronize(ctx->ev_poll[slot]));

@@ -1117,7 +1117,6 @@ static int rof_box_dev(ofx_ctx *ctx, int nc, double *const *u, const double *con
     set.LG = LG; set.stride = n; set.mask = mask; set.nc = nc; set.B = B;
     pt.nc = nc; pt.rm_stride = nrm; pt.sk_stride = n; pt.mask = mask;
     if (n_iter < 1) return OFX_OK;
-    // window length: option "rof_window" (24 | 10), else 24 steps for a lone solve and 10 for lockstep groups of 4 and more
     // window length: 10 steps per launch unless option "rof_window" = 24.  Measured (profiles/r03_x_rof_window_length.txt; 6 / 8 / 10 /
     // 12 / 16 / 24 steps): one 640x480 triple 21.7 / 21.4 / 21.4 / 22.3 / 23.2 / 26.0 ms, 320x240 12.9 / 12.7 / 12.9 / 13.4 / 14.2 /
     // 16.2 ms -- with all iterations in flight the pipeline's depth (9 LAGI, LAGI ~ 4 K) outweighs the per-launch fill a long
@@ -1443,7 +1442,7 @@ int occ_single_scale_dev(ofx_ctx *ctx, int G, const double *I_1, const double *I
     double *us[2] = {u1, u2};
     double2 *pps[2] = {reinterpret_cast<double2 *>(W.state), reinterpret_cast<double2 *>(W.state + 2 * nsk * G)};
     const double *fs[2] = {W.f1, W.f2};
-    double *h_err = reinterpret_cast<double *>(ctx->h_state);        // pinned, >= OCC_MAX_GROUP doubles
+    double *h_err = ctx->h_aux;                                      // pinned, OFX_MAX_GROUP doubles, not the poll ring
     double *d_err = W.part + (size_t) OCC_ERR_BLOCKS * G;
     for (int w = 0; w < P.warps; w++) {
         hipLaunchKernelGGL(k_occ_prepare, grid, block, 0, st, prep, nx, ny, OccGrp{n, all});

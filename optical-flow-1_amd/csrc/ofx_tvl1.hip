@@ -792,6 +792,7 @@ __global__ __launch_bounds__(64 * TILE_RH) void k_tvl1_tile(
     unsigned long long nit, int err_stride)
 {
     using v2 = typename Pix<T>::v2;
+    static_assert(K < 16, "4 bits of `nit` per pair");
     __shared__ double2 s_p[2][TILE_RH][64];                  // (p12, p22) of every row, double-buffered over iterations
     __shared__ double2 s_u[2][TILE_RH][64];                  // u_new of every row
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1330,6 +1331,8 @@ static int tvl1_run_iterations(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &
     return OFX_OK;
 }
 
+static_assert(OFX_MAX_GROUP * 4 <= 64 && OFX_MAX_GROUP * 2 <= 32,
+              "k_tvl1_tile / k_tvl1_iter3 pack 4 bits of iteration count (`nit`, 64 bits) and 2 bits of buffer index (`incode`, 32 bits) per pair");
 // tvl1_run_iterations through k_tvl1_tile: launch unit j = iterations [j K, j K + K) reads buffer (b_g + j) % 3 and writes
 // (b_g + j + 1) % 3; a loop that ends inside a unit is finished by one more launch that re-runs the unit's first n - j K
 // iterations from its input (every pair with its own count).
@@ -1638,6 +1641,47 @@ static bool ofx_ptr_is_local(const ofx_ctx *ctx, const void *p)
     }
     return a.type == hipMemoryTypeDevice && a.device == ctx->device;
 }
+// How a buffer that lives on `mem_device` (-1: host memory) reaches a context on `ctx_device`: 0 = in place, 1 = one
+// hipMemcpyDefault (host <-> device, or a peer copy over xGMI), 2 = two copies through a host bounce buffer because the two GPUs
+// cannot address each other (hipDeviceCanAccessPeer says no: another IOMMU group, peer access disabled, ...).  Pure decision,
+// exported so that the host-logic tests cover it without a GPU.
+extern "C" int ofx_staging_route(int ctx_device, int mem_device, int can_access_peer)
+{
+    if (mem_device == ctx_device) return 0;
+    if (mem_device < 0) return 1;
+    return can_access_peer ? 1 : 2;
+}
+// dst <- src (one of them on this context's GPU, the other anywhere), on the context's stream.  A route-2 copy is synchronous
+// and leaves a note in ofx_last_error (the call still succeeds).  UNEXECUTED on more than one GPU (no multi-GPU box in any round).
+static int ofx_copy_staged(ofx_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    const void *other = ofx_ptr_is_local(ctx, dst) ? src : dst;
+    int mem_device = -1, can = 1;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, other) == hipSuccess) {
+        if (a.type == hipMemoryTypeDevice) mem_device = a.device;
+    } else {
+        (void) hipGetLastError();
+    }
+    if (mem_device >= 0 && mem_device != ctx->device && hipDeviceCanAccessPeer(&can, ctx->device, mem_device) != hipSuccess) {
+        (void) hipGetLastError();
+        can = 0;
+    }
+    if (ofx_staging_route(ctx->device, mem_device, can) < 2) {
+        OFX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));
+        return OFX_OK;
+    }
+    void *bounce = nullptr;
+    OFX_HIP(ctx, hipHostMalloc(&bounce, bytes, hipHostMallocDefault));
+    hipError_t e = hipStreamSynchronize(ctx->stream);                                       // src may be this stream's product
+    if (e == hipSuccess) e = hipMemcpy(bounce, src, bytes, hipMemcpyDefault);
+    if (e == hipSuccess) e = hipMemcpy(dst, bounce, bytes, hipMemcpyDefault);
+    (void) hipHostFree(bounce);
+    if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "staging through the host failed: %s", hipGetErrorString(e));
+    snprintf(ctx->errmsg, sizeof(ctx->errmsg), "note: GPU %d cannot address GPU %d, buffers were staged through the host", ctx->device,
+             mem_device);
+    return OFX_OK;
+}
 
 template <typename T>
 static int tvl1_group_devapi(ofx_ctx *ctx, int G, const void *const *dI0_in, const void *const *dI1_in, void *const *d_flo_in,
@@ -1655,7 +1699,7 @@ static int tvl1_group_devapi(ofx_ctx *ctx, int G, const void *const *dI0_in, con
             if (ofx_ptr_is_local(ctx, src[k])) { *dst[k] = src[k]; continue; }
             T *stage;
             OFX_TRY(ofx_alloc(ctx, n, &stage));
-            OFX_HIP(ctx, hipMemcpyAsync(stage, src[k], n * sizeof(T), hipMemcpyDefault, ctx->stream));
+            OFX_TRY(ofx_copy_staged(ctx, stage, src[k], n * sizeof(T)));
             *dst[k] = stage;
         }
         d_flo[g] = d_flo_in[g];
@@ -1674,8 +1718,7 @@ static int tvl1_group_devapi(ofx_ctx *ctx, int G, const void *const *dI0_in, con
                        out, n);
     OFX_LAUNCH_CHECK(ctx);
     for (int g = 0; g < G; g++)
-        if (d_flo[g] != d_flo_in[g])
-            OFX_HIP(ctx, hipMemcpyAsync(d_flo_in[g], d_flo[g], n * sizeof(float2), hipMemcpyDefault, ctx->stream));
+        if (d_flo[g] != d_flo_in[g]) OFX_TRY(ofx_copy_staged(ctx, d_flo_in[g], d_flo[g], n * sizeof(float2)));
     return OFX_OK;
 }
 
@@ -1848,18 +1891,34 @@ extern "C" int ofx_tvl1_batch_group_size(ofx_ctx *const *ctxs, int n_ctx, int n_
     // + the pyramid temporaries: two scratch arrays of 2 full-size images per pair (op_build_pyramid_group)
     const double per_pair = (26.0 * px + 4.0 * (double) nx * ny) * elem;
     const double per_ctx = 64e6;                                    // error slots, arena slack
-    size_t mfree = 0, mtotal = 0;
+    // the budget is per DEVICE: the contexts of a batch may sit on several GPUs (ofx_tvl1_batch_dev), each of which holds the level
+    // arrays of its own contexts only -- free memory of every distinct device, divided by the contexts on it; the tightest fit wins
     int dev_now = 0;
     (void) hipGetDevice(&dev_now);
-    (void) hipSetDevice(ctxs[0]->device);
-    const hipError_t e = hipMemGetInfo(&mfree, &mtotal);
-    (void) hipSetDevice(dev_now);
     int cap = OFX_MAX_GROUP;
-    double budget = ctxs[0]->mem_budget > 0 ? ctxs[0]->mem_budget : (e == hipSuccess ? 0.5 * (double) mfree : -1.0);
-    if (budget >= 0) {
-        const double fit = (budget / n_ctx - per_ctx) / per_pair;
-        if (fit < cap) cap = fit < 1.0 ? 1 : (int) fit;
+    for (int w = 0; w < n_ctx; w++) {
+        if (!ctxs[w]) return -OFX_ERR_ARG;
+        int on_dev = 0;
+        bool seen = false;
+        for (int v = 0; v < n_ctx; v++) {
+            if (!ctxs[v] || ctxs[v]->device != ctxs[w]->device) continue;
+            on_dev++;
+            seen = seen || v < w;
+        }
+        if (seen) continue;                                         // this device was handled with its first context
+        double budget = ctxs[w]->mem_budget > 0 ? ctxs[w]->mem_budget * on_dev / n_ctx : -1.0;    // "mem_budget": all contexts of the batch
+        if (budget < 0) {
+            size_t mfree = 0, mtotal = 0;
+            (void) hipSetDevice(ctxs[w]->device);
+            if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) budget = 0.5 * (double) mfree;
+            else (void) hipGetLastError();
+        }
+        if (budget >= 0) {
+            const double fit = (budget / on_dev - per_ctx) / per_pair;
+            if (fit < cap) cap = fit < 1.0 ? 1 : (int) fit;
+        }
     }
+    (void) hipSetDevice(dev_now);
     const int rounds = (n_pairs + n_ctx * cap - 1) / (n_ctx * cap);
     G = (n_pairs + n_ctx * rounds - 1) / (n_ctx * rounds);
     return G < 1 ? 1 : G;

@@ -14,6 +14,36 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # OFX_REQUIRE_ALL: a test whose prerequisite is a git-ignored binary or an optional system library (the compiled reference, the
+    # shim driver, libpng16) FAILS instead of skipping when that prerequisite is absent -- so a record of the GPU suite shows they
+    # ran.  Set by default when the run selects the GPU tests (-m gpu); OFX_REQUIRE_ALL=0 switches it off.
+    if "OFX_REQUIRE_ALL" not in os.environ and "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):
+        os.environ["OFX_REQUIRE_ALL"] = "1"
+
+
+def require_or_skip(present, what):
+    """prerequisite check of a test: skip with the reason, or fail under OFX_REQUIRE_ALL=1"""
+    if present:
+        return
+    if os.environ.get("OFX_REQUIRE_ALL", "0") == "1":
+        pytest.fail("prerequisite missing (OFX_REQUIRE_ALL=1): " + what)
+    pytest.skip(what)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """skip reasons with counts: a record of the suite shows WHY something did not run (designed parameter skips vs a missing
+    binary), not only how many"""
+    skipped = terminalreporter.stats.get("skipped", [])
+    if not skipped:
+        return
+    reasons = {}
+    for rep in skipped:
+        r = rep.longrepr[2] if isinstance(rep.longrepr, tuple) and len(rep.longrepr) == 3 else str(rep.longrepr)
+        r = r[len("Skipped: "):] if r.startswith("Skipped: ") else r
+        reasons[r] = reasons.get(r, 0) + 1
+    terminalreporter.write_sep("-", "skip reasons")
+    for r, n in sorted(reasons.items(), key=lambda kv: -kv[1]):
+        terminalreporter.write_line("%5d  %s" % (n, r))
 
 
 @pytest.fixture(scope="session")
@@ -65,8 +95,7 @@ def orc(_orc_session):
 
 @pytest.fixture(scope="session")
 def ref(oracle_mod):
-    if not oracle_mod.have_ref():
-        pytest.skip("oracle/_ref/libofref.so not built (needs /root/reference)")
+    require_or_skip(oracle_mod.have_ref(), "oracle/_ref/libofref.so not built (needs /root/reference)")
     r = oracle_mod.Ref()
     r.set_num_threads(1)
     return r

@@ -10,7 +10,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--nx", "320", "--ny", "240", "--no-cpu", "--no-4k", "--no-sor", "--no-occ", "--fixed-steps", "1", "--warmup", "1"]
+SMALL = ["--nx", "320", "--ny", "240", "--no-cpu", "--no-4k", "--no-sor", "--no-cli", "--no-occ", "--fixed-steps", "1", "--warmup", "1"]
 
 
 def run_bench(args, timeout=600):
@@ -80,7 +80,7 @@ def test_bench_4k_batch_workload_shards_pairs_over_ranks():
 def test_bench_4k_batch_workload_on_one_gpu_at_full_size():
     """`bench.py --workload 4k-batch --steps 4 --gpus 1`: BASELINE config 5's size (3840x2160) on the one GPU, the launch
     shape roofline_4k quotes (lockstep groups, non-temporal stores); the line must carry the contract keys and a roofline."""
-    d = run_bench(["--gpus", "1", "--workload", "4k-batch", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-sor", "--no-occ",
+    d = run_bench(["--gpus", "1", "--workload", "4k-batch", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-sor", "--no-cli", "--no-occ",
                    "--fixed-steps", "1"])
     for k in CONTRACT:
         assert k in d, k

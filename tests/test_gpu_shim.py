@@ -8,14 +8,15 @@ import subprocess
 import numpy as np
 import pytest
 
+from conftest import require_or_skip
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "tests", "shim", "_build", "shim_driver")
 
 
 def test_reference_prototypes_through_the_shim(orc, synth, tmp_path):
-    if not os.path.exists(DRIVER):
-        pytest.skip("tests/shim/_build/shim_driver not built (needs /root/reference headers at build time)")
+    require_or_skip(os.path.exists(DRIVER), "tests/shim/_build/shim_driver not built (needs /root/reference headers at build time)")
     nx, ny, frames = 96, 64, 4
     seq = synth.sequence(nx, ny, frames)
     with open(tmp_path / "in.bin", "wb") as f:

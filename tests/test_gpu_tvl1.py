@@ -7,7 +7,7 @@ is the order of the convergence-error sum, so iteration counts must match and th
 to be (and asserted) equal to ~1e-9."""
 import numpy as np
 import pytest
-from conftest import aepe
+from conftest import aepe, require_or_skip
 
 pytestmark = pytest.mark.gpu
 
@@ -176,7 +176,26 @@ def test_full_size_1080p_matches_oracle(gpu64, oracle_mod, synth):
     finally:
         gpu64.set_option("relaxed_dual", 0)
     assert aepe(ut, vt, uo, vo) < 1e-4 and aepe(ut, vt, uo, vo) < 1e-8      # stated tolerance; what it actually achieves
-    assert np.abs(it_t - np.asarray(it_o)).max() <= 4
+    assert np.array_equal(it_t, it_o)       # on the BASELINE configs the tolerance mode's iteration tables EQUAL the reference's
+
+
+@pytest.mark.parametrize("pair,nx,ny", [("P0", 640, 480), ("P1", 640, 480), ("P0", 1920, 1080)])
+def test_tolerance_mode_iteration_tables_equal_the_strict_ones_on_the_baseline_configs(gpu64, synth, pair, nx, ny):
+    """BASELINE configs 1 and 2 (config 5's size: the 4K test below).  The tolerance mode changes the last bits of the dual update,
+    which could move a stopping test across its threshold; on the configs the metric is quoted on it does not -- every one of the
+    5 x 5 iteration counts equals the strict mode's, which is the reference's (README, bench.py ARITH say "equal": this
+    is where that is asserted; the randomised soak allows +-4)."""
+    I0, I1 = synth.pair(pair, nx, ny)
+    us, vs = gpu64.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+    it_s = gpu64.stats().iterations().copy()
+    gpu64.set_option("relaxed_dual", 1)
+    try:
+        ut, vt = gpu64.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+        it_t = gpu64.stats().iterations().copy()
+    finally:
+        gpu64.set_option("relaxed_dual", 0)
+    assert np.array_equal(it_t, it_s)
+    assert aepe(ut, vt, us, vs) < 1e-8
 
 
 @pytest.mark.timeout(900)
@@ -194,6 +213,14 @@ def test_full_size_4k_warps5_matches_oracle(gpu64, oracle_mod, synth):
     assert np.array_equal(gpu64.stats().iterations(), it_o)
     assert aepe(ug, vg, uo, vo) < 1e-4
     assert np.abs(ug - uo).max() < 1e-9 and np.abs(vg - vo).max() < 1e-9
+    gpu64.set_option("relaxed_dual", 1)     # config 5's size in the tolerance mode: tables equal, AEPE eight orders under the bar
+    try:
+        ut, vt = gpu64.tvl1_multiscale(I0, I1, nscales=5, **PAR)
+        it_t = gpu64.stats().iterations().copy()
+    finally:
+        gpu64.set_option("relaxed_dual", 0)
+    assert np.array_equal(it_t, it_o)
+    assert aepe(ut, vt, uo, vo) < 1e-8
 
 
 def test_4k_size_independent_properties(gpu64, synth):
@@ -321,8 +348,7 @@ def test_f32_mode_is_as_accurate_as_the_reference_own_float_build(gpu32, oracle_
     sources through the include guard of src/of.h) drifts from its double build by AEPE ~1e-5 (TV-L1) / ~2e-6 (HS).
     The GPU's OFX_F32 mode (float storage, double arithmetic in registers, relaxed dual update) must stay in that band."""
     import os
-    if not (oracle_mod.have_ref() and os.path.exists(oracle_mod.REF32_SO)):
-        pytest.skip("compiled reference (double + float builds) not present")
+    require_or_skip(oracle_mod.have_ref() and os.path.exists(oracle_mod.REF32_SO), "compiled reference (double + float builds) not present")
     r64, r32 = oracle_mod.Ref(), oracle_mod.Ref32()
     r64.set_num_threads(1)
     r32.set_num_threads(1)

@@ -363,3 +363,17 @@ def test_gray_byte_image_writer_pgm_and_png(io, tmp_path):
         out[y] = cur
     assert np.array_equal(out, big.astype(np.uint8))
     assert np.array_equal(read_image(io, tmp_path / "o.png"), big.astype(np.float64))       # and through our own reader
+
+
+def test_staging_route_of_the_cross_gpu_batch():
+    """ofx_tvl1_batch_dev over contexts on several GPUs: where a buffer that is not on the context's GPU comes from.  The decision is a
+    pure function of (context device, memory device, hipDeviceCanAccessPeer) -- the path itself has never run on more than one GPU."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "optical-flow-1_amd", "libofx.so"))
+    f = lib.ofx_staging_route
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int] * 3
+    assert f(0, 0, 1) == 0 and f(3, 3, 0) == 0             # on the context's GPU: in place
+    assert f(0, -1, 1) == 1 and f(0, -1, 0) == 1           # host memory: one copy
+    assert f(0, 1, 1) == 1                                 # another GPU, peer access: one copy over xGMI
+    assert f(0, 1, 0) == 2 and f(5, 2, 0) == 2             # no peer access: through a host bounce buffer

@@ -12,7 +12,11 @@ def newest(pat):
     return f[-1] if f else None
 
 
-out = {"note": __doc__.split("Prints")[0].strip()}
+import hashlib
+_h = hashlib.sha256()
+for _f in ("ofx_tvl1.hip", "ofx_device.h", "ofx_loop.h"):      # what bench.py's kernel_source_sha16() hashes
+    _h.update(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "optical-flow-1_amd", "csrc", _f), "rb").read())
+out = {"note": __doc__.split("Prints")[0].strip(), "kernel_source_sha16": _h.hexdigest()[:16]}
 for sz, G in (("1920x1080", 5), ("3840x2160", 4)):
     nx, ny = map(int, sz.split("x"))
     for m, mode, kern in ((0, "strict", "k_tvl1_iter2"), (1, "tolerance", "k_tvl1_iter2"), (1, "tolerance", "k_tvl1_iter3")):
