@@ -49,9 +49,20 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     if (!out) return OFX_ERR_ARG;
     *out = nullptr;
     if (precision != OFX_F64 && precision != OFX_F32) return OFX_ERR_ARG;
+    // OFX_TRACE_INIT=1: where the time of the first context of a process goes (stderr), for the front-ends' end-to-end budget
+    const bool trace = getenv("OFX_TRACE_INIT") != nullptr;
+    double t_prev = ofx_now_ms();
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        const double t = ofx_now_ms();
+        fprintf(stderr, "ofx_ctx_create: %-28s %8.2f ms\n", what, t - t_prev);
+        t_prev = t;
+    };
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return OFX_ERR_NODEV;
+    mark("hipGetDeviceCount (runtime)");
     if (hipSetDevice(device) != hipSuccess) return OFX_ERR_NODEV;
+    mark("hipSetDevice");
 
     ofx_ctx *ctx = new (std::nothrow) ofx_ctx();
     if (!ctx) return OFX_ERR_NOMEM;
@@ -107,10 +118,12 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->ev_t0 = ctx->ev_t1 = nullptr;
     for (int i = 0; i < OFX_NPOLL; i++) ctx->ev_poll[i] = nullptr;
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    mark("hipStreamCreate");
     static_assert(sizeof(OfxIterState) * OFX_MAX_GROUP <= OFX_STATE_BYTES, "state block too small");
     ok = ok && hipMalloc((void **) &ctx->d_state, OFX_STATE_BYTES + sizeof(double) * OFX_TVL1_MAX_ITERATIONS * OFX_NSHARD) == hipSuccess;
     if (ok) ctx->d_err = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_state) + OFX_STATE_BYTES);
     ctx->d_err_cap = OFX_TVL1_MAX_ITERATIONS;
+    mark("hipMalloc (loop state)");
     // the poll ring, and behind it OFX_MAX_GROUP doubles of pinned scratch (h_aux: the occlusion solver's per-triple errors); the
     // ring starts zeroed -- ofx_loop_wait_poll reads a record's `seq` == 0 as "not published yet"
     ok = ok && hipHostMalloc((void **) &ctx->h_state, sizeof(OfxIterState) * OFX_NPOLL * OFX_MAX_GROUP + sizeof(double) * OFX_MAX_GROUP,
@@ -119,9 +132,11 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
         memset(ctx->h_state, 0, sizeof(OfxIterState) * OFX_NPOLL * OFX_MAX_GROUP + sizeof(double) * OFX_MAX_GROUP);
         ctx->h_aux = reinterpret_cast<double *>(ctx->h_state + OFX_NPOLL * OFX_MAX_GROUP);
     }
+    mark("hipHostMalloc (poll ring)");
     for (int i = 0; ok && i < OFX_NPOLL; i++)
         ok = hipEventCreateWithFlags(&ctx->ev_poll[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->ev_t0) == hipSuccess && hipEventCreate(&ctx->ev_t1) == hipSuccess;
+    mark("hipEventCreate x 6");
     if (!ok) {
         (void) hipGetLastError();
         ofx_ctx_destroy(ctx);        // every handle is either valid or still null

@@ -507,6 +507,56 @@ template int ofx_band_copy<float2, false>(ofx_ctx *, const float2 *, float2 *, i
 template int ofx_band_copy<float4, true>(ofx_ctx *, const float4 *, float4 *, int, int, int);
 template int ofx_band_copy<float, true>(ofx_ctx *, const float *, float *, int, int, int);
 
+// Buffer loads (ofx_device.h has the stores): a lane whose byte offset lies outside the descriptor's range reads zeros and touches
+// no memory, so "this lane has nothing to load" is part of the address -- the instruction is issued unconditionally, in
+// straight-line code, and the compiler's s_waitcnt counts stay exact (a load under `if` ends in vmcnt(0) at the join).
+OFX_DEV double2 bld2(ofx_rsrc r, unsigned off, const double2 *)
+{
+    const ofx_u4v w = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    double2 d;
+    __builtin_memcpy(&d, &w, 16);
+    return d;
+}
+OFX_DEV double2 bld2(ofx_rsrc r, unsigned off, const float2 *)
+{
+    const ofx_u2v w = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    float2 f;
+    __builtin_memcpy(&f, &w, 8);
+    return make_double2((double) f.x, (double) f.y);
+}
+OFX_DEV double4 bld4(ofx_rsrc r, unsigned off, const double4 *)
+{
+    // (the builtin's arguments are descriptor, per-lane offset, scalar offset, cache policy: the second half is its own offset,
+    // and an out-of-range marker must stay one -- OFX_OOB + 16 would wrap to 0)
+    const ofx_u4v a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    const ofx_u4v b = __builtin_amdgcn_raw_buffer_load_b128(r, off == OFX_OOB ? OFX_OOB : off + 16u, 0, 0);
+    double2 lo, hi;
+    __builtin_memcpy(&lo, &a, 16);
+    __builtin_memcpy(&hi, &b, 16);
+    return make_double4(lo.x, lo.y, hi.x, hi.y);
+}
+OFX_DEV double4 bld4(ofx_rsrc r, unsigned off, const float4 *)
+{
+    const ofx_u4v w = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    float4 f;
+    __builtin_memcpy(&f, &w, 16);
+    return make_double4((double) f.x, (double) f.y, (double) f.z, (double) f.w);
+}
+OFX_DEV double bld1(ofx_rsrc r, unsigned off, const double *)
+{
+    const ofx_u2v w = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    double d;
+    __builtin_memcpy(&d, &w, 8);
+    return d;
+}
+OFX_DEV double bld1(ofx_rsrc r, unsigned off, const float *)
+{
+    const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+    float f;
+    __builtin_memcpy(&f, &w, 4);
+    return (double) f;
+}
+
 // operands of one anti-diagonal of a tile, as prefetched: own (du, dv), (Au, Av, Du, Dv), D, psi_s
 struct BrwSlot {
     double2 du;
@@ -580,13 +630,21 @@ __global__ __launch_bounds__(256) void k_brox_wave(typename Pix<T>::v2 *DUg, con
     }
     const int h0 = c0, hend = c1 - 1 + nr - 1;                              // anti-diagonals of the tile, inclusive
     const int hmax = nx + 63;                                               // last anti-diagonal that is storage
+    // An anti-diagonal of the band is 64 pixels, of which only those inside the tile's columns (and one to the right: the right
+    // neighbour) are this wave's business -- the others belong to the neighbouring tiles' ramps.  Their lanes are masked out of the
+    // loads: unmasked, a tile of TW columns reads TW + 63 + P columns of every row (measured 1.59 x the compulsory bytes,
+    // profiles/r04_sor_traffic.json).
+    const ofx_rsrc rDU = make_rsrc((void *) DU, BS * (unsigned) sizeof(v2)), rCO = make_rsrc((void *) CO, BS * (unsigned) sizeof(v4));
+    const ofx_rsrc rDm = make_rsrc((void *) Dm, BS * (unsigned) sizeof(T)), rPs = make_rsrc((void *) Ps, BS * (unsigned) sizeof(T));
     auto fetch = [&](int hh) -> BrwSlot {
         const unsigned e = (unsigned) (hh < hmax ? hh : hmax) * 64u + (unsigned) r;
+        const int jj = hh - r;
+        const bool need = rowok && jj >= c0 && jj <= c1;
         BrwSlot s;
-        s.du = ldw2(DU + e);
-        s.co = ldw4(CO + e);
-        s.dm = ldw(Dm + e);
-        s.ps = ldw(Ps + e);
+        s.du = bld2(rDU, need ? e * (unsigned) sizeof(v2) : OFX_OOB, (const v2 *) nullptr);
+        s.co = bld4(rCO, need ? e * (unsigned) sizeof(v4) : OFX_OOB, (const v4 *) nullptr);
+        s.dm = bld1(rDm, need ? e * (unsigned) sizeof(T) : OFX_OOB, (const T *) nullptr);
+        s.ps = bld1(rPs, need ? e * (unsigned) sizeof(T) : OFX_OOB, (const T *) nullptr);
         return s;
     };
     BrwSlot q[P];
@@ -631,7 +689,7 @@ __global__ __launch_bounds__(256) void k_brox_wave(typename Pix<T>::v2 *DUg, con
             const double duk = c.x, dvk = c.y;
             const double dun = tile_rnd<T>((1. - w) * duk + hst_div(w * (s.co.x - s.dm * dvk + alpha * div_du), s.co.z, ru));   // :162
             const double dvn = tile_rnd<T>((1. - w) * dvk + hst_div(w * (s.co.y - s.dm * dun + alpha * div_dv), s.co.w, rv));   // :163
-            if (active) stn2(DU + ((unsigned) h * 64u + (unsigned) r), make_double2(dun, dvn));
+            bst2<false>(rDU, active ? ((unsigned) h * 64u + (unsigned) r) * (unsigned) sizeof(v2) : OFX_OOB, make_double2(dun, dvn), (const v2 *) nullptr);
             e += active ? (dun - duk) * (dun - duk) + (dvn - dvk) * (dvn - dvk) : 0.0;     // :166
             newp = make_double2(dun, dvn);
             psp = s.ps;
