@@ -279,6 +279,36 @@ def test_png_input_follows_iio_semantics(io, tmp_path):
     assert not io.ofx_read_image_double(str(tmp_path / "broken.png").encode(), C.byref(wv), C.byref(hv))
 
 
+def test_png_decoding_agrees_with_an_independent_decoder(io, tmp_path):
+    """SURVEY 8(f)2, still "parity UNPINNED" against iio (which cannot be built here and ships no image fixtures): what CAN be
+    pinned is the decoding itself.  Pillow writes the files (real encoder: filters, compression, interlacing) and decodes them
+    again; ofx_read_image_double's samples are compared with Pillow's -- 8- and 16-bit gray as is, RGB and palette images through
+    the iio collapse (uint8)(.299 R + .587 G + .114 B) applied to Pillow's RGB samples."""
+    import ctypes.util
+    PIL = pytest.importorskip("PIL.Image")
+    if not (ctypes.util.find_library("png16") or os.path.exists("/lib/x86_64-linux-gnu/libpng16.so.16")):
+        pytest.skip("libpng16 not present on this machine")
+    rng = np.random.default_rng(11)
+    w, h = 37, 23
+    collapse = lambda rgb: (.299 * rgb[..., 0].astype(np.float64) + .587 * rgb[..., 1] + .114 * rgb[..., 2]).astype(np.uint8)
+    g8 = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    PIL.fromarray(g8).save(tmp_path / "g8.png", optimize=True)
+    assert np.array_equal(read_image(io, tmp_path / "g8.png"), np.asarray(PIL.open(tmp_path / "g8.png")).astype(np.float64))
+    g16 = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+    PIL.fromarray(g16).save(tmp_path / "g16.png")
+    assert np.array_equal(read_image(io, tmp_path / "g16.png"), np.asarray(PIL.open(tmp_path / "g16.png")).astype(np.float64))
+    assert np.array_equal(read_image(io, tmp_path / "g16.png"), g16.astype(np.float64))
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    PIL.fromarray(rgb).save(tmp_path / "rgb.png", compress_level=9)
+    back = np.asarray(PIL.open(tmp_path / "rgb.png").convert("RGB"))
+    assert np.array_equal(back, rgb)
+    assert np.array_equal(read_image(io, tmp_path / "rgb.png"), collapse(back).astype(np.float64))
+    pal = PIL.fromarray(rgb).quantize(colors=16)                     # a palette image with Pillow's own palette
+    pal.save(tmp_path / "pal.png")
+    back = np.asarray(PIL.open(tmp_path / "pal.png").convert("RGB"))
+    assert np.array_equal(read_image(io, tmp_path / "pal.png"), collapse(back).astype(np.float64))
+
+
 def test_bench_round_split_and_self_launch_command(monkeypatch):
     """bench.py: rounds are a partition with the last round ~1/4 (multiple of the contexts); N > 1 without a launcher
     starts torch.distributed.run as a child BEFORE torch is imported."""
