@@ -92,6 +92,9 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->chi_fuse = 1;
     ctx->fuse3 = 2;
     ctx->fuse3_min_px = 0.0;
+    ctx->fuse3_cursor = 1;
+    ctx->fuse3_afac1 = 0;
+    ctx->fuse3_afac2 = 0;
     ctx->rows_per_wave3 = 0;
     ctx->fixed_work = 0;
     ctx->sor_exact = 1;
@@ -119,7 +122,8 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     for (int i = 0; i < OFX_NPOLL; i++) ctx->ev_poll[i] = nullptr;
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     mark("hipStreamCreate");
-    static_assert(sizeof(OfxIterState) * OFX_MAX_GROUP <= OFX_STATE_BYTES, "state block too small");
+    static_assert(sizeof(OfxLoopDev) <= OFX_STATE_BYTES && OFX_STATE_BYTES % 512 == 0, "state block too small");
+    static_assert(OFX_ULOG >= OFX_TVL1_MAX_ITERATIONS / 2 + 8, "unit log too short");
     ok = ok && hipMalloc((void **) &ctx->d_state, OFX_STATE_BYTES + sizeof(double) * OFX_TVL1_MAX_ITERATIONS * OFX_NSHARD) == hipSuccess;
     if (ok) ctx->d_err = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_state) + OFX_STATE_BYTES);
     ctx->d_err_cap = OFX_TVL1_MAX_ITERATIONS;
@@ -292,6 +296,9 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
         return OFX_OK;
     }
     if (!strcmp(name, "fuse3_min_px")) { ctx->fuse3_min_px = value; return OFX_OK; }
+    if (!strcmp(name, "fuse3_cursor")) { ctx->fuse3_cursor = value != 0; return OFX_OK; }
+    if (!strcmp(name, "fuse3_afac1")) { ctx->fuse3_afac1 = value; return value >= 0 ? OFX_OK : ofx_fail(ctx, OFX_ERR_ARG, "fuse3_afac1 < 0"); }
+    if (!strcmp(name, "fuse3_afac2")) { ctx->fuse3_afac2 = value; return value >= 0 ? OFX_OK : ofx_fail(ctx, OFX_ERR_ARG, "fuse3_afac2 < 0"); }
     if (!strcmp(name, "rows_per_wave3")) { ctx->rows_per_wave3 = (int) value; return OFX_OK; }
     if (!strcmp(name, "spin_us")) {
         if (value < 0 || value > 1e6) return ofx_fail(ctx, OFX_ERR_ARG, "spin_us out of range");

@@ -25,9 +25,25 @@ struct OfxIterState {
                      // stored its intermediate state (tvl1_store_a in ofx_tvl1.hip, same formula)
     int    seq;      // host copy only: written LAST (after a system-scope fence) with the poll's sequence number, so the host
                      // can spin on it instead of sleeping in hipEventSynchronize (0 = not published yet)
+    // cursor loops (ofx_run_loop_cursor): the launch unit that contains iteration n - 1 -- its launch index, first iteration
+    // and iteration count; meaningful when done
+    int    unit, k0, ucnt;
 };
 
-#define OFX_STATE_BYTES 512    // >= sizeof(OfxIterState) * OFX_MAX_GROUP, keeps the error slots 512-byte aligned
+// Device-resident part of a cursor loop (TV-L1, three-iteration units that shrink near the end of a loop): the launch units of
+// a pair have no fixed size, so where a launch starts is device state.  Launch L of pair g reads cursor[L & 1][g], decides its
+// iteration count from the previous iteration's error, and ONE thread of it writes cursor[(L + 1) & 1][g] and ulog[g][L] (the
+// other blocks of launch L may not have read their cursor yet: two copies by launch parity).  scanned[g]: iterations the
+// finalize kernels have looked at.  The whole block is zeroed with the error slots at the start of every loop.
+#define OFX_ULOG 160           // launches of one loop: OFX_TVL1_MAX_ITERATIONS / 2 + slack (a unit has >= 2 iterations unless it is the tail)
+struct OfxLoopDev {
+    OfxIterState st[OFX_MAX_GROUP];
+    int cursor[2][OFX_MAX_GROUP];
+    int scanned[OFX_MAX_GROUP];
+    int ulog[OFX_MAX_GROUP][OFX_ULOG];
+};
+
+#define OFX_STATE_BYTES 11776  // >= sizeof(OfxLoopDev), a multiple of 512: keeps the error slots 512-byte aligned
 
 struct OfxSlab {
     char  *base;
@@ -75,6 +91,8 @@ struct ofx_ctx {
     int chunk;
     int fuse3;          // TV-L1: three iterations per launch (k_tvl1_iter3): 0 never, 1 levels of >= fuse3_min_px pixels x pairs, 2 auto (default)
     double fuse3_min_px;
+    int fuse3_cursor;   // 1 (default): k_tvl1_iter3 as a cursor loop -- units shrink to 2 / 1 iterations near the end of a loop; 0: fixed units of 3
+    double fuse3_afac1, fuse3_afac2;   // ... error / threshold ratios below which a unit runs 1 / 2 iterations (0 = 1.2 / 1.5)
     int rows_per_wave3; // strip height of k_tvl1_iter3 (0 = tvl1_pick_rows3)
     int chi_fuse;       // Solver_wrt_chi: 1 = CHI_N iterations per launch on LDS tiles (default), 0 = two launches per iteration
     int rof_window;     // steps per launch of the ROF box sweeps: 10 (default, also 0) | 24

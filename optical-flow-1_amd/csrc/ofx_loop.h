@@ -64,6 +64,8 @@ int ofx_loop_clear(ofx_ctx *ctx, size_t slots);                        // zero t
 // seq: number the records carry when they are complete (never 0); ofx_loop_wait_poll(slot, G, seq) waits for them
 int ofx_loop_finalize_group(ofx_ctx *ctx, const LoopSpec &L, int G, int slots_per_problem, int start, int launched,
                             OfxIterState *host_slot, int seq);
+int ofx_loop_finalize_cursor(ofx_ctx *ctx, const LoopSpec &L, int G, int slots_per_problem, int launch_end, int max_range,
+                             OfxIterState *host_slot, int seq);
 int ofx_loop_wait_poll(ofx_ctx *ctx, int slot, int G, int seq);
 static inline int ofx_poll_seq(const ofx_ctx *ctx) { return (int) (ctx->poll_seq & 0x3FFFFFFF) + 1; }
 
@@ -190,4 +192,86 @@ static int ofx_run_loop(ofx_ctx *ctx, const LoopSpec &L, LaunchFn launch, RedoFn
                         float *ms_out)
 {
     return ofx_run_loop_group(ctx, L, 1, launch, [&](const int *k_of) { return redo(k_of[0]); }, n_out, err_out, ms_out);
+}
+
+
+// ---- cursor loops ---------------------------------------------------------------------------------------------------------
+// The launch units of a loop have NO fixed size: every launch reads where its pair stands from device memory (OfxLoopDev), picks
+// its own iteration count (TV-L1: three iterations while the loop is far from its threshold, fewer when the previous error says
+// the stop is near -- fewer iterations computed past the stop, fewer re-runs) and logs where it started.  The host only counts
+// launches: launch(L, thr) enqueues launch L for all problems; units_per_chunk launches, then one finalize kernel (which learns
+// the iteration range from the device state), polled one chunk behind as in ofx_run_loop_group.  On return unit_out[g] / k0_out[g] /
+// ucnt_out[g] describe the launch unit that contains iteration n_g - 1; when n_g - k0 < ucnt the loop ended INSIDE that unit and
+// redo(n_of, k0_of, unit_of) -- called once, entries -1 for the problems that need nothing -- must re-run its first n - k0
+// iterations from the unit's input buffers.
+template <class LaunchFn, class RedoFn>
+static int ofx_run_loop_cursor(ofx_ctx *ctx, const LoopSpec &L, int G, int units_per_chunk, int max_unit, LaunchFn launch, RedoFn redo,
+                               int *n_out, double *err_out, int *unit_out, int *inside_out, float *ms_out)
+{
+    if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "loop group of %d problems", G);
+    const int per = L.max_iter + 1;
+    OFX_TRY(ofx_loop_reserve(ctx, G * per));
+    LoopSpec S = L;
+    if (S.fixed) S.thr = -1.0;
+    OFX_TRY(ofx_loop_clear(ctx, (size_t) G * per));
+    if (ms_out) OFX_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+    const int max_out = ctx->concurrency > 1 ? 1 : 2;
+    const int upc = units_per_chunk < 1 ? 1 : units_per_chunk;
+    int launches = 0, head = 0, tail = 0, slot_of[2] = {0, 0}, seq_of[2] = {0, 0};
+    bool stop = false;
+    OfxIterState fin[OFX_MAX_GROUP];
+    int status = OFX_OK;
+    for (;;) {
+        while (launches < OFX_ULOG && head - tail < max_out) {
+            const int c = OFX_ULOG - launches < upc ? OFX_ULOG - launches : upc;
+            for (int i = 0; i < c && status == OFX_OK; i++) status = launch(launches++, S.thr);
+            if (status != OFX_OK) break;
+            const int seq = ofx_poll_seq(ctx);
+            const int slot = (int) (ctx->poll_seq++ % OFX_NPOLL);
+            status = ofx_loop_finalize_cursor(ctx, S, G, per, launches, c * max_unit, &ctx->h_state[slot * OFX_MAX_GROUP], seq);
+            if (status != OFX_OK) break;
+            slot_of[head & 1] = slot;
+            seq_of[head & 1] = seq;
+            if (hipEventRecord(ctx->ev_poll[slot], ctx->stream) != hipSuccess) { status = ofx_fail(ctx, OFX_ERR_HIP, "event record failed"); break; }
+            head++;
+        }
+        if (status != OFX_OK || tail == head) break;
+        const int slot = slot_of[tail & 1];
+        status = ofx_loop_wait_poll(ctx, slot, G, seq_of[tail & 1]);
+        if (status != OFX_OK) break;
+        bool all = true;
+        for (int g = 0; g < G; g++) {
+            fin[g] = ctx->h_state[slot * OFX_MAX_GROUP + g];
+            all = all && fin[g].done;
+        }
+        tail++;
+        if (all) { stop = true; break; }
+    }
+    if (status == OFX_OK && !stop) status = ofx_fail(ctx, OFX_ERR_HIP, "iteration loop ended without a final state");
+    if (status == OFX_OK) {
+        int n_of[OFX_MAX_GROUP], k0_of[OFX_MAX_GROUP], u_of[OFX_MAX_GROUP];
+        bool any = false;
+        for (int g = 0; g < G; g++) {
+            const bool inside = fin[g].n > 0 && fin[g].n - fin[g].k0 < fin[g].ucnt;
+            n_of[g] = inside ? fin[g].n : -1;
+            k0_of[g] = fin[g].k0;
+            u_of[g] = fin[g].unit;
+            any = any || inside;
+            n_out[g] = fin[g].n;
+            err_out[g] = fin[g].error;
+            unit_out[g] = fin[g].n > 0 ? fin[g].unit : -1;
+            if (inside_out) inside_out[g] = inside ? 1 : 0;
+        }
+        if (any) status = redo(n_of, k0_of, u_of);
+    }
+    if (status != OFX_OK) {
+        (void) hipStreamSynchronize(ctx->stream);       // nothing of this loop in flight when the caller resets the arena
+        return status;
+    }
+    if (ms_out) {
+        OFX_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+        OFX_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
+        OFX_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev_t0, ctx->ev_t1));
+    }
+    return OFX_OK;
 }

@@ -57,6 +57,84 @@ __global__ __launch_bounds__(1024) void k_loop_finalize(const double *__restrict
     }
 }
 
+// The same for a CURSOR loop (OfxLoopDev): the range of iterations a chunk of launches ran is device state -- from scanned[g]
+// to the cursor the chunk's last launch (index launch_end - 1) left behind.  When the loop is over the record also names the
+// launch unit that contains the stopping iteration (the largest j with ulog[j] <= n - 1: later launches were no-ops and logged
+// the unchanged cursor), so that the host can re-run its first iterations from its input.
+__global__ __launch_bounds__(1024) void k_loop_finalize_cursor(const double *__restrict__ err, int slots_per_problem, int launch_end,
+                                                               int max_iter, int size, double thr, int crit, OfxLoopDev *dev,
+                                                               OfxIterState *host_st, int seq)
+{
+    extern __shared__ double s_err[];
+    const int g = blockIdx.x;
+    err += (size_t) g * slots_per_problem * OFX_NSHARD;
+    OfxIterState *st = dev->st + g;
+    host_st += g;
+    if (st->done) {
+        if (threadIdx.x == 0) {
+            host_st->n = st->n;
+            host_st->error = st->error;
+            host_st->apred = 0;
+            host_st->unit = st->unit;
+            host_st->k0 = st->k0;
+            host_st->ucnt = st->ucnt;
+            host_st->done = st->done;
+            __threadfence_system();
+            __hip_atomic_store(&host_st->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    const int start = dev->scanned[g], launched = dev->cursor[launch_end & 1][g];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = start + w; k < launched; k += 16) {
+        const double e = loop_error_from_sum(wave_allreduce_sum(err[(size_t) k * OFX_NSHARD + lane]), size, crit);
+        if (lane == 0) s_err[k - start] = e;
+    }
+    __syncthreads();
+    if (w == 0) {
+        int n = launched, done = (launched >= max_iter);
+        double error = launched > start ? s_err[launched - start - 1] : st->error;
+        for (int k = start; k < launched; k++) {
+            if (!(s_err[k - start] > thr)) { n = k + 1; done = 1; error = s_err[k - start]; break; }
+        }
+        int unit = 0;
+        if (done && n > 0)
+            for (int j = launch_end - 1; j >= 0; j--)
+                if (dev->ulog[g][j] <= n - 1) { unit = j; break; }
+        if (lane == 0) {
+            const int k0 = dev->ulog[g][unit];
+            const int next = unit + 1 < launch_end ? dev->ulog[g][unit + 1] : launched;
+            st->n = n;
+            st->done = done;
+            st->error = error;
+            st->unit = unit;
+            st->k0 = k0;
+            st->ucnt = next - k0;
+            dev->scanned[g] = launched;
+            host_st->n = n;
+            host_st->error = error;
+            host_st->apred = 0;
+            host_st->unit = unit;
+            host_st->k0 = k0;
+            host_st->ucnt = next - k0;
+            host_st->done = done;
+            __threadfence_system();
+            __hip_atomic_store(&host_st->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+int ofx_loop_finalize_cursor(ofx_ctx *ctx, const LoopSpec &L, int G, int slots_per_problem, int launch_end, int max_range,
+                             OfxIterState *host_slot, int seq)
+{
+    const size_t shmem = sizeof(double) * (size_t) max_range;
+    hipLaunchKernelGGL(k_loop_finalize_cursor, dim3(G), dim3(1024), shmem, ctx->stream, (const double *) ctx->d_err, slots_per_problem,
+                       launch_end, L.max_iter, L.size, L.thr, L.crit, reinterpret_cast<OfxLoopDev *>(ctx->d_state), host_slot, seq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
+    return OFX_OK;
+}
+
 int ofx_loop_finalize_group(ofx_ctx *ctx, const LoopSpec &L, int G, int slots_per_problem, int start, int launched,
                             OfxIterState *host_slot, int seq)
 {

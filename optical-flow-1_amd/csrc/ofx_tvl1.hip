@@ -704,22 +704,38 @@ OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const
     if (CNT == 3) loop_accumulate(err, slot0 + 2 * slot_step, accC, gw);
 }
 
-// Launch unit j = iterations [3 j, 3 j + 3) (k0 = 3 j): same interface as k_tvl1_tile -- `check`: the stopping test on the three
-// error slots before k0; `nit`: iterations to run, 4 bits per pair (3 for a unit; 1 | 2 for a redo or a tail, whose errors all go
-// into slot0); pairs whose bit of runmask is clear are skipped.
+// Launch unit of up to three iterations.  Two ways to say which:
+//  * dev == nullptr (the re-run of a stopped unit's first iterations): k0, `check`, slot0 and `nit` (iterations to run, 4 bits per
+//    pair; all errors into slot0 when check == 0) as arguments -- the interface of k_tvl1_tile;
+//  * dev != nullptr, a CURSOR loop (ofx_loop.h): launch number `launch` of the loop; pair g starts at iteration
+//    k0 = dev->cursor[launch & 1][g] and runs 3 iterations -- or 2 when the error of iteration k0 - 1 is within afac2 of the
+//    threshold, 1 within afac1: the loop is about to stop, and everything computed past the stop is wasted and costs a re-run
+//    (the decision is a function of data every wave reads, so all waves of the pair take the same one).  One thread per pair
+//    leaves the next launch's cursor and logs where this one started, also when the launch is a no-op.
 template <typename T, bool NT, bool STRICT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFX_ITER3_WAVES, OFX_ITER3_WAVES))) void k_tvl1_iter3(
     Tri<typename Pix<T>::v2> Ut, Tri<typename Pix<T>::v2> P1t, Tri<typename Pix<T>::v2> P2t,
     const typename Pix<T>::v2 *__restrict__ Ag, const T *__restrict__ Rg, double *__restrict__ errg, int k0, int check, int slot0,
     int nx, int ny, int rows, int strips_x, int strips_pad, double l_t, double theta, double taut, double eps2, unsigned incode,
-    unsigned runmask, unsigned long long nit, int err_stride)
+    unsigned runmask, unsigned long long nit, int err_stride, OfxLoopDev *dev, int launch, double afac1, double afac2, int max_iter)
 {
     using v2 = typename Pix<T>::v2;
     const int lane = threadIdx.x & 63;
     const int gw = OFX_WAVE_UNIFORM((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave index
     const int g = blockIdx.y;
     if (!((runmask >> g) & 1u)) return;
-    const int niter = (int) ((nit >> (4 * g)) & 15ull);
+    int niter = (int) ((nit >> (4 * g)) & 15ull);
+    const bool scribe = dev && blockIdx.x == 0 && threadIdx.x == 0;       // the one thread that writes the pair's loop state
+    if (dev) {
+        k0 = dev->cursor[launch & 1][g];
+        slot0 = k0;
+        check = 1;
+        if (scribe) {
+            dev->ulog[g][launch] = k0;
+            dev->cursor[(launch + 1) & 1][g] = k0;                         // unless the launch turns out to do work (below)
+        }
+        if (k0 >= max_iter) return;
+    }
     const size_t npix = (size_t) nx * ny;
     const TriSel<v2> hu = pick3(Ut, incode, g, npix), h1 = pick3(P1t, incode, g, npix), h2 = pick3(P2t, incode, g, npix);
     const v2 *__restrict__ Uin = hu.in, *__restrict__ P1in = h1.in, *__restrict__ P2in = h2.in;
@@ -754,9 +770,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFX_ITER3_W
         cur = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off);
     }
     if (check) {                                            // stopping test of src/tvl1flow.cpp:113 -- the same decision in every wave
+        double e1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; i++)
-            if (k0 - i > 0 && !(loop_error_from_sum(wave_allreduce_sum(prev[i]), nx * ny, OFX_CRIT_MEAN) > eps2)) return;
+        for (int i = 0; i < 3; i++) {
+            if (k0 - i > 0) {
+                const double e = loop_error_from_sum(wave_allreduce_sum(prev[i]), nx * ny, OFX_CRIT_MEAN);
+                if (!(e > eps2)) return;
+                if (i == 0) e1 = e;
+            }
+        }
+        if (dev) {
+            niter = (k0 > 0 && e1 <= eps2 * afac1) ? 1 : ((k0 > 0 && e1 <= eps2 * afac2) ? 2 : 3);
+            if (niter > max_iter - k0) niter = max_iter - k0;
+            if (scribe) dev->cursor[(launch + 1) & 1][g] = k0 + niter;
+        }
     }
     if (idle) return;
     const int step = check ? 1 : 0;                         // a redo's errors all go into its one scratch slot
@@ -1400,9 +1427,11 @@ static int tvl1_run_iterations_tile(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Par
     return OFX_OK;
 }
 
-// tvl1_run_iterations through k_tvl1_iter3: launch unit j = iterations [3 j, 3 j + 3) reads buffer (b_g + j) % 3 and writes
-// (b_g + j + 1) % 3; a loop that ends inside a unit is finished by one more launch that re-runs the unit's first n - 3 j
-// iterations from its input (every pair with its own count) -- the scheme of the tile kernel.
+// tvl1_run_iterations through k_tvl1_iter3 as a CURSOR loop (ofx_loop.h): launch L reads buffer (b_g + L) % 3 of the rotation and
+// writes (b_g + L + 1) % 3 and runs three iterations -- two, or one, once the loop is about to stop (k_tvl1_iter3) --, so where a
+// unit starts is device state.  A loop that still ends inside a unit is finished by one more launch that re-runs the unit's first
+// n - k0 iterations from its input (every pair with its own count).  Option "fuse3_cursor" = 0: the round-3 scheme, fixed units of
+// three iterations with the iteration index passed from the host.
 template <typename T>
 static int tvl1_run_iterations_tri(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Params &P, LoopSpec S, int *n_out, double *err_out,
                                    float *ms_out, int *alt_out)
@@ -1421,45 +1450,77 @@ static int tvl1_run_iterations_tri(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Para
     const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
     unsigned b0[OFX_MAX_GROUP];
     for (int g = 0; g < G; g++) b0[g] = L.curidx(g);
-    auto go = [&](int k0, int check, int slot0, double thr, unsigned incode, unsigned runmask, unsigned long long nit) -> int {
+    const bool cursor = ctx->fuse3_cursor != 0 && !S.fixed;
+    // the error decays by 6-14 % per iteration near the threshold: within afac2 the loop has a handful of iterations left,
+    // within afac1 the next one is the last more often than not (A/B on one box, profiles/r04_ab_cursor_loop.txt: fixed units of three 68.1k, cursor loop 71.2-71.6k Mpix*warp-iters/s whatever the two ratios in 1.08-1.2 / 1.3-2.0; 1.2 leaves the fewest re-runs)
+    const double afac2 = ctx->fuse3_afac2 > 0 ? ctx->fuse3_afac2 : 1.5, afac1 = ctx->fuse3_afac1 > 0 ? ctx->fuse3_afac1 : 1.2;
+    auto go = [&](int k0, int check, int slot0, double thr, unsigned incode, unsigned runmask, unsigned long long nit, OfxLoopDev *dev,
+                  int launch) -> int {
         auto kern = nt_stores ? k_tvl1_iter3<T, true, false> : k_tvl1_iter3<T, false, false>;
         if constexpr (sizeof(T) == sizeof(double)) {
             if (strict) kern = nt_stores ? k_tvl1_iter3<T, true, true> : k_tvl1_iter3<T, false, true>;
         }
         hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, L.Ut(), L.P1t(), L.P2t(), L.A, (const T *) L.R, ctx->d_err, k0, check,
-                           slot0, nx, ny, rows, strips_x, strips_pad, l_t, theta, taut, thr, incode, runmask, nit, err_stride);
+                           slot0, nx, ny, rows, strips_x, strips_pad, l_t, theta, taut, thr, incode, runmask, nit, err_stride, dev, launch,
+                           afac1, afac2, S.max_iter);
         OFX_LAUNCH_CHECK(ctx);
         return OFX_OK;
     };
-    auto launch = [&](int k, int cnt, double thr) -> int {
-        unsigned incode = 0;
-        unsigned long long nit = 0;
-        for (int g = 0; g < G; g++) {
-            incode |= ((b0[g] + (unsigned) (k / 3)) % 3u) << (2 * g);
-            nit |= (unsigned long long) cnt << (4 * g);
-        }
-        return go(k, 1, k, thr, incode, all, nit);
+    auto code_of_unit = [&](unsigned unit) -> unsigned {
+        unsigned c = 0;
+        for (int g = 0; g < G; g++) c |= ((b0[g] + unit) % 3u) << (2 * g);
+        return c;
     };
-    auto redo = [&](const int *k_of) -> int {
-        unsigned incode = 0, runmask = 0;
-        unsigned long long nit = 0;
+    int unit_of[OFX_MAX_GROUP];
+    int inside[OFX_MAX_GROUP];
+    if (cursor) {
+        OfxLoopDev *dev = reinterpret_cast<OfxLoopDev *>(ctx->d_state);
+        auto launch = [&](int Lidx, double thr) -> int { return go(0, 1, 0, thr, code_of_unit((unsigned) Lidx), all, 0ull, dev, Lidx); };
+        auto redo = [&](const int *n_of, const int *k0_of, const int *u_of) -> int {
+            unsigned incode = 0, runmask = 0;
+            unsigned long long nit = 0;
+            for (int g = 0; g < G; g++) {
+                if (n_of[g] < 0) continue;
+                runmask |= 1u << g;
+                incode |= ((b0[g] + (unsigned) u_of[g]) % 3u) << (2 * g);
+                nit |= (unsigned long long) (n_of[g] - k0_of[g]) << (4 * g);
+            }
+            return go(0, 0, S.max_iter, -1.0, incode, runmask, nit, nullptr, 0);    // no stopping test; errors into the scratch slot
+        };
+        const int upc = (S.chunk + 2) / 3 < 1 ? 1 : (S.chunk + 2) / 3;
+        // the cursor loop reserves G * (max_iter + 1) slots itself; make sure the state block it clears is the large one
+        OFX_TRY(ofx_run_loop_cursor(ctx, S, G, upc, 3, launch, redo, n_out, err_out, unit_of, inside, ms_out));
+    } else {
+        auto launch = [&](int k, int cnt, double thr) -> int {
+            unsigned long long nit = 0;
+            for (int g = 0; g < G; g++) nit |= (unsigned long long) cnt << (4 * g);
+            return go(k, 1, k, thr, code_of_unit((unsigned) (k / 3)), all, nit, nullptr, 0);
+        };
+        auto redo = [&](const int *k_of) -> int {
+            unsigned incode = 0, runmask = 0;
+            unsigned long long nit = 0;
+            for (int g = 0; g < G; g++) {
+                if (k_of[g] < 0) continue;
+                const int n = k_of[g] + 1, j = (n - 1) / 3;
+                runmask |= 1u << g;
+                incode |= ((b0[g] + (unsigned) j) % 3u) << (2 * g);
+                nit |= (unsigned long long) (n - j * 3) << (4 * g);
+            }
+            return go(0, 0, S.max_iter, -1.0, incode, runmask, nit, nullptr, 0);
+        };
+        int took_alt[OFX_MAX_GROUP];
+        OFX_TRY(ofx_run_loop_group(ctx, S, G, launch, redo, n_out, err_out, ms_out, 0u, took_alt));
         for (int g = 0; g < G; g++) {
-            if (k_of[g] < 0) continue;
-            const int n = k_of[g] + 1, j = (n - 1) / 3;
-            runmask |= 1u << g;
-            incode |= ((b0[g] + (unsigned) j) % 3u) << (2 * g);
-            nit |= (unsigned long long) (n - j * 3) << (4 * g);
+            unit_of[g] = n_out[g] > 0 ? (n_out[g] - 1) / 3 : -1;
+            inside[g] = (n_out[g] % 3 != 0 && n_out[g] != S.max_iter) ? 1 : 0;
         }
-        return go(0, 0, S.max_iter, -1.0, incode, runmask, nit);     // no stopping test; errors into the scratch slot
-    };
-    int took_alt[OFX_MAX_GROUP];
-    OFX_TRY(ofx_run_loop_group(ctx, S, G, launch, redo, n_out, err_out, ms_out, 0u, took_alt));
+    }
     unsigned cur = 0;
     for (int g = 0; g < G; g++) {
-        const unsigned units = (unsigned) ((n_out[g] + 2) / 3);
+        const unsigned units = (unsigned) (unit_of[g] + 1);        // the result is the output of the unit that contains iteration n - 1
         cur |= ((b0[g] + units) % 3u) << (2 * g);
         L.last_n[g] = n_out[g];
-        if (alt_out) alt_out[g] = (n_out[g] % 3 != 0 && n_out[g] != S.max_iter) ? 1 : 0;    // ended inside a unit: its first iterations were re-run
+        if (alt_out) alt_out[g] = inside[g] ? 1 : 0;               // ended inside a unit: its first iterations were re-run
     }
     L.cur = cur;
     return OFX_OK;

@@ -30,10 +30,11 @@ for r in range(rounds):
             print(name, "FAILED", p.stderr[-500:])
             continue
         d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-        rec = {"value": d["value"], "fixed": d["fixed_work"]["value"], "launch_us": d["roofline"]["avg_launch_us"],
+        rec = {"value": d["value"], "fixed": d.get("fixed_work", {}).get("value"), "launch_us": d.get("roofline", {}).get("avg_launch_us"),
                "single_ms": d.get("single_pair", {}).get("device_resident", {}).get("ms_per_pair"),
                "host_ms": d.get("single_pair", {}).get("host_entry", {}).get("ms_per_pair"),
-               "fixed_single": d["fixed_work"]["single_pair"]["value"]}
+               "fixed_single": d.get("fixed_work", {}).get("single_pair", {}).get("value"),
+               "odd_stops": d.get("loop_ends", {}).get("odd_stops")}
         res[name].append(rec)
         print(r, name, json.dumps(rec), flush=True)
 for name, v in res.items():
