@@ -445,7 +445,7 @@ def sor_leg(ofx_mod, synth, local, dev, with_cpu=True):
             c.set_option("sor_exact", 1)
         modes["exact"]["mode"] = "exact (reference sweep order, bit-identical to the reference)"
         modes["tolerance"]["mode"] = ("sor_exact = 0: " + ("four-colour sweeps, 2 per launch on LDS tiles (k_hs_tile)" if name.startswith("hs") else
-                                      "finest level: checkerboard of 64 x 128 tiles, the reference's order inside a tile (k_brox_wave); coarser levels red-black"))
+                                      "finest level: checkerboard of 64 x 128 tiles, the reference's order inside a tile (k_brox_wave); coarser levels red-black, 4 sweeps per launch on LDS tiles (k_brox_tile)"))
         if ref is not None:
             fn = getattr(ref, ref_name)
             ref.set_num_threads(1)

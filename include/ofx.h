@@ -103,9 +103,10 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         everywhere: 1.3e-4).  Lone solves 5-10x faster than exact, lockstep groups supported.  On inputs where
  *                         the solves run into maxiter unconverged (the discontinuous pair P1 at 1080p) ANY re-ordering moves the
  *                         flow by as much as the reference's own OpenMP threads do (AEPE 2.5e-2) -- use the exact mode there.
- *   "sor_fuse"       sor_exact = 0, Horn-Schunck: sweeps per launch K = 1..4 (0 = default 2); -1 = the round-1 kernels, one
- *                         launch per colour and sweep (single pairs only; Brox: red-black on every level).  Results do not
- *                         depend on K.
+ *   "sor_fuse"       sor_exact = 0: sweeps per launch of the tile kernels, K = 1..4 (0 = default: Horn-Schunck 2, Brox's red-black
+ *                         levels 4); 9 = Brox's red-black levels through k_brox_sor, two launches per sweep (A/B); -1 = the round-1
+ *                         kernels, one launch per colour and sweep (single pairs only; Brox: red-black on every level).  Results
+ *                         do not depend on K.
  *   "sor_tile"       sor_exact = 0, Horn-Schunck: tile geometry 1 = 128 x 32 pixels on 16 waves, 2 = on 8 waves (default),
  *                         3 = 128 x 48 on 12 waves.  Results do not depend on it.
  *   "sor_wave_levels"  sor_exact = 0, Brox: pyramid levels 0 .. n - 1 use the checkerboard-of-tiles sweeps (default 1: the

@@ -222,7 +222,7 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
         return OFX_OK;
     }
     if (!strcmp(name, "sor_fuse")) {
-        if (value < -1 || value > 4) return ofx_fail(ctx, OFX_ERR_ARG, "sor_fuse must be -1 .. 4");
+        if ((value < -1 || value > 4) && value != 9) return ofx_fail(ctx, OFX_ERR_ARG, "sor_fuse must be -1 .. 4 (or 9)");
         ctx->sor_fuse = (int) value;
         return OFX_OK;
     }

@@ -1982,6 +1982,11 @@ static int brox_single_scale_dev(ofx_ctx *ctx, BroxLevel<T> &L, const BroxParams
                 };
                 OFX_TRY(sor_exact_loop(ctx, n, P.TOL, OFX_BROX_MAX_ITERATIONS, ny + nx - 2, BROX_PLANE_C, plane, save,
                                        restore, &nsor[0], &error[0]));
+            } else if (tol_mode && ctx->sor_fuse != 9) {
+                // the coarser levels of the tolerance mode: red-black, K sweeps per launch on LDS tiles (k_brox_tile; sor_fuse = 9:
+                // the two launches per sweep of k_brox_sor below, for A/B)
+                OFX_TRY(ofx_brox_tile_solve<T>(ctx, G, L.DU, L.DUck, L.CO, (const T *) L.Dm, (const T *) L.Psis, nx, ny, P.alpha, P.TOL,
+                                               OFX_BROX_MAX_ITERATIONS, ctx->sor_fuse, nsor, error, ctx->profile ? &ms : nullptr));
             } else if (error[0] > P.TOL) {
                 LoopSpec LS;
                 LS.max_iter = OFX_BROX_MAX_ITERATIONS;

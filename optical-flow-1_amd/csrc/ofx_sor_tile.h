@@ -23,3 +23,10 @@ template <typename V, bool IN> int ofx_band_copy(ofx_ctx *ctx, const V *src, V *
 template <typename T>
 int ofx_brox_wave_solve(ofx_ctx *ctx, int G, typename Pix<T>::v2 *DUb, const typename Pix<T>::v4 *COb, const T *Dmb, const T *Psb,
                         int nx, int ny, double alpha, double TOL, int maxiter, int *niter, double *error, float *ms);
+
+// Brox, the levels below those: red-black sweeps ((i + j) even first, the order of k_brox_sor and oracle.set_sor_order(1)), K per
+// launch on LDS tiles (k_brox_tile).  DU0 holds (du, dv) on entry and on return; DU1 is the second buffer of the ping-pong.
+template <typename T>
+int ofx_brox_tile_solve(ofx_ctx *ctx, int G, typename Pix<T>::v2 *DU0, typename Pix<T>::v2 *DU1, const typename Pix<T>::v4 *CO,
+                        const T *Dm, const T *Ps, int nx, int ny, double alpha, double TOL, int maxiter, int K, int *niter, double *error,
+                        float *ms);

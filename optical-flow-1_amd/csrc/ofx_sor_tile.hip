@@ -750,3 +750,303 @@ template int ofx_brox_wave_solve<double>(ofx_ctx *, int, double2 *, const double
                                          double, int, int *, double *, float *);
 template int ofx_brox_wave_solve<float>(ofx_ctx *, int, float2 *, const float4 *, const float *, const float *, int, int, double, double,
                                         int, int *, double *, float *);
+
+// ============================================================================================================================
+// Brox, the coarser levels: red-black sweeps, K per launch on LDS tiles (k_brox_tile)
+// ============================================================================================================================
+// Below the levels that k_brox_wave sweeps, the order is the red-black one of k_brox_sor (ofx_sor.hip; (i + j) even first) -- the
+// result does not depend on tiles, K or the group -- but as ONE launch per K sweeps instead of two per sweep: k_brox_sor touches
+// every cache line in both colour passes (190 B per pixel-sweep at the HBM side, 2.4 x the 80 B unit, profiles/r04_sor_traffic.json)
+// and a lone solve on these levels is a chain of ~8 us launches.  The tile scheme is k_hs_tile's: cells of 2 x 2 pixels (two of
+// either colour), lane = cell column, the unknowns AND psi_s published in LDS colour planes, a pixel's other operands -- (Au, Av,
+// Du, Dv), D -- in registers; the 5-point stencil needs two LDS reads per operand plane (the other two neighbours are the cell's
+// own pixels), a sweep's dependency cone is 2 pixels in x and y, so K sweeps recompute a halo of 2 K.  A missing neighbour at the
+// image border is the pixel itself with psi = 0 (:332-388), i.e. a select, no apron.
+#define BRT_PS_BASE(CR) (4 * ((CR) + 2) * HST_PW)     // the psi_s planes follow the four planes of unknowns (as doubles)
+
+template <int CR, int CI, int CJ, int DI, int DJ>
+OFX_DEV double2 brt_nb_u(const double2 *s_u, int a_row, int lane, const double2 (&uc)[4])
+{
+    constexpr int si = CI + DI, sj = CJ + DJ;
+    if constexpr (si >= 0 && si <= 1 && sj >= 0 && sj <= 1) {
+        return uc[si * 2 + sj];
+    } else {
+        constexpr int plane = ((si & 1) << 1) | (sj & 1);
+        constexpr int drow = si < 0 ? -1 : si / 2, dcol = sj < 0 ? -1 : sj / 2;
+        return s_u[hst_at<CR>(plane, a_row + drow, lane + dcol)];
+    }
+}
+template <int CR, int CI, int CJ, int DI, int DJ>
+OFX_DEV double brt_nb_ps(const double *s_ps, int a_row, int lane, const double (&pc)[4])
+{
+    constexpr int si = CI + DI, sj = CJ + DJ;
+    if constexpr (si >= 0 && si <= 1 && sj >= 0 && sj <= 1) {
+        return pc[si * 2 + sj];
+    } else {
+        constexpr int plane = ((si & 1) << 1) | (sj & 1);
+        constexpr int drow = si < 0 ? -1 : si / 2, dcol = sj < 0 ? -1 : sj / 2;
+        return s_ps[hst_at<CR>(plane, a_row + drow, lane + dcol)];
+    }
+}
+
+struct BrtCoef {
+    double au, av, du, dv, dm;
+};
+
+// SOR update of one pixel, src/brox_optic_flow_spatial.cpp:129-172 (the expressions of brox_point_finish in ofx_sor.hip)
+template <typename T, int CR, int CI, int CJ>
+OFX_DEV double2 brt_update(const double2 *s_u, const double *s_ps, int a_row, int lane, const double2 (&uc)[4], const double (&pc)[4],
+                           const BrtCoef &k, double alpha, bool top, bool bot, bool lef, bool rig, double &e)
+{
+    const double2 c = uc[CI * 2 + CJ];
+    const double psc = pc[CI * 2 + CJ];
+    const double2 dn0 = brt_nb_u<CR, CI, CJ, 1, 0>(s_u, a_row, lane, uc), up0 = brt_nb_u<CR, CI, CJ, -1, 0>(s_u, a_row, lane, uc);
+    const double2 rt0 = brt_nb_u<CR, CI, CJ, 0, 1>(s_u, a_row, lane, uc), lf0 = brt_nb_u<CR, CI, CJ, 0, -1>(s_u, a_row, lane, uc);
+    const double pdn = brt_nb_ps<CR, CI, CJ, 1, 0>(s_ps, a_row, lane, pc), pup = brt_nb_ps<CR, CI, CJ, -1, 0>(s_ps, a_row, lane, pc);
+    const double prt = brt_nb_ps<CR, CI, CJ, 0, 1>(s_ps, a_row, lane, pc), plf = brt_nb_ps<CR, CI, CJ, 0, -1>(s_ps, a_row, lane, pc);
+    const double dnx = bot ? c.x : dn0.x, dny = bot ? c.y : dn0.y, upx = top ? c.x : up0.x, upy = top ? c.y : up0.y;
+    const double rtx = rig ? c.x : rt0.x, rty = rig ? c.y : rt0.y, lfx = lef ? c.x : lf0.x, lfy = lef ? c.y : lf0.y;
+    const double p1 = bot ? 0.0 : 0.5 * (pdn + psc);                    // src/brox_spatial_mask.cpp:16-93
+    const double p2 = top ? 0.0 : 0.5 * (pup + psc);
+    const double p3 = rig ? 0.0 : 0.5 * (prt + psc);
+    const double p4 = lef ? 0.0 : 0.5 * (plf + psc);
+    const double w = BRW_SOR_W;
+    double du = k.du, dv = k.dv;
+#ifndef OFX_HST_HOIST
+    asm volatile("" : "+v"(du), "+v"(dv));                              // the reciprocals stay in the loop (registers, k_hs_tile)
+#endif
+    const double ru = rcp_newton(du), rv = rcp_newton(dv);
+    const double div_du = p1 * dnx + p2 * upx + p3 * rtx + p4 * lfx;    // :153-154
+    const double div_dv = p1 * dny + p2 * upy + p3 * rty + p4 * lfy;    // :155-156
+    const double duk = c.x, dvk = c.y;
+    const double dun = tile_rnd<T>((1. - w) * duk + hst_div(w * (k.au - k.dm * dvk + alpha * div_du), du, ru));   // :162
+    const double dvn = tile_rnd<T>((1. - w) * dvk + hst_div(w * (k.av - k.dm * dun + alpha * div_dv), dv, rv));   // :163
+    e = (dun - duk) * (dun - duk) + (dvn - dvk) * (dvn - dvk);          // :166
+    return make_double2(dun, dvn);
+}
+
+// one pixel colour (CI, CJ) of the cells of a thread in sweep s (red = (0,0) and (1,1), black = (0,1) and (1,0))
+template <typename T, int K, int TH, int NW, int CI, int CJ>
+OFX_DEV double brt_colour_step(double2 *s_u, const double *s_ps, int w, int lane, int x0, int y0, int nx, int ny, int s,
+                               double2 (&u)[TH / 2 / NW][4], const double (&ps)[TH / 2 / NW][4], const BrtCoef (&kf)[TH / 2 / NW][4],
+                               const HstFlags &fl, double alpha)
+{
+    constexpr int CR = TH / 2, CPT = CR / NW, C = CI * 2 + CJ;
+    const int lj = 2 * lane + CJ, jj = x0 + lj;
+    const bool colx = (unsigned) (lj - (2 * s + 1)) <= (unsigned) (HST_W - 3 - 4 * s);      // columns [2 s + 1, W - 2 - 2 s]
+    const bool lef = jj == 0, rig = jj == nx - 1;
+    unsigned f_in = fl.inside, f_own = fl.owner;
+    asm volatile("" : "+v"(f_in), "+v"(f_own));
+    double e = 0.0;
+#pragma unroll
+    for (int m = 0; m < CPT; m++) {
+        const int a_row = w + NW * m;
+        const int li = 2 * a_row + CI, ii = y0 + li;
+        const bool rowy = (unsigned) (li - (2 * s + 1)) <= (unsigned) (TH - 3 - 4 * s);      // rows [2 s + 1, TH - 2 - 2 s]
+        const bool active = colx && rowy && hst_bit(f_in, m * 4 + C);
+        double e1;
+        const double2 un = brt_update<T, CR, CI, CJ>(s_u, s_ps, a_row, lane, u[m], ps[m], kf[m][C], alpha, ii == 0, ii == ny - 1, lef, rig, e1);
+        e += (active && hst_bit(f_own, m * 4 + C)) ? e1 : 0.0;
+        u[m][C].x = active ? un.x : u[m][C].x;
+        u[m][C].y = active ? un.y : u[m][C].y;
+        s_u[hst_at<CR>(C, a_row, lane)] = u[m][C];                       // (an inactive cell rewrites its own value: no aprons here)
+    }
+    return e;
+}
+
+template <typename T, int K, int TH, int NW>
+__global__ __launch_bounds__(64 * NW) void k_brox_tile(typename Pix<T>::v2 *DU0, typename Pix<T>::v2 *DU1,
+                                                       const typename Pix<T>::v4 *__restrict__ COg, const T *__restrict__ Dmg,
+                                                       const T *__restrict__ Psg, double *__restrict__ errg, int k0, int check, int slot0,
+                                                       int nx, int ny, int tiles_x, double alpha, double tol, unsigned incode,
+                                                       unsigned runmask, unsigned long long nit, int err_stride)
+{
+    using v2 = typename Pix<T>::v2;
+    using v4 = typename Pix<T>::v4;
+    static_assert((TH / 2) % NW == 0 && TH % 2 == 0 && K >= 1 && K < 16 && HST_W - 4 * K > 0 && TH - 4 * K > 0, "tile geometry");
+    constexpr int CR = TH / 2, CPT = CR / NW, HX = 2 * K, HY = 2 * K, OW = HST_W - 2 * HX, OH = TH - 2 * HY;
+    extern __shared__ double2 s_u[];                        // four planes of unknowns, then four of psi_s (hst_at, BRT_PS_BASE)
+    double *s_ps = reinterpret_cast<double *>(s_u + BRT_PS_BASE(CR));
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int g = blockIdx.y;
+    if (!((runmask >> g) & 1u)) return;
+    const int niter = (int) ((nit >> (4 * g)) & 15ull);
+    const size_t npix = (size_t) nx * ny;
+    const bool from1 = (incode >> g) & 1u;
+    const v2 *__restrict__ Uin = (from1 ? DU1 : DU0) + (size_t) g * npix;
+    v2 *__restrict__ Uout = (from1 ? DU0 : DU1) + (size_t) g * npix;
+    const v4 *__restrict__ CO = COg + (size_t) g * npix;
+    const T *__restrict__ Dm = Dmg + (size_t) g * npix;
+    const T *__restrict__ Ps = Psg + (size_t) g * npix;
+    double *__restrict__ err = errg + (size_t) g * err_stride;
+    double prev[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) prev[i] = (check && k0 - i > 0) ? loop_fetch_prev(err, k0 - i) : 0.0;
+
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x0 = tx * OW - HX, y0 = ty * OH - HY;         // both even: tile parity = image parity
+    double2 u[CPT][4];
+    double ps[CPT][4];
+    BrtCoef kf[CPT][4];
+    HstFlags fl = {0u, 0u, 0u};
+#pragma unroll
+    for (int m = 0; m < CPT; m++) {
+        const int a_row = w + NW * m;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int li = 2 * a_row + (c >> 1), lj = 2 * lane + (c & 1), ii = y0 + li, jj = x0 + lj;
+            const int ic = ii < 0 ? 0 : (ii > ny - 1 ? ny - 1 : ii), jc = jj < 0 ? 0 : (jj > nx - 1 ? nx - 1 : jj);
+            const unsigned p = (unsigned) ic * (unsigned) nx + (unsigned) jc;                       // element index; clamped into the image
+            u[m][c] = ldw2(hst_off(Uin, p * (unsigned) sizeof(v2)));
+            const double4 co = ldw4(hst_off(CO, p * (unsigned) sizeof(v4)));
+            kf[m][c].au = co.x;
+            kf[m][c].av = co.y;
+            kf[m][c].du = co.z;
+            kf[m][c].dv = co.w;
+            kf[m][c].dm = ldw(hst_off(Dm, p * (unsigned) sizeof(T)));
+            ps[m][c] = ldw(hst_off(Ps, p * (unsigned) sizeof(T)));
+            const bool inside = ii >= 0 && ii < ny && jj >= 0 && jj < nx;
+            const unsigned bit = 1u << (m * 4 + c);
+            fl.inside |= inside ? bit : 0u;
+            fl.owner |= (inside && li >= HY && li < TH - HY && lj >= HX && lj < HST_W - HX) ? bit : 0u;
+        }
+    }
+    asm volatile("" : "+v"(fl.inside), "+v"(fl.owner));
+    if (check) {                                            // :315 -- the same decision in every wave, before the first barrier
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if (k0 - i > 0 && !(loop_error_from_sum(wave_allreduce_sum(prev[i]), nx * ny, OFX_CRIT_SQRT_MEAN) > tol)) return;
+    }
+#pragma unroll
+    for (int m = 0; m < CPT; m++) {
+        const int a_row = w + NW * m;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            s_u[hst_at<CR>(c, a_row, lane)] = u[m][c];
+            s_ps[hst_at<CR>(c, a_row, lane)] = ps[m][c];
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < niter; s++) {
+        double e = brt_colour_step<T, K, TH, NW, 0, 0>(s_u, s_ps, w, lane, x0, y0, nx, ny, s, u, ps, kf, fl, alpha);
+        e += brt_colour_step<T, K, TH, NW, 1, 1>(s_u, s_ps, w, lane, x0, y0, nx, ny, s, u, ps, kf, fl, alpha);
+        __syncthreads();
+        e += brt_colour_step<T, K, TH, NW, 0, 1>(s_u, s_ps, w, lane, x0, y0, nx, ny, s, u, ps, kf, fl, alpha);
+        e += brt_colour_step<T, K, TH, NW, 1, 0>(s_u, s_ps, w, lane, x0, y0, nx, ny, s, u, ps, kf, fl, alpha);
+        __syncthreads();
+        loop_accumulate(err, slot0 + (check ? s : 0), e, blockIdx.x * NW + w);
+    }
+#pragma unroll
+    for (int m = 0; m < CPT; m++) {
+        const int a_row = w + NW * m;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int ii = y0 + 2 * a_row + (c >> 1), jj = x0 + 2 * lane + (c & 1);
+            if (hst_bit(fl.owner, m * 4 + c)) stn2(hst_off(Uout, ((unsigned) ii * (unsigned) nx + (unsigned) jj) * (unsigned) sizeof(v2)), u[m][c]);
+        }
+    }
+}
+
+// pairs whose bit of `mask` is set: dst <- src (the tile sweeps' result back into the buffer the rest of the level reads)
+template <typename V> __global__ void k_copy_pairs(const V *__restrict__ src, V *__restrict__ dst, size_t npix, unsigned mask)
+{
+    if (!((mask >> blockIdx.y) & 1u)) return;
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npix) dst[blockIdx.y * npix + i] = src[blockIdx.y * npix + i];
+}
+
+template <typename T, int K, int TH, int NW>
+static int brox_tile_launch(ofx_ctx *ctx, int G, typename Pix<T>::v2 *DU0, typename Pix<T>::v2 *DU1, const typename Pix<T>::v4 *CO,
+                            const T *Dm, const T *Ps, int k0, int check, int slot0, int nx, int ny, double alpha, double thr,
+                            unsigned incode, unsigned runmask, unsigned long long nit, int err_stride)
+{
+    constexpr int OW = HST_W - 4 * K, OH = TH - 4 * K;
+    const int tiles_x = ofx_cdiv(nx, OW), tiles_y = ofx_cdiv(ny, OH);
+    const size_t lds = (size_t) BRT_PS_BASE(TH / 2) * (sizeof(double2) + sizeof(double));
+    if (lds > 64 * 1024)
+        OFX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_brox_tile<T, K, TH, NW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipLaunchKernelGGL((k_brox_tile<T, K, TH, NW>), dim3((unsigned) (tiles_x * tiles_y), G), dim3(64 * NW), lds, ctx->stream, DU0, DU1, CO,
+                       Dm, Ps, ctx->d_err, k0, check, slot0, nx, ny, tiles_x, alpha, thr, incode, runmask, nit, err_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "brox tile launch failed: %s", hipGetErrorString(e));
+    return OFX_OK;
+}
+
+// One solve of the coarser levels; DU0 holds the incoming (du, dv), DU1 is the second buffer of the ping-pong; on return the
+// result is in DU0 again for every pair (k_copy_pairs for those whose last launch wrote DU1).
+template <typename T>
+int ofx_brox_tile_solve(ofx_ctx *ctx, int G, typename Pix<T>::v2 *DU0, typename Pix<T>::v2 *DU1, const typename Pix<T>::v4 *CO,
+                        const T *Dm, const T *Ps, int nx, int ny, double alpha, double TOL, int maxiter, int K, int *niter, double *error,
+                        float *ms)
+{
+    if (G < 1 || G > OFX_MAX_GROUP) return ofx_fail(ctx, OFX_ERR_ARG, "brox: group of %d pairs", G);
+    if ((double) nx * ny * sizeof(typename Pix<T>::v4) >= 4294967296.0)
+        return ofx_fail(ctx, OFX_ERR_ARG, "brox: tile sweeps address a level with 32-bit byte offsets (%dx%d is too large)", nx, ny);
+    for (int g = 0; g < G; g++) { niter[g] = 0; error[g] = 1000; }                                   // :312
+    if (maxiter <= 0 || !(1000.0 > TOL)) return OFX_OK;
+    if (K <= 0) K = 4;                                      // measured (config 4): one pair 42.6 (k_brox_sor) / 45.5 / 40.6 / 37.8 ms for K = 1 / 2 / 4,
+                                                            // batches of 48 37.4 / 41.6 / 45.3 / 45.3 % of the HBM peak on the 80 B unit
+    if (K > 4) K = 4;
+    if (K == 3) K = 2;                                      // instantiated: 1, 2, 4
+    LoopSpec S;
+    S.max_iter = maxiter;
+    S.size = nx * ny;
+    S.thr = TOL;
+    S.crit = OFX_CRIT_SQRT_MEAN;
+    S.fixed = ctx->fixed_work != 0;
+    S.pairs = K == 2;
+    S.fuse = K > 2 ? K : 0;
+    S.afac = 0.0;
+    if (ctx->chunk > 0) S.chunk = ctx->chunk;
+    else {
+        const double tiles = (double) ofx_cdiv(nx, HST_W - 4 * K) * ofx_cdiv(ny, 32 - 4 * K) * G;
+        const double est_us = 3.0 + 2.5 * K * (tiles < 256.0 ? 1.0 : tiles / 256.0);
+        int units = (int) (80.0 / est_us);
+        units = units < 1 ? 1 : (units > 8 ? 8 : units);
+        S.chunk = units * K;
+    }
+    const int err_stride = (S.max_iter + 1) * OFX_NSHARD;
+    const unsigned all = (G >= 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
+    auto go = [&](int k0, int check, int slot0, double thr, unsigned incode, unsigned runmask, unsigned long long nit) -> int {
+        switch (K) {
+        case 1: return brox_tile_launch<T, 1, 32, 16>(ctx, G, DU0, DU1, CO, Dm, Ps, k0, check, slot0, nx, ny, alpha, thr, incode, runmask, nit, err_stride);
+        case 2: return brox_tile_launch<T, 2, 32, 16>(ctx, G, DU0, DU1, CO, Dm, Ps, k0, check, slot0, nx, ny, alpha, thr, incode, runmask, nit, err_stride);
+        default: return brox_tile_launch<T, 4, 32, 16>(ctx, G, DU0, DU1, CO, Dm, Ps, k0, check, slot0, nx, ny, alpha, thr, incode, runmask, nit, err_stride);
+        }
+    };
+    auto launch = [&](int k, int cnt, double thr) -> int {
+        const unsigned flip = ((k / K) & 1) ? all : 0u;      // unit j reads DU0 when j is even (every pair starts in DU0)
+        unsigned long long nit = 0;
+        for (int g = 0; g < G; g++) nit |= (unsigned long long) cnt << (4 * g);
+        return go(k, 1, k, thr, flip, all, nit);
+    };
+    auto redo = [&](const int *k_of) -> int {
+        unsigned incode = 0, runmask = 0;
+        unsigned long long nit = 0;
+        for (int g = 0; g < G; g++) {
+            if (k_of[g] < 0) continue;
+            const int n = k_of[g] + 1, j = (n - 1) / K;
+            runmask |= 1u << g;
+            incode |= ((unsigned) j & 1u) << g;
+            nit |= (unsigned long long) (n - j * K) << (4 * g);
+        }
+        return go(0, 0, S.max_iter, -1.0, incode, runmask, nit);
+    };
+    OFX_TRY(ofx_run_loop_group(ctx, S, G, launch, redo, niter, error, ms));
+    unsigned in1 = 0;
+    for (int g = 0; g < G; g++) in1 |= ((unsigned) ((niter[g] + K - 1) / K) & 1u) << g;
+    if (in1) {
+        const size_t npix = (size_t) nx * ny;
+        hipLaunchKernelGGL((k_copy_pairs<typename Pix<T>::v2>), dim3((unsigned) ((npix + 255) / 256), G), dim3(256), 0, ctx->stream,
+                           (const typename Pix<T>::v2 *) DU1, DU0, npix, in1);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return ofx_fail(ctx, OFX_ERR_HIP, "copy launch failed: %s", hipGetErrorString(e));
+    }
+    return OFX_OK;
+}
+template int ofx_brox_tile_solve<double>(ofx_ctx *, int, double2 *, double2 *, const double4 *, const double *, const double *, int, int,
+                                         double, double, int, int, int *, double *, float *);
+template int ofx_brox_tile_solve<float>(ofx_ctx *, int, float2 *, float2 *, const float4 *, const float *, const float *, int, int, double,
+                                        double, int, int, int *, double *, float *);

@@ -103,7 +103,7 @@ def test_hs_tile_lockstep_group_equals_pairs_solved_alone(gpu64, tol, synth, G, 
 
 
 BROX_CASES = [("P0", 64, 48, 2, 64, 1), ("P1", 160, 120, 3, 128, 1), ("P1", 135, 68, 2, 32, 2), ("P1", 300, 130, 2, 128, 1), ("P0", 33, 70, 1, 16, 1),
-              ("P1", 257, 75, 2, 64, 2), ("P1", 70, 129, 1, 128, 1), ("P0", 16, 12, 1, 128, 1)]
+              ("P1", 257, 75, 2, 64, 2), ("P1", 70, 129, 1, 128, 1), ("P0", 16, 12, 1, 128, 1), ("P1", 300, 130, 3, 128, 0), ("P1", 135, 68, 2, 128, 0)]
 
 
 @pytest.mark.parametrize("pair,nx,ny,ns,tw,wl", BROX_CASES)
@@ -115,12 +115,14 @@ def test_brox_tile_sweeps_equal_the_oracle(gpu64, tol, synth, pair, nx, ny, ns, 
     tol.set_sor_wave_levels(wl)
     gpu64.set_option("sor_tile_w", tw)
     gpu64.set_option("sor_wave_levels", wl)
-    for P in (0, 2, 8):
+    uo, vo, it_o = tol.brox_spatial(I1, I2, **kw)
+    # prefetch depth of k_brox_wave x sweeps per launch of k_brox_tile (the levels below; 9 = k_brox_sor, two launches per sweep)
+    for P, K in ((0, 0), (2, 1), (8, 4), (4, 9)):
         gpu64.set_option("sor_wave_p", P)
-        uo, vo, it_o = tol.brox_spatial(I1, I2, **kw)
+        gpu64.set_option("sor_fuse", K)
         ug, vg = gpu64.brox_spatial(I1, I2, **kw)
-        assert np.array_equal(gpu64.stats().iterations(), it_o), P
-        assert np.array_equal(ug, uo) and np.array_equal(vg, vo), P
+        assert np.array_equal(gpu64.stats().iterations(), it_o), (P, K)
+        assert np.array_equal(ug, uo) and np.array_equal(vg, vo), (P, K)
 
 
 @pytest.mark.parametrize("G", [1, 3, 16])

@@ -91,9 +91,10 @@ if "--no-big" not in sys.argv:
     t0 = time.perf_counter()
     ref = orc.brox_spatial(I1, I2, **kw)
     print("oracle brox (reference order, 1 thread) %.2f s, sweeps %d" % (time.perf_counter() - t0, int(np.asarray(ref[2]).sum())), flush=True)
-    for wl, tw in ((0, 64), (1, 64), (1, 128), (2, 64), (6, 64)):
+    for wl, tw, K in ((0, 128, 9), (0, 128, 2), (1, 128, 9), (1, 128, 1), (1, 128, 2), (1, 128, 4), (1, 64, 2)):
         ctx.set_option("sor_wave_levels", wl)
         ctx.set_option("sor_tile_w", tw)
+        ctx.set_option("sor_fuse", K)
         ctx.brox_spatial(I1, I2, **kw)
         ts = []
         for _ in range(3):
@@ -101,7 +102,7 @@ if "--no-big" not in sys.argv:
             ug, vg = ctx.brox_spatial(I1, I2, **kw)
             ts.append(time.perf_counter() - t0)
         st = ctx.stats()
-        print(json.dumps({"cfg4": "brox 1280x720", "wave_levels": wl, "tile_w": tw, "seconds": round(min(ts), 4), "sweeps": int(st.iterations().sum()),
+        print(json.dumps({"cfg4": "brox 1280x720", "wave_levels": wl, "tile_w": tw, "K": K, "seconds": round(min(ts), 4), "sweeps": int(st.iterations().sum()),
                           "per_level": [int(x) for x in st.iterations().sum(axis=1)],
                           "mpix_sweeps_per_s": round(st.work_pix_iters / min(ts) / 1e6, 1),
                           "aepe_vs_reference_order": aepe((ug, vg), ref)}), flush=True)
