@@ -103,7 +103,7 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *                         everywhere: 1.3e-4).  Lone solves 5-10x faster than exact, lockstep groups supported.  On inputs where
  *                         the solves run into maxiter unconverged (the discontinuous pair P1 at 1080p) ANY re-ordering moves the
  *                         flow by as much as the reference's own OpenMP threads do (AEPE 2.5e-2) -- use the exact mode there.
- *   "sor_fuse"       sor_exact = 0: sweeps per launch of the tile kernels, K = 1..4 (0 = default: Horn-Schunck 2, Brox's red-black
+ *   "sor_fuse"       sor_exact = 0: sweeps per launch of the tile kernels, K = 1..4 (0 = default: Horn-Schunck 2 in lockstep groups of >= 4 pairs, else 4; Brox's red-black
  *                         levels 4); 9 = Brox's red-black levels through k_brox_sor, two launches per sweep (A/B); -1 = the round-1
  *                         kernels, one launch per colour and sweep (single pairs only; Brox: red-black on every level).  Results
  *                         do not depend on K.

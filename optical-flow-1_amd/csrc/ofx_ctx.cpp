@@ -123,7 +123,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     mark("hipStreamCreate");
     static_assert(sizeof(OfxLoopDev) <= OFX_STATE_BYTES && OFX_STATE_BYTES % 512 == 0, "state block too small");
-    static_assert(OFX_ULOG >= OFX_TVL1_MAX_ITERATIONS / 2 + 8, "unit log too short");
+    static_assert(OFX_ULOG >= OFX_TVL1_MAX_ITERATIONS + 16, "unit log too short");
     ok = ok && hipMalloc((void **) &ctx->d_state, OFX_STATE_BYTES + sizeof(double) * OFX_TVL1_MAX_ITERATIONS * OFX_NSHARD) == hipSuccess;
     if (ok) ctx->d_err = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_state) + OFX_STATE_BYTES);
     ctx->d_err_cap = OFX_TVL1_MAX_ITERATIONS;

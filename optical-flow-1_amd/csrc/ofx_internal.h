@@ -35,7 +35,7 @@ struct OfxIterState {
 // iteration count from the previous iteration's error, and ONE thread of it writes cursor[(L + 1) & 1][g] and ulog[g][L] (the
 // other blocks of launch L may not have read their cursor yet: two copies by launch parity).  scanned[g]: iterations the
 // finalize kernels have looked at.  The whole block is zeroed with the error slots at the start of every loop.
-#define OFX_ULOG 160           // launches of one loop: OFX_TVL1_MAX_ITERATIONS / 2 + slack (a unit has >= 2 iterations unless it is the tail)
+#define OFX_ULOG 320           // launches of one loop: a unit may be a single iteration, so up to OFX_TVL1_MAX_ITERATIONS of them (+ no-ops behind the stop)
 struct OfxLoopDev {
     OfxIterState st[OFX_MAX_GROUP];
     int cursor[2][OFX_MAX_GROUP];
@@ -43,7 +43,7 @@ struct OfxLoopDev {
     int ulog[OFX_MAX_GROUP][OFX_ULOG];
 };
 
-#define OFX_STATE_BYTES 11776  // >= sizeof(OfxLoopDev), a multiple of 512: keeps the error slots 512-byte aligned
+#define OFX_STATE_BYTES 22016  // >= sizeof(OfxLoopDev), a multiple of 512: keeps the error slots 512-byte aligned
 
 struct OfxSlab {
     char  *base;

@@ -1474,8 +1474,10 @@ static int tvl1_run_iterations_tri(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Para
     int unit_of[OFX_MAX_GROUP];
     int inside[OFX_MAX_GROUP];
     if (cursor) {
-        OfxLoopDev *dev = reinterpret_cast<OfxLoopDev *>(ctx->d_state);
-        auto launch = [&](int Lidx, double thr) -> int { return go(0, 1, 0, thr, code_of_unit((unsigned) Lidx), all, 0ull, dev, Lidx); };
+        // (ctx->d_state is read at launch time: the loop driver may re-allocate the state block before the first launch)
+        auto launch = [&](int Lidx, double thr) -> int {
+            return go(0, 1, 0, thr, code_of_unit((unsigned) Lidx), all, 0ull, reinterpret_cast<OfxLoopDev *>(ctx->d_state), Lidx);
+        };
         auto redo = [&](const int *n_of, const int *k0_of, const int *u_of) -> int {
             unsigned incode = 0, runmask = 0;
             unsigned long long nit = 0;

@@ -21,10 +21,11 @@ FULL_SIZE_ONLY_DEFAULT = ("test_full_size", "test_4k_size", "test_headline_launc
                           "test_batch_dev_on_four_contexts", "test_f32_mode_is_as_accurate", "test_tile_kernel")
 
 
-@pytest.fixture(autouse=True, params=[0, 4, -3], ids=["strips", "tile4", "fuse3"])
+@pytest.fixture(autouse=True, params=[0, 4, -3, -4], ids=["strips", "tile4", "fuse3", "fuse3_fixed_units"])
 def tile_mode(request, gpu64, gpu32):
     """which iteration kernel: the marching strips with two iterations per launch (default), the 2-D tile kernel (tile = 4), the
-    marching strips with three iterations per launch (fuse3 = 1)"""
+    marching strips with three iterations per launch (fuse3 = 1) as a cursor loop (units shrink near the end of a loop, the
+    default) and with fixed units of three (fuse3_cursor = 0)"""
     if request.node.name.startswith(FULL_SIZE_ONLY_DEFAULT):
         if request.param != 0:
             pytest.skip("full-size case: default kernel choice only")
@@ -32,11 +33,45 @@ def tile_mode(request, gpu64, gpu32):
         return
     for c in (gpu64, gpu32):
         c.set_option("tile", request.param if request.param > 0 else 0)
-        c.set_option("fuse3", 1 if request.param == -3 else 0)
+        c.set_option("fuse3", 1 if request.param in (-3, -4) else 0)
+        c.set_option("fuse3_cursor", 0 if request.param == -4 else 1)
     yield request.param
     for c in (gpu64, gpu32):
         c.set_option("tile", 0)
         c.set_option("fuse3", 2)
+        c.set_option("fuse3_cursor", 1)
+
+
+@pytest.mark.parametrize("afac1,afac2", [(1.2, 1.5), (1e-9, 1e-9), (1e9, 1e9), (1e-9, 1e9), (1.05, 3.0)])
+def test_cursor_loop_unit_sizes_do_not_change_the_result(gpu64, orc, synth, afac1, afac2, tile_mode):
+    """k_tvl1_iter3 as a cursor loop: when a launch runs 3, 2 or 1 iterations is a performance decision (error / threshold ratios
+    afac2, afac1) -- never 2 or 1 (1e-9), always 1 (1e9), always 2, odd ratios: iteration tables and flows equal the oracle's in all
+    of them, for a lone pair and a lockstep group whose pairs stop at different iterations."""
+    if tile_mode != -3:
+        pytest.skip("cursor loop only")
+    import torch
+    gpu64.set_option("fuse3_afac1", afac1)
+    gpu64.set_option("fuse3_afac2", afac2)
+    try:
+        nx, ny, G = 150, 97, 5
+        pairs = [synth.pair("P0" if k % 3 == 2 else "P1", nx, ny, k) for k in range(G)]
+        want = [orc.tvl1_multiscale(p[0], p[1], nscales=3, **PAR) for p in pairs]
+        u, v = gpu64.tvl1_multiscale(pairs[0][0], pairs[0][1], nscales=3, **PAR)
+        assert np.array_equal(gpu64.stats().iterations(), want[0][2])
+        assert np.abs(u - want[0][0]).max() < 1e-9 and np.abs(v - want[0][1]).max() < 1e-9
+        d0 = [torch.from_numpy(p[0]).cuda() for p in pairs]
+        d1 = [torch.from_numpy(p[1]).cuda() for p in pairs]
+        flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device="cuda")
+        st = gpu64.tvl1_group_dev([t.data_ptr() for t in d0], [t.data_ptr() for t in d1], [flo[k].data_ptr() for k in range(G)], nx, ny,
+                                  nscales=3, **PAR)
+        gpu64.synchronize()
+        got = flo.cpu().numpy()
+        for k in range(G):
+            assert np.array_equal(st[k].iterations(), want[k][2]), k
+            assert np.array_equal(got[k], np.stack([want[k][0], want[k][1]], axis=-1).astype(np.float32)), k
+    finally:
+        gpu64.set_option("fuse3_afac1", 0)
+        gpu64.set_option("fuse3_afac2", 0)
 
 
 def linearised_state(orc, synth, nx, ny, seed=0):
