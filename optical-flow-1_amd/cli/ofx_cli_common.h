@@ -10,7 +10,8 @@
 #include "ofx_io.h"
 
 /* OFX_DEVICE = GPU index (default 0); OFX_PRECISION = f64 (default, strict) | f32 (float storage); OFX_TOLERANCE=1: the f64
- * tolerance mode of the TV-L1 dual update (option relaxed_dual; not byte-identical .flo files); OFX_STATS: see cli_write_stats */
+ * tolerance mode of the TV-L1 dual update (option relaxed_dual; not byte-identical .flo files); OFX_SOR_TOLERANCE=1: the tolerance
+ * mode of the SOR solvers (option sor_exact = 0); OFX_STATS: see cli_write_stats */
 static ofx_ctx *cli_context(void)
 {
     const char *d = getenv("OFX_DEVICE"), *p = getenv("OFX_PRECISION");
@@ -24,6 +25,8 @@ static ofx_ctx *cli_context(void)
     }
     if (getenv("OFX_STATS")) ofx_set_option(ctx, "profile", 1);       /* HIP-event times of the iteration launches per scale */
     if (getenv("OFX_TOLERANCE")) ofx_set_option(ctx, "relaxed_dual", atoi(getenv("OFX_TOLERANCE")) != 0);
+    /* OFX_SOR_TOLERANCE=1: Horn-Schunck / Brox with re-ordered sweeps inside the AEPE < 1e-4 bar (option sor_exact = 0) */
+    if (getenv("OFX_SOR_TOLERANCE")) ofx_set_option(ctx, "sor_exact", atoi(getenv("OFX_SOR_TOLERANCE")) != 0 ? 0 : 1);
     return ctx;
 }
 

@@ -129,7 +129,9 @@ OFX_DEV double2 hst_nb(const double2 *s_u, int a_row, int lane, const double2 (&
 // SOR update of one pixel, src/horn_schunck_pyramidal.cpp:31-71 (the expressions of hs_point_finish in ofx_sor.hip):
 // p1..p4 = up-left, up-right, bottom-left, bottom-right, p5..p8 = up, left, bottom, right; the bottom-right corner of the image
 // lists its diagonal taps bottom pair first (:222-228).  Returns the new value; e = the squared update (:70).
-template <typename T, int CR, int CI, int CJ>
+// CORNER = false: the caller knows the pixel is not the image's bottom-right corner (any row but the last one -- a wave-uniform
+// fact), and the operand swap, eight register moves per update, is not even compiled in.
+template <typename T, int CR, int CI, int CJ, bool CORNER = true>
 OFX_DEV double2 hst_update(const double2 *s_u, int a_row, int lane, const double2 (&uc)[4], const HstCoef &k, double alpha2, bool corner,
                            double &e)
 {
@@ -137,7 +139,7 @@ OFX_DEV double2 hst_update(const double2 *s_u, int a_row, int lane, const double
     double2 p3 = hst_nb<CR, CI, CJ, 1, -1>(s_u, a_row, lane, uc), p4 = hst_nb<CR, CI, CJ, 1, 1>(s_u, a_row, lane, uc);
     const double2 p5 = hst_nb<CR, CI, CJ, -1, 0>(s_u, a_row, lane, uc), p6 = hst_nb<CR, CI, CJ, 0, -1>(s_u, a_row, lane, uc);
     const double2 p7 = hst_nb<CR, CI, CJ, 1, 0>(s_u, a_row, lane, uc), p8 = hst_nb<CR, CI, CJ, 0, 1>(s_u, a_row, lane, uc);
-    if (corner) {
+    if (CORNER && corner) {
         const double2 t1 = p1, t2 = p2;
         p1 = p3; p2 = p4; p3 = t1; p4 = t2;
     }
@@ -187,9 +189,10 @@ OFX_DEV double hst_colour_step(double2 *s_u, int w, int lane, int x0, int y0, in
         const int li = 2 * a_row + CI;
         const bool rowy = (unsigned) (li - (2 * s + 1)) <= (unsigned) (TH - 3 - 4 * s);          // wave-uniform
         const bool active = colx && rowy && hst_bit(f_in, m * 4 + C);
-        const bool corner = y0 + li == ny - 1 && x0 + lj == nx - 1;
         double e1;
-        const double2 un = hst_update<T, CR, CI, CJ>(s_u, a_row, lane, u[m], kf[m][C], alpha2, corner, e1);
+        double2 un;
+        if (y0 + li == ny - 1) un = hst_update<T, CR, CI, CJ, true>(s_u, a_row, lane, u[m], kf[m][C], alpha2, x0 + lj == nx - 1, e1);   // wave-uniform test
+        else un = hst_update<T, CR, CI, CJ, false>(s_u, a_row, lane, u[m], kf[m][C], alpha2, false, e1);
         e += (active && hst_bit(f_own, m * 4 + C)) ? e1 : 0.0;
         u[m][C].x = active ? un.x : u[m][C].x;
         u[m][C].y = active ? un.y : u[m][C].y;

@@ -139,6 +139,32 @@ def test_other_front_ends_run(synth, tmp_path):
     assert np.array_equal(f, np.stack([g["u"], g["v"]], axis=-1).astype(np.float32))
 
 
+def test_sor_front_ends_in_the_tolerance_mode(orc, synth, tmp_path):
+    """OFX_SOR_TOLERANCE=1: the SOR front-ends with the re-ordered sweeps of option sor_exact = 0 -- the .flo equals the oracle's
+    restatement of those sweep orders bit for bit (and differs from the exact mode's, which is the reference's)"""
+    nx, ny = 200, 140
+    I0, I1 = synth.pair("P1", nx, ny)
+    write_pgm(tmp_path / "a.pgm", I0)
+    write_pgm(tmp_path / "b.pgm", I1)
+    env = dict(os.environ, OFX_SOR_TOLERANCE="1")
+    orc.set_sor_order(1)
+    orc.set_sor_wave_levels(1)
+    try:
+        r = subprocess.run([os.path.join(BIN, "horn_schunck_pyramidal"), str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"),
+                            str(tmp_path / "h.flo"), "0", "20", "3", "0.5", "4", "0.0001", "150", "0"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        uo, vo, _ = orc.hs_pyramidal(I0, I1, alpha=20.0, nscales=3, zfactor=0.5, warps=4, TOL=1e-4, maxiter=150)
+        assert np.array_equal(read_flo(tmp_path / "h.flo"), np.stack([uo, vo], axis=-1).astype(np.float32))
+        r = subprocess.run([os.path.join(BIN, "brox_spatial"), str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"),
+                            str(tmp_path / "x.flo"), "0", "50", "10", "3", "0.5", "0.0001", "1", "4", "0"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        uo, vo, _ = orc.brox_spatial(I0, I1, alpha=50.0, gamma=10.0, nscales=3, nu=0.5, TOL=1e-4, inner=1, outer=4)
+        assert np.array_equal(read_flo(tmp_path / "x.flo"), np.stack([uo, vo], axis=-1).astype(np.float32))
+    finally:
+        orc.set_sor_order(0)
+        orc.set_sor_wave_levels(0)
+
+
 def test_batch_front_end_writes_the_same_flo_as_tvl1flow(orc, synth, tmp_path):
     """optical-flow-1_amd/batch_run.py on one GPU: 3 pairs from PGM files -> 3 .flo files, byte-identical to
     the single-pair results (and, rehearsing the 2-rank path over gloo on the same GPU, identical again)."""
