@@ -250,3 +250,56 @@ def test_robust_expo_random_configurations(gpu64, orc, synth, seed):
     ug, vg = gpu64.robust_expo(I1, I2, **kw)
     assert np.array_equal(gpu64.stats().iterations()[:ns, :it.shape[1]], it), kw
     assert np.abs(ug - uo).max() < 1e-11 and np.abs(vg - vo).max() < 1e-11, kw
+
+
+FUZZ_SOR_TOL = int(os.environ.get("OFX_FUZZ_SOR_TOL", "6"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_SOR_TOL))
+def test_sor_tolerance_mode_random_lockstep_groups(gpu64, orc, synth, seed):
+    """The tolerance-mode sweeps (option sor_exact = 0, csrc/ofx_sor_tile.hip) on random sizes, pyramid depths, groups, sweeps per
+    launch, tile geometries, tile widths and tile levels: every pair's sweep table and .flo payload equal the oracle's restatement
+    of the same sweep order, bit for bit (the result may depend on NONE of the performance knobs)."""
+    import torch
+    rng = np.random.default_rng((1700 if FUZZ_SEED == 2026 else 6000 * FUZZ_SEED) + seed)
+    nx, ny, G = int(rng.integers(20, 300)), int(rng.integers(16, 200)), int(rng.choice([1, 2, 3, 5, 16]))
+    ns = 3 if min(nx, ny) >= 80 else (2 if min(nx, ny) >= 40 else 1)
+    pairs = [synth.pair("P0" if k % 4 == 3 else "P1", nx, ny, k) for k in range(G)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in pairs]
+    d1 = [torch.from_numpy(p[1]).cuda() for p in pairs]
+    flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ptr = lambda ts: [t.data_ptr() for t in ts]
+    tw, wl = int(rng.choice([16, 50, 64, 128])), int(rng.choice([0, 1, 1, 2]))
+    opts = (("sor_exact", 0), ("sor_fuse", int(rng.choice([0, 1, 2, 3, 4]))), ("sor_tile", int(rng.choice([0, 1, 2, 3]))),
+            ("sor_tile_w", tw), ("sor_wave_levels", wl), ("sor_wave_p", int(rng.choice([0, 2, 6]))))
+    for name, val in opts:
+        gpu64.set_option(name, val)
+    orc.set_sor_order(1)
+    orc.set_sor_tile(tw, 64)
+    orc.set_sor_wave_levels(wl)
+    try:
+        hk = dict(alpha=float(rng.choice([7.0, 20.0])), nscales=ns, zfactor=0.5, warps=int(rng.integers(1, 4)),
+                  TOL=float(rng.choice([1e-4, 1e-3])), maxiter=int(rng.choice([5, 6, 7, 150])))
+        st = gpu64.hs_group_dev(ptr(d0), ptr(d1), [flo[k].data_ptr() for k in range(G)], nx, ny, **hk)
+        gpu64.synchronize()
+        got = flo.cpu().numpy().copy()
+        for k in range(G):
+            uo, vo, it = orc.hs_pyramidal(pairs[k][0], pairs[k][1], **hk)
+            assert np.array_equal(st[k].iterations(), it), ("hs", k, G, nx, ny, hk, opts)
+            assert np.array_equal(got[k], np.stack([uo, vo], axis=-1).astype(np.float32)), ("hs", k, G, nx, ny, opts)
+        bk = dict(alpha=float(rng.choice([50.0, 18.0])), gamma=float(rng.choice([10.0, 0.0])), nscales=ns, nu=0.5, TOL=1e-4,
+                  inner=int(rng.integers(1, 3)), outer=int(rng.integers(1, 4)))
+        st = gpu64.brox_group_dev(ptr(d0), ptr(d1), [flo[k].data_ptr() for k in range(G)], nx, ny, **bk)
+        gpu64.synchronize()
+        got = flo.cpu().numpy().copy()
+        for k in range(G):
+            uo, vo, it = orc.brox_spatial(pairs[k][0], pairs[k][1], **bk)
+            assert np.array_equal(st[k].iterations(), it), ("brox", k, G, nx, ny, bk, opts)
+            assert np.array_equal(got[k], np.stack([uo, vo], axis=-1).astype(np.float32)), ("brox", k, G, nx, ny, opts)
+    finally:
+        orc.set_sor_order(0)
+        orc.set_sor_tile(128, 64)
+        orc.set_sor_wave_levels(0)
+        for name, val in (("sor_exact", 1), ("sor_fuse", 0), ("sor_tile", 0), ("sor_tile_w", 0), ("sor_wave_levels", 1), ("sor_wave_p", 0)):
+            gpu64.set_option(name, val)
