@@ -34,7 +34,7 @@ for log in sorted(glob.glob(os.path.join(src, "fetch_*.log"))):
                 for r in csv.DictReader(open(kt)):
                     dur[r["Kernel_Name"].split("(")[0].split("<")[0]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     for name, v in per.items():
-        if not any(k in name for k in ("k_hs_window", "k_brox_window", "k_hs_tile", "k_brox_wave", "k_brox_sor", "k_hs_sor")):
+        if not any(k in name for k in ("k_hs_window", "k_brox_window", "k_hs_tile", "k_brox_wave", "k_brox_tile", "k_brox_sor", "k_hs_sor")):
             continue
         rd, wr = 2.0 * v.get("FETCH_SIZE", 0.0) * 1024, v.get("WRITE_SIZE", 0.0) * 1024
         rec["kernels"][name] = {"dispatches": cnt[name], "read_bytes": rd, "write_bytes": wr,
