@@ -216,6 +216,33 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def sor_source_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ofx_sor.hip", "ofx_sor_tile.hip", "ofx_device.h", "ofx_loop.h"):
+        h.update(open(os.path.join(ROOT, "optical-flow-1_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def sor_traffic(solver, mode):
+    """HBM-side traffic of the sweep kernels per pixel-sweep from the committed counter passes (tools/sessions/r04_06_sor_traffic.sh:
+    one full-resolution single-scale group solve per --pmc pass), with the stale flag of roofline.traffic"""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r04_sor_traffic.json")))
+    except Exception:
+        return None
+    tags = {("hs", "exact"): ["hs_exact_global", "hs_exact_lds"], ("hs", "tolerance"): ["hs_tolerance_k2", "hs_tolerance_k4"],
+            ("brox", "exact"): ["brox_exact_global", "brox_exact_lds"],
+            ("brox", "tolerance"): ["brox_tolerance", "brox_redblack_tile_k4", "brox_redblack_two_launches_per_sweep"]}[(solver, mode)]
+    out = {"source": "profiles/r04_sor_traffic.json (builder-run rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; not "
+                     "measured by this run)", "stale": j.get("kernel_source_sha16") != sor_source_sha16(), "kernels": {}}
+    for t in tags:
+        for name, r in j.get(t, {}).get("kernels", {}).items():
+            out["kernels"]["%s (%s)" % (name.replace("void ", ""), t)] = {"bytes_per_pixel_sweep": round(r["bytes_per_pixel_sweep"], 1),
+                                                                          "traffic_over_compulsory": round(r["traffic_over_compulsory"], 3)}
+    return out
+
+
 def load_pmc():
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -443,6 +470,10 @@ def sor_leg(ofx_mod, synth, local, dev, with_cpu=True):
                                                         "pairs_desc": "P0 + 47 P1 variants, device-resident"})}
         for c in ctxs + [solo]:
             c.set_option("sor_exact", 1)
+        for mode in modes:
+            tr = sor_traffic("hs" if name.startswith("hs") else "brox", mode)
+            if tr:
+                modes[mode]["traffic"] = tr
         modes["exact"]["mode"] = "exact (reference sweep order, bit-identical to the reference)"
         modes["tolerance"]["mode"] = ("sor_exact = 0: " + ("four-colour sweeps, 2 per launch on LDS tiles (k_hs_tile)" if name.startswith("hs") else
                                       "finest level: checkerboard of 64 x 128 tiles, the reference's order inside a tile (k_brox_wave); coarser levels red-black, 4 sweeps per launch on LDS tiles (k_brox_tile)"))

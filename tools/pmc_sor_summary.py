@@ -6,7 +6,11 @@ passes; divided by the pixel-sweeps the run printed; against SURVEY 8(d)'s unit 
 Prints one JSON object (committed as profiles/r04_sor_traffic.json)."""
 import collections, csv, glob, json, os, sys
 src = sys.argv[1]
-out = {"note": __doc__.split("Prints")[0].strip()}
+import hashlib
+_h = hashlib.sha256()
+for _f in ("ofx_sor.hip", "ofx_sor_tile.hip", "ofx_device.h", "ofx_loop.h"):      # what bench.py's sor_source_sha16() hashes
+    _h.update(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "optical-flow-1_amd", "csrc", _f), "rb").read())
+out = {"note": __doc__.split("Prints")[0].strip(), "kernel_source_sha16": _h.hexdigest()[:16]}
 for log in sorted(glob.glob(os.path.join(src, "fetch_*.log"))):
     tag = os.path.basename(log)[len("fetch_"):-len(".log")]
     meta = None
