@@ -142,7 +142,9 @@ int   ofx_set_option(ofx_ctx *ctx, const char *name, double value);
  *   "rof_window"     steps per launch of the ROF box sweeps: 10 (default) or 24 (the round-2 geometry, 143 KB of LDS per workgroup)
  *   "chi_fuse"       1/0  Solver_wrt_chi: 5 iterations per launch on overlapping LDS tiles (default 1); 0 = two launches per
  *                         iteration.  Results do not depend on either.
- *   "gauss_fused"    1/0  pyramids of lockstep groups: row + column pass of the Gaussian in one launch (default 1)
+ *   "gauss_fused"    pyramids of lockstep groups: 1 (default) row + column pass of the Gaussian in one launch, and for zfactor = 1/2
+ *                         the whole zoom_out (smoothing + 2:1 sampling) in one; 3 = without the zoom_out fusion, 2 = the
+ *                         generic-radius fused kernel, 0 = two passes.  Results do not depend on it.
  *   "spin_us"        microseconds the host spins on a convergence poll's pinned record before it sleeps in
  *                         hipEventSynchronize (default 150; 0 = never)
  *   "warp_lds"       1/0  TV-L1 warp with the bicubic taps staged through LDS (default 1)

@@ -208,7 +208,7 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
         return OFX_OK;
     }
     if (!strcmp(name, "relaxed_dual")) { ctx->relaxed_dual = value != 0; return OFX_OK; }
-    if (!strcmp(name, "gauss_fused")) { ctx->gauss_fused = value == 2 ? 2 : (value != 0); return OFX_OK; }   // 2: the generic-radius fused kernel
+    if (!strcmp(name, "gauss_fused")) { ctx->gauss_fused = (value == 2 || value == 3) ? (int) value : (value != 0); return OFX_OK; }   // 2: the generic-radius fused kernel; 3: radius-templated, zoom_out not fused
     if (!strcmp(name, "warp_lds")) { ctx->warp_lds = value != 0; return OFX_OK; }
     if (!strcmp(name, "nt_stores")) { ctx->nt_stores = (int) value; return (value >= 0 && value <= 2) ? OFX_OK : ofx_fail(ctx, OFX_ERR_ARG, "nt_stores = 0 | 1 | 2"); }
     if (!strcmp(name, "lockstep")) {

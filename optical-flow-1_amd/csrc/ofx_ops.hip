@@ -383,6 +383,61 @@ __global__ __launch_bounds__(256) void k_gauss_xy_gr(OfxPlanes2<const T> in_p, O
         if (i < ny) stn(out + (size_t) i * nx + j, sum);
     }
 }
+// zoom_out with zfactor = 1/2 (src/zoom.cpp:41-78) in ONE launch: the bicubic sample of the smoothed image at (2 j1, 2 i1) is the
+// smoothed pixel itself -- at integer coordinates cubic_interpolation_cell returns v1 + 0.5 * 0 * (...) = v1 in both directions
+// (src/bicubic_interpolation.cpp:108-145; the smoothed values are >= 0, so no signed zero is involved) -- and 2 j1 <= nx - 1 for
+// every output column of zoom_size.  So only the even columns of the row pass and the even rows of the column pass are computed
+// (same sums in the same order per pixel), written straight into the coarser level: the smoothed full-size image is neither
+// stored nor re-read (26 -> 10 bytes per input pixel) and the resample launch disappears.
+#define GXD_THO 12                                               // output rows per block (24 input rows + 2 R of halo)
+template <typename T, int R>
+__global__ __launch_bounds__(256) void k_gauss_xy_dec(OfxPlanes2<const T> in_p, OfxPlanes2<T> out_p, int nx, int ny, int nxo, int nyo,
+                                                      GaussTaps taps)
+{
+    constexpr int W = 128 + 2 * R, H = 2 * GXD_THO + 2 * R;
+    __shared__ double s_in[H * W];
+    __shared__ double s_mid[H * 64];
+    const T *__restrict__ in = in_p.at(blockIdx.z);
+    T *__restrict__ out = out_p.at(blockIdx.z);
+    const int j0 = blockIdx.x * 128, i0 = blockIdx.y * 2 * GXD_THO;       // origin of the block's input region
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    int jc[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        int j = gauss_reflect(j0 - R + tx + 64 * q, nx);
+        jc[q] = j < 0 ? 0 : (j > nx - 1 ? nx - 1 : j);
+    }
+    for (int r = ty; r < H; r += 4) {
+        int i = gauss_reflect(i0 - R + r, ny);
+        i = i < 0 ? 0 : (i > ny - 1 ? ny - 1 : i);
+        const T *__restrict__ row = in + (size_t) i * nx;
+        s_in[r * W + tx] = ldw(row + jc[0]);
+        s_in[r * W + tx + 64] = ldw(row + jc[1]);
+        if (tx < 2 * R) s_in[r * W + tx + 128] = ldw(row + jc[2]);
+    }
+    __syncthreads();
+    for (int r = ty; r < H; r += 4) {                            // row pass at the even columns, operators.cpp:541-575
+        const double *row = s_in + r * W + R + 2 * tx;
+        double sum = taps.B[0] * row[0];
+#pragma unroll
+        for (int k = 1; k <= R; k++) sum += taps.B[k] * (row[-k] + row[k]);
+        s_mid[r * 64 + tx] = sizeof(T) == sizeof(float) ? (double) (float) sum : sum;
+    }
+    __syncthreads();
+    const int jo = blockIdx.x * 64 + tx;
+    if (jo >= nxo) return;
+    constexpr int SEG = GXD_THO / 4;                             // output rows per thread
+#pragma unroll
+    for (int o = 0; o < SEG; o++) {                              // column pass at the even rows, :577-611
+        const int lo = ty * SEG + o, io = blockIdx.y * GXD_THO + lo;
+        const double *c = s_mid + (R + 2 * lo) * 64 + tx;
+        double sum = taps.B[0] * c[0];
+#pragma unroll
+        for (int k = 1; k <= R; k++) sum += taps.B[k] * (c[-k * 64] + c[k * 64]);
+        if (io < nyo) stn(out + (size_t) io * nxo + jo, sum);
+    }
+}
+
 template <typename T>
 static void gauss_xy_launch(ofx_ctx *ctx, dim3 grid, OfxPlanes2<const T> in, OfxPlanes2<T> out, int nx, int ny, const GaussTaps &taps)
 {
@@ -790,6 +845,16 @@ int op_build_pyramid_group(ofx_ctx *ctx, int G, const void *const *dA, const voi
         for (int s = 1; s < nscales; s++) {
             const int nx = nxs[s - 1], ny = nys[s - 1];
             const size_t st = (size_t) nx * ny;
+            GaussTaps tz;
+            if (ctx->gauss_fused == 1 && zfactor == 0.5 && ofx_gauss_taps(zsigma, &tz) == OFX_OK && tz.size - 1 == 5 && tz.size < nx &&
+                tz.size < ny && 2 * (nxs[s] - 1) <= nx - 1 && 2 * (nys[s] - 1) <= ny - 1) {
+                // smoothing and the 2:1 sampling in one launch (k_gauss_xy_dec)
+                hipLaunchKernelGGL((k_gauss_xy_dec<T, 5>), dim3(ofx_cdiv(nxs[s], 64), ofx_cdiv(nys[s], GXD_THO), 2 * G), dim3(64, 4), 0,
+                                   ctx->stream, OfxPlanes2<const T>{lvA[s - 1], lvB[s - 1], G, st},
+                                   OfxPlanes2<T>{lvA[s], lvB[s], G, (size_t) nxs[s] * nys[s]}, nx, ny, nxs[s], nys[s], tz);
+                OFX_LAUNCH_CHECK(ctx);
+                continue;
+            }
             OFX_TRY(gauss_xy(lvA[s - 1], lvB[s - 1], tmpB, tmpB + (size_t) G * st, nx, ny, zsigma));
             dim3 g = grid2d(nxs[s], nys[s]);
             g.z = 2 * G;

@@ -349,15 +349,16 @@ def test_lockstep_group_f32_equals_single_pair_f32(ofx_mod, gpu32, synth):
 
 @pytest.mark.parametrize("zfactor", [0.5, 0.62, 0.75, 0.9])
 def test_fused_gaussian_kernels_agree(gpu64, synth, zfactor):
-    """The pyramids' presmoothing / zoom Gaussians exist three times: two passes through memory (gauss_fused = 0), both passes in
-    one launch for any radius (2), and with the radius a template parameter and a register window in the column pass (1, the
-    default; the zoom factors here give radii 1 ... 5).  Same sums in the same order: the flows of a group must not differ by a bit."""
+    """The pyramids' presmoothing / zoom Gaussians exist four times: two passes through memory (gauss_fused = 0), both passes in
+    one launch for any radius (2), with the radius a template parameter and a register window in the column pass (3), and -- the
+    default, 1 -- that kernel plus, for zfactor = 1/2, the whole zoom_out (smoothing + 2:1 sampling) in one launch (k_gauss_xy_dec;
+    odd and even level sizes).  Same sums in the same order: the flows of a group must not differ by a bit."""
     import torch
     nx, ny, G = 203, 131, 3
     dev = torch.device("cuda")
     pairs = [synth.pair_device("P1", nx, ny, k, dev) for k in range(G)]
     outs = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         gpu64.set_option("gauss_fused", mode)
         flo = torch.zeros((G, ny, nx, 2), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
@@ -368,6 +369,7 @@ def test_fused_gaussian_kernels_agree(gpu64, synth, zfactor):
     gpu64.set_option("gauss_fused", 1)
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
     assert torch.equal(outs[0].view(torch.int32), outs[2].view(torch.int32))
+    assert torch.equal(outs[0].view(torch.int32), outs[3].view(torch.int32))
     assert torch.isfinite(outs[1]).all() and float(outs[1].abs().max()) > 0.0
 
 
