@@ -96,6 +96,7 @@ extern "C" int ofx_ctx_create(ofx_ctx **out, int device, int precision)
     ctx->fuse3_afac1 = 0;
     ctx->fuse3_afac2 = 0;
     ctx->rows_per_wave3 = 0;
+    ctx->rows3_max = 32;
     ctx->fixed_work = 0;
     ctx->sor_exact = 1;
     ctx->sor_batch = 0;
@@ -300,6 +301,7 @@ extern "C" int ofx_set_option(ofx_ctx *ctx, const char *name, double value)
     if (!strcmp(name, "fuse3_afac1")) { ctx->fuse3_afac1 = value; return value >= 0 ? OFX_OK : ofx_fail(ctx, OFX_ERR_ARG, "fuse3_afac1 < 0"); }
     if (!strcmp(name, "fuse3_afac2")) { ctx->fuse3_afac2 = value; return value >= 0 ? OFX_OK : ofx_fail(ctx, OFX_ERR_ARG, "fuse3_afac2 < 0"); }
     if (!strcmp(name, "rows_per_wave3")) { ctx->rows_per_wave3 = (int) value; return OFX_OK; }
+    if (!strcmp(name, "rows3_max")) { ctx->rows3_max = (int) value; return OFX_OK; }
     if (!strcmp(name, "spin_us")) {
         if (value < 0 || value > 1e6) return ofx_fail(ctx, OFX_ERR_ARG, "spin_us out of range");
         ctx->spin_us = (int) value;

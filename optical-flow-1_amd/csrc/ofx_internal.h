@@ -94,6 +94,7 @@ struct ofx_ctx {
     int fuse3_cursor;   // 1 (default): k_tvl1_iter3 as a cursor loop -- units shrink to 2 / 1 iterations near the end of a loop; 0: fixed units of 3
     double fuse3_afac1, fuse3_afac2;   // ... error / threshold ratios below which a unit runs 1 / 2 iterations (0 = 1.2 / 1.5)
     int rows_per_wave3; // strip height of k_tvl1_iter3 (0 = tvl1_pick_rows3)
+    int rows3_max;      // tallest strip tvl1_pick_rows3 considers when contexts share the device
     int chi_fuse;       // Solver_wrt_chi: 1 = CHI_N iterations per launch on LDS tiles (default), 0 = two launches per iteration
     int rof_window;     // steps per launch of the ROF box sweeps: 10 (default, also 0) | 24
     int rof_pipe;       // ROF box sweeps (ofx_occ.hip): 1 = all iterations of a call in flight (default), 0 = one at a time

@@ -106,7 +106,7 @@ OFX_DEV double2 tvl1_primal(double2 u, double2 a, double r, double2 p1, double2 
     const double grad = ix * ix + iy * iy;                  // :100-104
     const double rho = r + (ix * u.x + iy * u.y);           // :119-120
     const double ltg = l_t * grad;
-    const double fi = STRICT ? -rho / grad : -rho * rcp_newton(grad);   // used only where grad >= TVL1_GRAD_IS_ZERO
+    const double fi = STRICT ? -rho / grad : -rho * rcp_tol(grad);   // used only where grad >= TVL1_GRAD_IS_ZERO
     double d1, d2;
     if (rho < -ltg)                     { d1 = l_t * ix;  d2 = l_t * iy; }
     else if (rho > ltg)                 { d1 = -l_t * ix; d2 = -l_t * iy; }
@@ -197,13 +197,13 @@ OFX_DEV void tvl1_dual(double2 p1, double2 p2, double2 un, double r1, double r2,
         q2.y = (p2.y + taut * u2y) / ng2;
 #endif
     } else {
-        // no bit-exactness to keep here: the square root and the reciprocal are the bare rsq / rcp iterations of the compiler's
-        // own expansions (<= 1 ulp), without their range scaling and fix-ups -- the clamp keeps rsq finite at |grad u| = 0,
-        // where sqrt(2^-600) = 2^-300 vanishes in 1 + taut g; the denominators are >= 1
-        const double g1 = sqrt_unscaled(fmax(u1x * u1x + u1y * u1y, 0x1p-600));
-        const double g2 = sqrt_unscaled(fmax(u2x * u2x + u2y * u2y, 0x1p-600));
-        const double i1 = rcp_newton(1.0 + taut * g1);
-        const double i2 = rcp_newton(1.0 + taut * g2);
+        // no bit-exactness to keep here: the square root and the reciprocal are one refinement step on the rsq / rcp estimates
+        // (sqrt_tol / rcp_tol, ~2^-45), without range scaling and fix-ups -- the clamp keeps rsq finite at |grad u| = 0, where
+        // sqrt(2^-600) = 2^-300 vanishes in 1 + taut g; the denominators are >= 1
+        const double g1 = sqrt_tol(fmax(u1x * u1x + u1y * u1y, 0x1p-600));
+        const double g2 = sqrt_tol(fmax(u2x * u2x + u2y * u2y, 0x1p-600));
+        const double i1 = rcp_tol(1.0 + taut * g1);
+        const double i2 = rcp_tol(1.0 + taut * g2);
         q1.x = (p1.x + taut * u1x) * i1;
         q1.y = (p1.y + taut * u1y) * i1;
         q2.x = (p2.x + taut * u2x) * i2;
@@ -386,7 +386,10 @@ __global__ __launch_bounds__(256) OFX_ITER1_ATTR void k_tvl1_iter(
 // same arithmetic, so results do not depend on the decomposition and stay bit-identical to the
 // one-iteration kernel.  HBM traffic per iteration drops from 15 to ~(9 (rows+3)/rows 64/60 + 6)/2
 // elements per pixel (8.3 at rows = 16).
+#ifndef STRIP2_OUT
 #define STRIP2_OUT 60
+#endif
+#define STRIP2_HALO ((64 - STRIP2_OUT) / 2)      // halo lanes each side: two are needed
 // waves per SIMD the fused kernel is compiled for (3: 130 VGPRs as the compiler likes it; 4: capped at
 // 128 VGPRs with a 3-dword spill).  The strip-height model below needs the same number.
 #ifndef OFX_ITER2_WAVES
@@ -534,10 +537,10 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
     const int ys = y0 > 0 ? y0 - 1 : 0;                      // first row loaded
     const int yl = (yend + 1 < ny - 1) ? yend + 1 : ny - 1;  // last row loaded
 
-    const int c = strip * STRIP2_OUT - 2 + lane;            // lanes 0,1 / 62,63 are halo columns
+    const int c = strip * STRIP2_OUT - STRIP2_HALO + lane;  // lanes 0,1 / 62,63 are halo columns
     const int cc = c < 0 ? 0 : (c > nx - 1 ? nx - 1 : c);
     const bool lef = (c == 0), rig = (c == nx - 1);
-    const bool owner = (lane >= 2) && (lane <= STRIP2_OUT + 1) && (c < nx);
+    const bool owner = (lane >= STRIP2_HALO) && (lane < STRIP2_OUT + STRIP2_HALO) && (c < nx);
 
     const unsigned E2 = 2 * sizeof(T);                      // bytes per pixel of the pair arrays
     const unsigned row2 = (unsigned) nx * E2;
@@ -568,16 +571,26 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
 // ---- three iterations per launch ------------------------------------------------------------------------------------------
 // The two-iteration kernel in tolerance mode is bound by its memory streams (6.0 - 6.3 TB/s by the counters, VALU 45 % active,
 // profiles/r03_pmc_group_launches.json).  A third fused iteration moves the same streams once per THREE iterations: six-stage
-// pipeline per loaded row y,   S1 u_A(y)  S2 p_A(y-1)  S3 u_B(y-2)  S4 p_B(y-3)  S5 u_C(y-4)  S6 p_C(y-5),   three halo lanes each
-// side (58 output columns), rows y0-2 .. yend+2 loaded.  HBM elements per pixel and iteration: (9 (rows+5)/rows 64/58 + 6) / 3
-// = 6.0 at 24 rows against 8.4 for two.  CNT < 3 runs only the first CNT iterations (the redo of a loop that ended inside a unit
-// and the tail unit of an iteration limit that is no multiple of 3): same stages, results stored after stage 2 CNT.
-#define STRIP3_OUT 58
+// pipeline per loaded row y,   S1 u_A(y)  S2 p_A(y-1)  S3 u_B(y-2)  S4 p_B(y-3)  S5 u_C(y-4)  S6 p_C(y-5),   rows y0-2 .. yend+2
+// loaded.  The dependency cone needs three halo lanes each side (58 output columns); the kernel takes FOUR and stores 56 columns:
+// 56 x 16 B = seven whole 128-byte lines per row and stream, where 58 columns left a partial line at both ends of every row
+// segment -- the launch's memory ceiling (OFX_CEIL_MEM: loads, stores and lane shifts, no arithmetic) 274 -> 249 us at 1080p x 5,
+// the launch itself 292 -> 277 us (profiles/r04_ab_iter3_alignment.txt).  HBM elements per pixel and iteration:
+// (9 (rows+5)/rows 64/56 + 6) / 3 = 5.9 at 32 rows against 8.4 for two.  CNT < 3 runs only the first CNT iterations (the redo of a
+// loop that ended inside a unit and the tail unit of an iteration limit that is no multiple of 3): same stages, results stored
+// after stage 2 CNT.
+#ifndef STRIP3_OUT
+#define STRIP3_OUT 56
+#endif
+#define STRIP3_HALO ((64 - STRIP3_OUT) / 2)      // halo lanes each side: three are needed
 // Measured and dropped (profiles/r03_q_ab_three_iterations_per_launch.txt): 2 waves per SIMD instead of 3 (same speed: the
 // launch is not bound by resident waves); the pipeline registers in row-indexed rings with a four-step loop body instead of
 // shifting ~50 doubles per step (v_mov_b64 119 -> 57 per step, 210 VGPRs: 1.5 % SLOWER -- VALU issue is not the bound either).
 #ifndef OFX_ITER3_WAVES
 #define OFX_ITER3_WAVES 3
+#endif
+#ifndef OFX_ITER3_PF
+#define OFX_ITER3_PF 1      // rows the loads run ahead of the stages
 #endif
 template <typename T, bool NT, bool STRICT, int CNT>
 OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const typename Pix<T>::v2 *__restrict__ P1in,
@@ -608,10 +621,26 @@ OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const
     const int hiB = (yend + CNT - 3 < nyl) ? yend + CNT - 3 : nyl;                  // last row of p_B
     const int hiC = (yend < nyl) ? yend : nyl;                                      // last row of u_C
     const int ylast = yend - 1 + (2 * CNT - 1);
+#ifdef OFX_CEIL_ALU
+    const unsigned off0 = off;
+#endif
 
+#if OFX_ITER3_PF == 2
+    RowIn<T> nx1 = cur;                                      // row ys + 1: the loads run two rows ahead of the stages
+    if (ys + 1 <= ylc) nx1 = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + row2);
+#endif
     auto step = [&](const int y) {
+#if OFX_ITER3_PF == 2
+        RowIn<T> nxt = nx1;
+        if (y + 2 <= ylc) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + 2 * row2);
+#else
         RowIn<T> nxt = cur;
+#ifdef OFX_CEIL_ALU   // ceiling experiment (tools/ceilings.sh): arithmetic kept, loads alternate between the strip's first two rows
+        if (y + 1 <= ylc) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off0 + ((y & 1) ? row2 : 0u));
+#else
         if (y + 1 <= ylc) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + row2);
+#endif
+#endif
         unsigned stu = OFX_OOB, stp = OFX_OOB;               // this step's stores: u (one row), p (the row above it)
         double2 su = z2, sp1 = z2, sp2 = z2;
 
@@ -681,6 +710,9 @@ OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const
             }
         }
         // the stores of this step: always issued, lanes / steps with nothing to write are out of range
+#ifdef OFX_CEIL_ALU
+        stu = OFX_OOB; stp = OFX_OOB;
+#endif
         bst2<NT>(rU, stu, su, Uout);
         bst2<NT>(rP1, stp, sp1, P1out);
         bst2<NT>(rP2, stp, sp2, P2out);
@@ -694,7 +726,12 @@ OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const
         uB2 = uB1; uB1 = uB0;
         pB2a = pB1a; pB2b = pB1b; pB1a = pBna; pB1b = pBnb;
         uC1 = uC0;
+#if OFX_ITER3_PF == 2
+        cur = nx1;
+        nx1 = nxt;
+#else
         cur = nxt;
+#endif
         off += row2;
         so += row2;
     };
@@ -752,10 +789,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFX_ITER3_W
     const int yend = (y0 + rows < ny) ? y0 + rows : ny;     // rows [y0, yend) are written by this wave
     const int ys = y0 > 2 ? y0 - 2 : 0;                      // first row loaded
     const int yl = (yend + 2 < ny - 1) ? yend + 2 : ny - 1;  // last row loaded
-    const int c = strip * STRIP3_OUT - 3 + lane;            // lanes 0..2 / 61..63 are halo columns
+    const int c = strip * STRIP3_OUT - STRIP3_HALO + lane;  // lanes 0..2 / 61..63 are halo columns
     const int cc = c < 0 ? 0 : (c > nx - 1 ? nx - 1 : c);
     const bool lef = (c == 0), rig = (c == nx - 1);
-    const bool owner = (lane >= 3) && (lane <= STRIP3_OUT + 2) && (c < nx);
+    const bool owner = (lane >= STRIP3_HALO) && (lane < STRIP3_OUT + STRIP3_HALO) && (c < nx);
     const unsigned E2 = 2 * sizeof(T);
     const unsigned row2 = (unsigned) nx * E2;
     const unsigned off = ((unsigned) ys * nx + cc) * E2;    // byte offset of (y, cc): loads
@@ -1209,13 +1246,23 @@ static int tvl1_run_iterations_tri(ofx_ctx *ctx, Tvl1Level<T> &L, const Tvl1Para
 static int tvl1_pick_rows3(const ofx_ctx *ctx, int nx, int ny, int G)
 {
     if (ctx->rows_per_wave3 > 0) return ctx->rows_per_wave3;
+    {   // A/B knob only: OFX_ROWS3="ny:rows/ny:rows" forces the strip height on the levels of the given heights
+        static const char *tab = getenv("OFX_ROWS3");
+        for (const char *q = tab; q && *q;) {
+            int lny = 0, r = 0;
+            if (sscanf(q, "%d:%d", &lny, &r) == 2 && lny == ny && r > 0) return r;
+            q = strchr(q, '/');
+            if (q) q++;
+        }
+    }
     const long strips_pad = (long) ofx_cdiv(ofx_cdiv(nx, STRIP3_OUT), 4) * 4 * G;
     const int rmax = 32;
     int best = rmax;
     long best_cost = -1;
     if (ctx->concurrency > 1) {
-        static const int cand[] = {2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32};
+        static const int cand[] = {2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 36, 40, 48, 54, 64, 72, 80, 96};
         for (int r : cand) {
+            if (r > ctx->rows3_max) break;
             const long waves = strips_pad * ofx_cdiv(ny, r);
             const long slots = ctx->rows_slots > 0 ? ctx->rows_slots : 1024;
             const long cost = ((waves + slots - 1) / slots) * (r + 7);

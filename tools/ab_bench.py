@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/ab_bench.py name=lib.so[,opt=val...] ... [--rounds N] [--args "..."]: A/B of library builds / options ON ONE BOX.
+"""tools/ab_bench.py name=lib.so[,opt=val...][,env:NAME=VALUE...] ... [--rounds N] [--args "..."]: A/B of library builds / options ON ONE BOX.
 Boxes differ by several per cent (clocks, silicon), so variants are only comparable inside one session: every round runs
 bench.py once per variant, in turn; prints value / fixed-work / roofline launch time / single-pair ms per run and the medians."""
 import json, os, statistics, subprocess, sys
@@ -23,7 +23,11 @@ for r in range(rounds):
             env["OFX_LIB_PATH"] = os.path.join(ROOT, parts[0])
         opts = []
         for o in parts[1:]:
-            opts += ["--opt", o]
+            if o.startswith("env:"):                       # env:NAME=VALUE -- an environment knob of the library
+                k, v = o[4:].split("=", 1)
+                env[k] = v.replace(";", ",")
+            else:
+                opts += ["--opt", o]
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"] + extra.split() + opts
         p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
         if p.returncode:
@@ -34,7 +38,8 @@ for r in range(rounds):
                "single_ms": d.get("single_pair", {}).get("device_resident", {}).get("ms_per_pair"),
                "host_ms": d.get("single_pair", {}).get("host_entry", {}).get("ms_per_pair"),
                "fixed_single": d.get("fixed_work", {}).get("single_pair", {}).get("value"),
-               "odd_stops": d.get("loop_ends", {}).get("odd_stops")}
+               "odd_stops": d.get("loop_ends", {}).get("odd_stops"), "strict": d.get("strict", {}).get("value"),
+               "launch2_us": d.get("roofline", {}).get("two_iterations_per_launch", {}).get("avg_launch_us")}
         res[name].append(rec)
         print(r, name, json.dumps(rec), flush=True)
 for name, v in res.items():
