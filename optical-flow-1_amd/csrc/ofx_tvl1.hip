@@ -583,14 +583,15 @@ __global__ OFX_ITER2_BOUNDS void k_tvl1_iter2(
 #define STRIP3_OUT 56
 #endif
 #define STRIP3_HALO ((64 - STRIP3_OUT) / 2)      // halo lanes each side: three are needed
+// Round 4 (profiles/r04_ab_iter3_alignment.txt, all on the 1080p x 5 launch): memory ceiling 266 us, ALU ceiling 219 us (256 at
+// 2 waves per SIMD -- which rules out a four-iteration kernel of ~205 VGPRs), production 291 us; measured and dropped: loads two
+// rows ahead (production + 7 %, ceiling + 4 %), non-temporal row loads (+ 9 %: the halo re-reads then miss), a workgroup barrier
+// per step to keep adjacent strips on the same row (+ 1 %), strips of 48 / 64 rows (no change).
 // Measured and dropped (profiles/r03_q_ab_three_iterations_per_launch.txt): 2 waves per SIMD instead of 3 (same speed: the
 // launch is not bound by resident waves); the pipeline registers in row-indexed rings with a four-step loop body instead of
 // shifting ~50 doubles per step (v_mov_b64 119 -> 57 per step, 210 VGPRs: 1.5 % SLOWER -- VALU issue is not the bound either).
 #ifndef OFX_ITER3_WAVES
 #define OFX_ITER3_WAVES 3
-#endif
-#ifndef OFX_ITER3_PF
-#define OFX_ITER3_PF 1      // rows the loads run ahead of the stages
 #endif
 template <typename T, bool NT, bool STRICT, int CNT>
 OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const typename Pix<T>::v2 *__restrict__ P1in,
@@ -625,21 +626,12 @@ OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const
     const unsigned off0 = off;
 #endif
 
-#if OFX_ITER3_PF == 2
-    RowIn<T> nx1 = cur;                                      // row ys + 1: the loads run two rows ahead of the stages
-    if (ys + 1 <= ylc) nx1 = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + row2);
-#endif
     auto step = [&](const int y) {
-#if OFX_ITER3_PF == 2
-        RowIn<T> nxt = nx1;
-        if (y + 2 <= ylc) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + 2 * row2);
-#else
         RowIn<T> nxt = cur;
 #ifdef OFX_CEIL_ALU   // ceiling experiment (tools/ceilings.sh): arithmetic kept, loads alternate between the strip's first two rows
         if (y + 1 <= ylc) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off0 + ((y & 1) ? row2 : 0u));
 #else
         if (y + 1 <= ylc) nxt = tvl1_load_row<T>(Uin, P1in, P2in, A, R, off + row2);
-#endif
 #endif
         unsigned stu = OFX_OOB, stp = OFX_OOB;               // this step's stores: u (one row), p (the row above it)
         double2 su = z2, sp1 = z2, sp2 = z2;
@@ -726,12 +718,7 @@ OFX_DEV void tvl1_iter3_march(const typename Pix<T>::v2 *__restrict__ Uin, const
         uB2 = uB1; uB1 = uB0;
         pB2a = pB1a; pB2b = pB1b; pB1a = pBna; pB1b = pBnb;
         uC1 = uC0;
-#if OFX_ITER3_PF == 2
-        cur = nx1;
-        nx1 = nxt;
-#else
         cur = nxt;
-#endif
         off += row2;
         so += row2;
     };
