@@ -320,8 +320,9 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None, mode="str
     if F == 3:
         roof["note"] = ("three fused iterations move the compulsory streams once per THREE iterations: `frac` (compulsory bytes per launch / "
                         "launch time / peak) is lower than the two-iteration kernel's although the iteration rate is ~30 % higher -- "
-                        "the launch is bound by FP64 issue, no longer by its streams (DESIGN 5.1d); `two_iterations_per_launch` is the "
-                        "same launch shape with option fuse3 = 0")
+                        "by its ceiling builds the launch follows its memory path (~5 TB/s of real traffic for this stream mix), FP64 issue "
+                        "25 % below it (DESIGN 5.1, profiles/r04_ab_iter3_alignment.txt); `two_iterations_per_launch` is the same "
+                        "launch shape with option fuse3 = 0")
     if group and F == 3:                                  # the same launch shape with two iterations per launch, for comparison
         ctx.set_option("fuse3", 0)
         ctx.set_option("profile", 1)
@@ -366,8 +367,9 @@ def roofline_of(ctx, solve_one, precision, nx, ny, passes, group=None, mode="str
         roof["valu_active"] = round(r3["valu_active_fraction"], 3)
         roof["limiter"] = ("strict kernel: co-limited by FP64 issue (VALU active 0.70) and memory (counter traffic 5.6-5.7 TB/s at the counter "
                            "pass's launch time)" if mode == "strict" else
-                           ("tolerance kernel, three iterations per launch: bound by FP64 issue (VALU active %.2f), streams at %.1f TB/s by "
-                            "the counters" % (r3["valu_active_fraction"], r3["counter_tb_per_s"])) if F == 3 else
+                           ("tolerance kernel, three iterations per launch: follows its memory path -- streams at %.1f TB/s by the counters, "
+                            "memory ceiling (no arithmetic) 266 us / ALU ceiling (cache-resident loads, no stores) 219 us / production "
+                            "291 us on one box at 1080p x 5; VALU active %.2f" % (r3["counter_tb_per_s"], r3["valu_active_fraction"])) if F == 3 else
                            "tolerance kernel: memory-bound -- counter traffic 6.0 (1080p) / 6.3 (4K) TB/s at the counter pass's launch time, "
                            "the rate the guide gives as achievable for HBM3E on this part; VALU active 0.45-0.48")
         levels = [{"size": "%dx%d" % (st.nx[s_], st.ny[s_]), "iter_us": round(lv_ms[s_] * 1e3 / max(lv_n[s_], 1), 2),

@@ -194,35 +194,6 @@ OFX_DEV double rcp_newton(double d)              // 1 / d to <= 1 ulp for normal
     e = __builtin_fma(-d, r, 1.0);
     return __builtin_fma(r, e, r);
 }
-// The tolerance / f32 arithmetic of the TV-L1 stages (not the strict one): ONE refinement step on the 2^-23 estimates of
-// v_rsq_f64 / v_rcp_f64 -- relative error ~2^-45, eleven orders of magnitude inside the AEPE bar -- instead of the two steps
-// + residual correction that make the last bit right.  Issue cost (tools/ubench/f64_issue.hip: a plain f64 instruction is 4
-// cycles per wave, v_rcp / v_rsq / v_sqrt_f64 16): square root 4 + 4 against 4 + 9 units, reciprocal 4 + 2 against 4 + 4.
-#ifndef OFX_TOL_NEWTON
-#define OFX_TOL_NEWTON 1
-#endif
-OFX_DEV double sqrt_tol(double x)
-{
-#if OFX_TOL_NEWTON >= 2
-    return sqrt_unscaled(x);
-#else
-    const double y = __builtin_amdgcn_rsq(x);
-    const double g = x * y;
-    const double h = y * 0.5;
-    const double r = __builtin_fma(-h, g, 0.5);
-    return __builtin_fma(g, r, g);
-#endif
-}
-OFX_DEV double rcp_tol(double d)
-{
-#if OFX_TOL_NEWTON >= 2
-    return rcp_newton(d);
-#else
-    const double r = __builtin_amdgcn_rcp(d);
-    const double e = __builtin_fma(-d, r, 1.0);
-    return __builtin_fma(r, e, r);
-#endif
-}
 OFX_DEV double div_unscaled(double n, double d)
 {
     double r = __builtin_amdgcn_rcp(d);

@@ -87,6 +87,36 @@ OFX_DEV RowIn<T> tvl1_load_row(const typename Pix<T>::v2 *U, const typename Pix<
     return r;
 }
 
+// The tolerance / f32 arithmetic of the TV-L1 stages (not the strict one): ONE refinement step on the 2^-23 estimates of
+// v_rsq_f64 / v_rcp_f64 -- relative error ~2^-45, eleven orders of magnitude inside the AEPE bar -- instead of the two steps
+// + residual correction that make the last bit right.  Issue cost (tools/ubench/f64_issue.hip: a plain f64 instruction is 4
+// cycles per wave, v_rcp / v_rsq / v_sqrt_f64 16): square root 4 + 4 against 4 + 9 units, reciprocal 4 + 2 against 4 + 4.
+#ifndef OFX_TOL_NEWTON
+#define OFX_TOL_NEWTON 1
+#endif
+OFX_DEV double sqrt_tol(double x)
+{
+#if OFX_TOL_NEWTON >= 2
+    return sqrt_unscaled(x);
+#else
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y;
+    const double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(g, r, g);
+#endif
+}
+OFX_DEV double rcp_tol(double d)
+{
+#if OFX_TOL_NEWTON >= 2
+    return rcp_newton(d);
+#else
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+#endif
+}
+
 // Stage "primal" at one pixel: thresholding TH (src/tvl1flow.cpp:117-143), divergence of p
 // (src/operators.cpp:35-78) and u = v + theta div p (:156-157).  l11/l21 = p11/p21 of the left pixel,
 // up12/up22 = p12/p22 of the pixel above.  Returns the new (u1,u2), rounded to the storage type.
