@@ -45,8 +45,8 @@ HBM_PEAK_GBS = 8000.0
 ARITH = {"strict": "f64 storage and arithmetic, every per-pixel operation in the reference's IEEE order (glibc-exact hypot, IEEE divisions): "
                    "flows and iteration tables bit-identical to the reference (tests/test_gpu_tvl1.py)",
          "tolerance": "f64 storage and arithmetic; in the dual update sqrt(x^2 + y^2) for libm's hypot and one reciprocal per denominator "
-                      "(rsq / rcp + Newton steps, <= 1 ulp each), primal division by reciprocal: not bit-identical -- AEPE vs the "
-                      "reference ~1e-12 px on every BASELINE config (profiles/r03_*_relaxed_dual_accuracy.jsonl, bar: 1e-4), iteration "
+                      "(v_rsq_f64 / v_rcp_f64 + one refinement step, ~2^-45 relative), primal division by reciprocal: not bit-identical -- AEPE vs the "
+                      "reference ~1e-12 px on every BASELINE config (this line's cpu_baseline.gpu_vs_this_reference_run; bar: 1e-4), iteration "
                       "tables equal on all of them"}
 WORKLOADS = {"1080p": (1920, 1080), "4k-batch": (3840, 2160)}
 
