@@ -1,4 +1,5 @@
 // tools/ubench/f64_issue.hip -- issue cost of the f64 VALU instructions the iteration kernels are made of (gfx950).
+// (the binary is git-ignored: build it in the container, it travels to the GPU box with the snapshot)
 // Each kernel runs REPS x 8 independent copies of one instruction per wave, W waves per SIMD; cycles per wave instruction =
 // elapsed s_memrealtime-free estimate: time / (REPS * 8 * W) * clock.  Build: hipcc -O3 --offload-arch=gfx950 -o f64_issue f64_issue.hip
 #include <hip/hip_runtime.h>
