@@ -28,6 +28,12 @@
 #include "ofx_device.h"
 #include "ofx_loop.h"
 
+// between the two colours of a pixel row: the wave's own LDS stores before its own loads (OFX_HST_FOUR_BARRIERS: the A/B build)
+#ifdef OFX_HST_FOUR_BARRIERS
+#define HST_PAIR_SYNC() __syncthreads()
+#else
+#define HST_PAIR_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#endif
 #define HST_SOR_W 1.9                // src/horn_schunck_pyramidal.cpp:21
 #define HST_W 128                    // tile width in pixels
 #define HST_CW 64                    // ... in cells = lanes of a wave
@@ -325,12 +331,17 @@ __global__ __launch_bounds__(64 * NW) void k_hs_tile(typename Pix<T>::v2 *U0, ty
     __syncthreads();
 #pragma unroll 1
     for (int s = 0; s < niter; s++) {
+        // Two barriers per sweep, not four.  A pixel of colour (0,1) reads the NEW (0,0) values only of its own pixel row -- its
+        // own cell and the next cell column, i.e. its own wave (lane = cell column), whose LDS stores and loads are executed in
+        // order --; everything it reads from other cell rows, hence other waves, is colour (1,0) / (1,1), which nobody writes
+        // before the next barrier (mirrors included: the apron of a border pixel is read by the pixels of that pixel's own row).
+        // The same holds for (1,0) -> (1,1).  Fewer, longer phases between barriers: the waves' LDS bursts no longer coincide.
         double e = hst_colour_step<T, K, TH, NW, 0, 0>(s_u, w, lane, x0, y0, nx, ny, s, u, kf, fl, alpha2);
-        __syncthreads();
+        HST_PAIR_SYNC();
         e += hst_colour_step<T, K, TH, NW, 0, 1>(s_u, w, lane, x0, y0, nx, ny, s, u, kf, fl, alpha2);
         __syncthreads();
         e += hst_colour_step<T, K, TH, NW, 1, 0>(s_u, w, lane, x0, y0, nx, ny, s, u, kf, fl, alpha2);
-        __syncthreads();
+        HST_PAIR_SYNC();
         e += hst_colour_step<T, K, TH, NW, 1, 1>(s_u, w, lane, x0, y0, nx, ny, s, u, kf, fl, alpha2);
         __syncthreads();
         loop_accumulate(err, slot0 + (check ? s : 0), e, blockIdx.x * NW + w);
