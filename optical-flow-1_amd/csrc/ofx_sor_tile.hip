@@ -13,7 +13,8 @@
 // every colour).  Lane = cell column, wave w owns cell rows w, w + 4, ...; a thread keeps the unknowns and the constant
 // operands (A, dif) of its cells in registers for the whole launch and publishes the unknowns in LDS, one plane per
 // colour, so that the eight neighbours of a pixel are eight conflict-free 16-byte reads at fixed offsets.  One colour
-// step = read neighbours, update, write own plane, barrier.  The dependency cone of one sweep is 4 pixels in x and 2 in
+// step = read neighbours, update, write own plane; a workgroup barrier after every SECOND step (the two colours of a pixel
+// row only exchange values inside a wave, see the sweep loop of k_hs_tile).  The dependency cone of one sweep is 4 pixels in x and 2 in
 // y (colour (1,1) sees (1,0) sees (0,1) sees (0,0) horizontally, vertically only two links), so K sweeps need a halo of
 // 4 K columns and 2 K rows that is recomputed, not exchanged: the workgroup loads the tile once, runs K sweeps and
 // stores the inner (128 - 8 K) x (TH - 4 K) pixels.  Sweep s only updates the part of the tile that can still reach
